@@ -1,0 +1,443 @@
+/*
+ * kbe_oracle.c -- CPU restatement of the reference's novel-view render kernels.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call it; the product path
+ * (ken-burns-effect_amd/) never does and has no CPU fallback.
+ *
+ * Each function restates one piece of /root/reference/utils/common.py (the CUDA kernel
+ * strings and the torch glue around them) in plain C, serial, in point-/pixel-index order,
+ * and cites the lines it follows.  Parity pin: tests/test_oracle_golden.py checks every
+ * function bit-for-bit against the .npz files under tests/golden, which tests/golden/make_golden.py
+ * produced by executing the reference itself in the build container (torch parts imported
+ * directly; kernel text compiled unmodified for the host and run in index order).
+ *
+ * Floating-point contract: kernel literals without suffix are
+ * doubles, so a few sub-expressions are evaluated in fp64 and rounded once; everything
+ * else is fp32 with one rounding per operation.  Build with -ffp-contract=off; the single
+ * place where the reference as compiled by NVRTC (--fmad=true) fuses a multiply-add,
+ * x + dist * (-x), is written as an explicit fmaf and selectable through `use_fma`
+ * (1 = normative, what the HIP kernels implement; 0 = two roundings, kept to show fidelity
+ * to the "nofma" golden vectors).
+ *
+ * Layouts are the reference's: points [B,3,N], data [B,C,N], zee [B,1,H,W],
+ * acc [B,C+1,H,W], images [B,C,H,W]; all contiguous fp32.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KBO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------ */
+/* projection shared by updateZee and updateOutput (common.py:447-484 == :599-636)       */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    float err;          /* dblError */
+    int x[4], y[4];     /* NW, NE, SW, SE corner coordinates */
+    float w[4];         /* dblNorthwest, dblNortheast, dblSouthwest, dblSoutheast */
+} kbo_proj;
+
+/* returns 0 when the point is dropped before any pixel is touched */
+static int kbo_project(float px, float py, float pz, double focal, double baseline,
+                       int W, int H, int use_fma, kbo_proj* p)
+{
+    /* common.py:453  if (dblLinePoint.z < 0.001) return;   (double compare) */
+    if (!((double) pz >= 0.001)) return 0;
+    /* common.py:447-451: plane point (0,0,F) with F a double literal narrowed to float;
+       line vector = (0,0,0) - P */
+    const float F_f = (float) focal;
+    const float lvx = 0.0f - px, lvy = 0.0f - py, lvz = 0.0f - pz;
+    /* common.py:457-459: dot products against the normal (0,0,1) collapse to the z terms */
+    const float num = F_f - pz;
+    const float den = lvz;
+    const float dist = num / den;
+    /* common.py:461  if (fabs(den) < 0.001) return;  -- same set as the first cull */
+    if ((double) fabsf(den) < 0.001) return 0;
+    /* common.py:465  P + dist * lineVector  (helper_math.h operator*(float,float3), operator+) */
+    float ix, iy;
+    if (use_fma) { ix = fmaf(dist, lvx, px); iy = fmaf(dist, lvy, py); }
+    else { float tx = dist * lvx, ty = dist * lvy; ix = px + tx; iy = py + ty; }
+    /* common.py:467-468  float = float + (0.5 * SIZE) - 0.5  evaluated left to right in double */
+    const float ox = (float) (((double) ix + 0.5 * (double) W) - 0.5);
+    const float oy = (float) (((double) iy + 0.5 * (double) H) - 0.5);
+    /* common.py:470  1000000.0 - ((F * B) / (z + 0.0000001)), all double, one rounding */
+    p->err = (float) (1000000.0 - ((focal * baseline) / ((double) pz + 0.0000001)));
+    /* float -> int of a value outside int range (or NaN) is platform-defined in the reference
+       (x86 0x80000000, GPU saturates / NaN -> 0).  In every such case all four corners are
+       out of the image on both platforms, except NaN on a GPU; inputs are required to be
+       finite and non-finite projections are dropped here (documented in DESIGN.md). */
+    if (!(fabsf(ox) < 1.0e9f) || !(fabsf(oy) < 1.0e9f)) return 0;
+    /* common.py:472-479 */
+    const int nwx = (int) floorf(ox), nwy = (int) floorf(oy);
+    p->x[0] = nwx;     p->y[0] = nwy;
+    p->x[1] = nwx + 1; p->y[1] = nwy;
+    p->x[2] = nwx;     p->y[2] = nwy + 1;
+    p->x[3] = nwx + 1; p->y[3] = nwy + 1;
+    /* common.py:481-484  (int - float) promotes the int to float */
+    p->w[0] = ((float) p->x[3] - ox) * ((float) p->y[3] - oy);
+    p->w[1] = (ox - (float) p->x[2]) * ((float) p->y[2] - oy);
+    p->w[2] = ((float) p->x[1] - ox) * (oy - (float) p->y[1]);
+    p->w[3] = (ox - (float) p->x[0]) * (oy - (float) p->y[0]);
+    (void) H;
+    return 1;
+}
+
+/* common.py:486-506: the first of NW, NE, SW, SE whose weight is >= the other three */
+static int kbo_winner(const kbo_proj* p)
+{
+    const float nw = p->w[0], ne = p->w[1], sw = p->w[2], se = p->w[3];
+    if ((nw >= ne) & (nw >= sw) & (nw >= se)) return 0;
+    if ((ne >= nw) & (ne >= sw) & (ne >= se)) return 1;
+    if ((sw >= nw) & (sw >= ne) & (sw >= se)) return 2;
+    if ((se >= nw) & (se >= ne) & (se >= sw)) return 3;
+    return -1;
+}
+
+static int kbo_inside(int x, int y, int W, int H)
+{
+    return (x >= 0) & (x < W) & (y >= 0) & (y < H);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kernel_pointrender_updateZee  (common.py:435-507), zee pre-filled by kbo_fill_zee      */
+/* `winner` (optional, [B,N] int32) receives the linear pixel index y*W+x that the point  */
+/* min-splats to, or -1 -- the "z-buffer index" of the parity contract.                   */
+/* ------------------------------------------------------------------------------------ */
+KBO_API void kbo_zsplat(const float* points, int B, int N, int W, int H, double focal,
+                        double baseline, int use_fma, float* zee, int32_t* winner)
+{
+    for (int b = 0; b < B; b++) {
+        const float* P = points + (size_t) b * 3 * N;
+        float* Z = zee + (size_t) b * H * W;
+        for (int i = 0; i < N; i++) {
+            kbo_proj p;
+            int idx = -1;
+            if (kbo_project(P[i], P[N + i], P[2 * (size_t) N + i], focal, baseline, W, H, use_fma, &p)) {
+                const int c = kbo_winner(&p);
+                if (c >= 0 && kbo_inside(p.x[c], p.y[c], W, H)) {
+                    idx = p.y[c] * W + p.x[c];
+                    /* atomicMin(float) via CAS loop, common.py:275-283: plain float min */
+                    if (Z[idx] > p.err) Z[idx] = p.err;
+                }
+            }
+            if (winner) winner[(size_t) b * N + i] = idx;
+        }
+    }
+}
+
+/* common.py:430  tensorZee ... .fill_(1000000.0) */
+KBO_API void kbo_fill_zee(float* zee, size_t n)
+{
+    for (size_t i = 0; i < n; i++) zee[i] = 1000000.0f;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kernel_pointrender_updateDegrid (common.py:525-568)                                    */
+/* One pixel: reads `src` (centre + 8 neighbours), returns the new centre value.          */
+/* ------------------------------------------------------------------------------------ */
+static float kbo_degrid_pixel(const float* src, int x, int y, int W, int H)
+{
+    static const int ox[4] = { 1, 0, 1, 1 };    /* common.py:539 */
+    static const int oy[4] = { 0, 1, 1, -1 };   /* common.py:540 */
+    const float c = src[y * W + x];
+    int count = 0;
+    float sum = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
+        if (!kbo_inside(x1, y1, W, H)) continue;    /* :548 */
+        if (!kbo_inside(x2, y2, W, H)) continue;    /* :551 */
+        const float a = src[y1 * W + x1], d = src[y2 * W + x2];
+        /* :556-557  float >= float + 1.0  -> double compare */
+        if ((double) c >= (double) a + 1.0) {
+            if ((double) c >= (double) d + 1.0) {
+                count += 2;
+                sum += a;       /* :559 */
+                sum += d;       /* :560 */
+            }
+        }
+    }
+    if (count > 0) return fminf(c, sum / (float) count);    /* :566 */
+    return c;
+}
+
+/* The reference text executed one thread after the other in index order (Gauss-Seidel):
+   the schedule the golden vectors were produced with.  In place. */
+KBO_API void kbo_degrid_serial(float* zee, int B, int W, int H)
+{
+    for (int b = 0; b < B; b++) {
+        float* Z = zee + (size_t) b * H * W;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                Z[y * W + x] = kbo_degrid_pixel(Z, x, y, W, H);
+    }
+}
+
+/* Out-of-place (Jacobi): every read sees the pre-degrid buffer.  A legal outcome of the
+   racy reference kernel and the normative schedule of the HIP path. */
+KBO_API void kbo_degrid_jacobi(const float* zee_in, float* zee_out, int B, int W, int H)
+{
+    for (int b = 0; b < B; b++) {
+        const float* S = zee_in + (size_t) b * H * W;
+        float* D = zee_out + (size_t) b * H * W;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                D[y * W + x] = kbo_degrid_pixel(S, x, y, W, H);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kernel_pointrender_updateOutput (common.py:586-669).  acc is [B,C+1,H,W], zero-filled  */
+/* by the caller (common.py:431); channel C accumulates the bilinear weights (the `ones`  */
+/* channel appended at common.py:429).  Summation in point-index order.                   */
+/* ------------------------------------------------------------------------------------ */
+KBO_API void kbo_accumulate(const float* points, const float* data, int B, int N, int C,
+                            const float* zee, int W, int H, double focal, double baseline,
+                            int use_fma, float* acc)
+{
+    const size_t HW = (size_t) H * W;
+    for (int b = 0; b < B; b++) {
+        const float* P = points + (size_t) b * 3 * N;
+        const float* D = data + (size_t) b * C * N;
+        const float* Z = zee + (size_t) b * HW;
+        float* A = acc + (size_t) b * (C + 1) * HW;
+        for (int i = 0; i < N; i++) {
+            kbo_proj p;
+            if (!kbo_project(P[i], P[N + i], P[2 * (size_t) N + i], focal, baseline, W, H, use_fma, &p)) continue;
+            for (int c = 0; c < 4; c++) {
+                if (!kbo_inside(p.x[c], p.y[c], W, H)) continue;                /* :638 */
+                const size_t px = (size_t) p.y[c] * W + p.x[c];
+                if (!((double) p.err <= (double) Z[px] + 1.0)) continue;         /* :639 */
+                for (int ch = 0; ch < C; ch++) {
+                    const float v = D[(size_t) ch * N + i] * p.w[c];             /* :641 product rounded, */
+                    A[ch * HW + px] = A[ch * HW + px] + v;                       /*      then atomicAdd   */
+                }
+                A[C * HW + px] = A[C * HW + px] + 1.0f * p.w[c];
+            }
+        }
+    }
+}
+
+/* common.py:686  output[:, :-1] / (output[:, -1:] + 0.0000001), output[:, -1:].clone() */
+KBO_API void kbo_normalize(const float* acc, int B, int C, int W, int H, float* render, float* existing)
+{
+    const size_t HW = (size_t) H * W;
+    for (int b = 0; b < B; b++) {
+        const float* A = acc + (size_t) b * (C + 1) * HW;
+        for (size_t px = 0; px < HW; px++) {
+            const float wsum = A[C * HW + px];
+            const float den = wsum + 0.0000001f;
+            for (int ch = 0; ch < C; ch++) render[((size_t) b * C + ch) * HW + px] = A[ch * HW + px] / den;
+            existing[(size_t) b * HW + px] = wsum;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kernel_discfill_updateOutput (common.py:838-924); output pre-filled with input (:834)  */
+/* ------------------------------------------------------------------------------------ */
+KBO_API void kbo_fill_disocclusion(const float* input, const float* depth, int B, int C, int W,
+                                   int H, float* output)
+{
+    /* common.py:859-867: direction table normalised in fp32 */
+    float dirx[16] = { -1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3 };
+    float diry[16] = { 1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2 };
+    for (int d = 0; d < 16; d++) {
+        const float n = sqrtf((dirx[d] * dirx[d]) + (diry[d] * diry[d]));
+        dirx[d] /= n;
+        diry[d] /= n;
+    }
+    const size_t HW = (size_t) H * W;
+    memcpy(output, input, sizeof(float) * (size_t) B * C * HW);
+    for (int b = 0; b < B; b++) {
+        const float* Dp = depth + (size_t) b * HW;
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            if (Dp[y * W + x] > 0.0f) continue;                 /* :850 */
+            float shortest = 1000000.0f;
+            int fx = -1, fy = -1;
+            for (int d = 0; d < 16; d++) {
+                float ax = (float) x, ay = (float) y, bx = (float) x, by = (float) y;
+                int iax = 0, iay = 0, ibx = 0, iby = 0;
+                for (;;) {                                      /* :876-883 walk against the direction */
+                    ax -= dirx[d]; iax = (int) roundf(ax);
+                    ay -= diry[d]; iay = (int) roundf(ay);
+                    if ((iax < 0) | (iax >= W)) break;
+                    if ((iay < 0) | (iay >= H)) break;
+                    if (Dp[iay * W + iax] > 0.0f) break;
+                }
+                if ((iax < 0) | (iax >= W)) continue;           /* :884-885 */
+                if ((iay < 0) | (iay >= H)) continue;
+                for (;;) {                                      /* :887-894 walk along the direction */
+                    bx += dirx[d]; ibx = (int) roundf(bx);
+                    by += diry[d]; iby = (int) roundf(by);
+                    if ((ibx < 0) | (ibx >= W)) break;
+                    if ((iby < 0) | (iby >= H)) break;
+                    if (Dp[iby * W + ibx] > 0.0f) break;
+                }
+                if ((ibx < 0) | (ibx >= W)) continue;           /* :895-896 */
+                if ((iby < 0) | (iby >= H)) continue;
+                /* :898  sqrt(powf(dx, 2) + powf(dy, 2)) -- exact small integers */
+                const float ddx = (float) (ibx - iax), ddy = (float) (iby - iay);
+                const float dist = sqrtf(ddx * ddx + ddy * ddy);
+                if (shortest > dist) {                          /* :900 strictly shorter */
+                    fx = iax; fy = iay;
+                    if (Dp[iay * W + iax] < Dp[iby * W + ibx]) { fx = ibx; fy = iby; }   /* :904 farther end */
+                    shortest = dist;
+                }
+            }
+            if (fx == -1 || fy == -1) continue;                 /* :913-919 */
+            for (int ch = 0; ch < C; ch++)                      /* :921-923 copy from INPUT */
+                output[((size_t) b * C + ch) * HW + (size_t) y * W + x] =
+                    input[((size_t) b * C + ch) * HW + (size_t) fy * W + fx];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* torch glue restated                                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+/* torch.linspace(-0.5*n + 0.5, 0.5*n - 0.5, n)[i] in fp32 (symmetric evaluation, as
+   ATen's linspace kernel does: from the start for the first half, from the end after). */
+static float kbo_linspace(int n, int i)
+{
+    const float start = (float) ((-0.5 * n) + 0.5), end = (float) ((0.5 * n) - 0.5);
+    if (n == 1) return start;
+    const float step = (end - start) / (float) (n - 1);
+    return (i < n / 2) ? start + step * (float) i : end - step * (float) (n - 1 - i);
+}
+
+/* depth_to_points (common.py:382-392): [B,1,H,W] -> [B,3,H,W] */
+KBO_API void kbo_depth_to_points(const float* depth, int B, int W, int H, double focal, float* points)
+{
+    const float inv = (float) (1.0 / focal);     /* python double scalar narrowed by torch */
+    const size_t HW = (size_t) H * W;
+    for (int b = 0; b < B; b++)
+        for (int y = 0; y < H; y++) {
+            const float v = kbo_linspace(H, y) * inv;
+            for (int x = 0; x < W; x++) {
+                const float u = kbo_linspace(W, x) * inv;
+                const float d = depth[b * HW + (size_t) y * W + x];
+                points[((size_t) b * 3 + 0) * HW + (size_t) y * W + x] = d * u;
+                points[((size_t) b * 3 + 1) * HW + (size_t) y * W + x] = d * v;
+                points[((size_t) b * 3 + 2) * HW + (size_t) y * W + x] = d;
+            }
+        }
+}
+
+/* process_shift tensor part (common.py:104-109): x *= z / (z + 1e-7); y likewise; += shift */
+KBO_API void kbo_shift_points(const float* points, int B, int N, const float* shift3, float* out)
+{
+    for (int b = 0; b < B; b++) {
+        const float* P = points + (size_t) b * 3 * N;
+        float* O = out + (size_t) b * 3 * N;
+        for (int i = 0; i < N; i++) {
+            const float z = P[2 * (size_t) N + i];
+            const float r = z / (z + 0.0000001f);
+            const float x = P[i] * r, y = P[N + i] * r;
+            O[i] = x + shift3[0];
+            O[N + i] = y + shift3[1];
+            O[2 * (size_t) N + i] = z + shift3[2];
+        }
+    }
+}
+
+static int kbo_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int kbo_reflect(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * (n - 1) - v; return v; }
+
+/* spatial_filter 'laplacian' (common.py:397-409): replicate pad 1, per-channel 3x3 with the
+   reference's ASYMMETRIC taps [0][1]=-1 [0][2]=-1 [1][0]=-1 [1][1]=4 [2][0]=-1.
+   Summation order is ours (row-major taps, fmaf); torch/cuDNN's is unspecified, so parity
+   with the reference is to ~1e-6 relative, not bitwise (tests state the tolerance). */
+KBO_API void kbo_laplacian(const float* in, int planes, int W, int H, float* out)
+{
+    for (int p = 0; p < planes; p++) {
+        const float* I = in + (size_t) p * H * W;
+        float* O = out + (size_t) p * H * W;
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            const int ym = kbo_clampi(y - 1, 0, H - 1), yp = kbo_clampi(y + 1, 0, H - 1);
+            const int xm = kbo_clampi(x - 1, 0, W - 1), xp = kbo_clampi(x + 1, 0, W - 1);
+            float a = 0.0f;
+            a = fmaf(-1.0f, I[ym * W + x], a);
+            a = fmaf(-1.0f, I[ym * W + xp], a);
+            a = fmaf(-1.0f, I[y * W + xm], a);
+            a = fmaf(4.0f, I[y * W + x], a);
+            a = fmaf(-1.0f, I[yp * W + xm], a);
+            O[y * W + x] = a;
+        }
+    }
+}
+
+static int kbo_cmpf(const void* a, const void* b)
+{
+    const float x = *(const float*) a, y = *(const float*) b;
+    return (x > y) - (x < y);
+}
+
+/* spatial_filter 'median-3' / 'median-5' (common.py:411-421): reflect pad, k*k window,
+   torch.median = the lower middle element = sorted[(k*k - 1) / 2]. */
+KBO_API void kbo_median(const float* in, int planes, int W, int H, int k, float* out)
+{
+    const int r = k / 2;
+    float win[25];
+    for (int p = 0; p < planes; p++) {
+        const float* I = in + (size_t) p * H * W;
+        float* O = out + (size_t) p * H * W;
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            int n = 0;
+            for (int dy = -r; dy <= r; dy++) for (int dx = -r; dx <= r; dx++)
+                win[n++] = I[kbo_reflect(y + dy, H) * W + kbo_reflect(x + dx, W)];
+            qsort(win, (size_t) n, sizeof(float), kbo_cmpf);
+            O[y * W + x] = win[(n - 1) / 2];
+        }
+    }
+}
+
+/* common.py:255  (x * 255.0).clip(0.0, 255.0).astype(np.uint8) on render[0, 0:3] transposed
+   to HWC: fp32 product, clamp, truncation toward zero.  in: [C>=3,H,W] plane-major. */
+KBO_API void kbo_frame_u8(const float* render, int W, int H, uint8_t* frame_hwc)
+{
+    const size_t HW = (size_t) H * W;
+    for (size_t px = 0; px < HW; px++)
+        for (int ch = 0; ch < 3; ch++) {
+            float v = render[ch * HW + px] * 255.0f;
+            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+            frame_hwc[px * 3 + ch] = (uint8_t) v;
+        }
+}
+
+/* PartialConv2d mask bookkeeping (utils/partial_conv.py:62-77), multi_channel=True.
+   msum[b,oy,ox] = sum over Cin*k*k window of mask (zero pad) -- identical for every output
+   channel because weight_maskUpdater is all ones (:33); then
+     ratio = winsize / (msum + 1e-8); um = clamp(msum, 0, 1); ratio *= um
+     out   = ((raw - bias) * ratio + bias) * um
+   raw/out: [B,Cout,Ho,Wo]; mask: [B,Cin,H,W]; um: [B,1,Ho,Wo] (the reference materialises
+   Cout identical copies). */
+KBO_API void kbo_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin,
+                                int H, int W, int Cout, int Ho, int Wo, int k, int stride, int pad,
+                                float* out, float* um_out)
+{
+    const float winsize = (float) (Cin * k * k);
+    for (int b = 0; b < B; b++)
+        for (int oy = 0; oy < Ho; oy++) for (int ox = 0; ox < Wo; ox++) {
+            float msum = 0.0f;
+            for (int ci = 0; ci < Cin; ci++)
+                for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) {
+                    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                    msum += mask[(((size_t) b * Cin + ci) * H + iy) * W + ix];
+                }
+            float ratio = winsize / (msum + 1e-8f);
+            const float um = msum < 0.0f ? 0.0f : (msum > 1.0f ? 1.0f : msum);
+            ratio = ratio * um;
+            um_out[((size_t) b * Ho + oy) * Wo + ox] = um;
+            for (int co = 0; co < Cout; co++) {
+                const size_t o = (((size_t) b * Cout + co) * Ho + oy) * Wo + ox;
+                const float bv = bias ? bias[co] : 0.0f;
+                float v = bias ? ((raw[o] - bv) * ratio + bv) * um : raw[o] * ratio;
+                out[o] = v;
+            }
+        }
+}
