@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the novel-view frame loop (BASELINE.json: frames/sec at 1024x1024, scatter HBM GB/s).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one output frame of the reference's process_kenburns loop body
+(/root/reference/utils/common.py:222-260): camera shift -> forward-warp of the resident point
+cloud (z-splat, degrid, z-tested bilinear accumulate) -> disocclusion fill -> uint8 ->
+centred crop + resize -> the finished frame landing in (pinned) host memory.  The point cloud
+is resident in HBM when the timed region starts; frames are sharded over ranks (rank r renders
+steps r, r+N, ... of an N*K-step path; the one RCCL broadcast of the cloud is inside the timed
+region).  Synthetic seeded RGBD input (no datasets / checkpoints are reachable offline).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel:
+algorithmic bytes / HIP-event time, measured live) and `cpu_baseline` (the CPU oracle timed
+on this host, rank 0 at N=1 only -- the oracle is used here as the baseline, never as the
+product path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def build_scene(size, device, inpaint):
+    """objectCommon for a seeded synthetic size x size RGBD image."""
+    from ken_burns_effect_amd import _native, common, synthetic
+    K = _native.kernels()
+    image, disp = synthetic.make_rgbd(size, size, seed=0)
+    depth = (synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)
+    oc = {'dblFocal': synthetic.FOCAL, 'dblBaseline': synthetic.BASELINE, 'intWidth': size, 'intHeight': size,
+          'dblDispmin': float(disp.min()), 'dblDispmax': float(disp.max()),
+          'objectDepthrange': synthetic.depthrange_of(depth), 'tensorRawImage': image.to(device),
+          'tensorRawDisparity': disp.to(device), 'tensorRawDepth': depth.to(device)}
+    oc['tensorRawPoints'] = K.depth_to_points(oc['tensorRawDepth'], synthetic.FOCAL).view(1, 3, -1)
+    common._reset_inpa(oc)
+    return oc
+
+
+def time_kernels(oc, cams, reps=30):
+    """Average duration of each frame kernel from HIP events on the launch stream: `reps`
+    back-to-back launches of the same kernel between two events (so each figure includes one
+    same-stream kernel boundary, ~1.5 us).  Returns {name: seconds}."""
+    from ken_burns_effect_amd import _native
+    K = _native.kernels()
+    W, H, N = oc['intWidth'], oc['intHeight'], oc['tensorInpaPoints'].shape[-1]
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H)
+    focal, shift3 = cams[len(cams) // 2]
+    Bl = oc['dblBaseline']
+    pts = state['cloud7'][0:3].unsqueeze(0)
+    data = state['cloud7'][3:7].unsqueeze(0)
+    zkeys, _ = K.zsplat(pts, W, H, focal, Bl, shift3)
+    zee = K.degrid(zkeys=zkeys)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    import ctypes
+    lib = K.lib
+    P = _native._ptr
+    st = _native._stream
+    sh = _native._shift(shift3)
+    acc = state['acc']
+    i32 = torch.int32
+    out = {}
+    out['zsplat'] = timed(lambda: lib.kbe_zsplat(P(pts), 1, N, W, H, ctypes.c_double(focal), ctypes.c_double(Bl), sh,
+                                                 P(zkeys, i32), None, st()))
+    out['degrid'] = timed(lambda: lib.kbe_degrid(P(zkeys, i32), None, 1, W, H, P(zee), st()))
+    out['accumulate'] = timed(lambda: lib.kbe_accumulate(P(pts), P(data), 1, N, 4, P(zee), W, H, ctypes.c_double(focal),
+                                                         ctypes.c_double(Bl), sh, P(acc), st()))
+    out['frame'] = timed(lambda: K.render_frame(state, shift3, focal, Bl))
+    return out
+
+
+def cpu_baseline(oc, cams, crop, budget_s=20.0):
+    """The CPU oracle (oracle/kbe_oracle.c, single thread) rendering the same frames on this host."""
+    from oracle import kbe_oracle
+    ok = kbe_oracle.OracleKernels(schedule='jacobi')
+    W, H = oc['intWidth'], oc['intHeight']
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), W, H)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    n = 0
+    while n < len(cams) and (n < 2 or time.perf_counter() - t0 < budget_s):
+        focal, shift3 = cams[(n * 7) % len(cams)]
+        frame = ok.render_frame(state, shift3, focal, oc['dblBaseline'])
+        if crop is not None:
+            ok.crop_resize_u8(frame, crop[0], crop[1])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d frames of the same %dx%d workload, oracle/kbe_oracle.c single-threaded (host has %d cores)'
+                      % (n, W, H, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--dolly', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-crop', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world_size == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world_size)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world_size > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=device)
+
+    from ken_burns_effect_amd import common, sharding, synthetic
+
+    size = args.size
+    ofrom, oto = synthetic.default_windows(size, size, args.dolly)
+    total_steps = args.steps * world_size
+    settings = {'dblSteps': np.linspace(0.0, 1.0, max(total_steps, 2)).tolist()[:total_steps], 'objectFrom': ofrom,
+                'objectTo': oto, 'boolInpaint': False, 'dolly': args.dolly}
+    crop = None if args.no_crop else common.crop_size(settings)
+
+    # rank 0 owns the scene; other ranks receive the cloud through the broadcast below
+    oc = build_scene(size, device, inpaint=False) if rank == 0 else {}
+    if world_size > 1:
+        sharding.broadcast_cloud(oc, device)          # untimed warm-up of the communicator + fills `oc` everywhere
+    n_points = oc['tensorInpaPoints'].shape[-1]
+    _, my_steps = sharding.shard_steps(settings['dblSteps'], rank, world_size)
+    cams = common.frame_cameras(dict(settings, dblSteps=my_steps), oc)
+
+    # warm-up (untimed)
+    common.render_frames(cams[:max(args.warmup, 1)], oc, crop)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    if world_size > 1:
+        sharding.broadcast_cloud(oc, device)          # the one exchange step of a video, inside the timed region
+    frames = common.render_frames(cams, oc, crop)       # K frames -> pinned host memory, one sync at the end
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert frames.shape == (args.steps, size, size, 3)
+
+    if rank == 0:
+        kt = time_kernels(oc, cams)
+        HW = size * size
+        # algorithmic bytes of the scatter (render_pointcloud, C = 4) per frame: SURVEY.md 8d
+        scatter_bytes = 28 * n_points + 20 * HW
+        acc_bytes = 28 * n_points + 4 * HW + 20 * HW      # accumulate kernel alone: points+data in, zee in, acc out
+        dom = 'accumulate'
+        achieved = acc_bytes / kt[dom] / 1e9
+        line = {
+            'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
+            'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%dx%d %s camera path, %d points, per frame: shift+zsplat+degrid+accumulate+fill+u8%s+D2H'
+                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, '' if crop is None else '+crop/resize'),
+                       'frames_per_rank': args.steps, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': acc_bytes,
+                         'kernel_us': {k: v * 1e6 for k, v in kt.items()},
+                         'scatter_GBps': scatter_bytes / (kt['zsplat'] + kt['degrid'] + kt['accumulate']) / 1e9},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(oc, cams, crop)
+        print(json.dumps(line), flush=True)
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

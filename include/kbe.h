@@ -1,0 +1,168 @@
+/*
+ * kbe.h -- C ABI of libkbe_hip.so, the MI355X (gfx950) novel-view render kernels.
+ *
+ * What this replaces.  The reference has no FFI layer; its de-facto kernel boundary is
+ *     launch_kernel(name, preprocess_kernel(src, vars))(grid, block, args=[n, ptr...], stream)
+ * (/root/reference/utils/common.py:267-380, call sites :516-521, :578-582, :680-684, :930-934):
+ * CUDA source strings JIT-compiled by CuPy/NVRTC per (shape, focal, baseline) and launched on
+ * raw `tensor.data_ptr()` device pointers on torch's current stream.  Every entry point below
+ * is the compiled-once equivalent of one such launch (or of the torch glue between two of
+ * them): plain device pointers, sizes as runtime ints, focal/baseline as `double` (they are
+ * pasted into the reference kernels as double literals and take part in fp64 sub-expressions,
+ * SURVEY.md Appendix B), and the HIP stream the work is enqueued on.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers to contiguous fp32 (unless typed otherwise) in the
+ *     reference's layouts: points [B,3,N], data [B,C,N], z-buffer [B,1,H,W], images [B,C,H,W].
+ *   - The caller owns every buffer, including scratch; nothing here allocates, frees or
+ *     synchronises.  All launches are asynchronous on `stream` (a hipStream_t; NULL = default).
+ *   - Return value: KBE_OK, or a negative KBE_E_* for invalid arguments / launch failures
+ *     (hipGetLastError after the launch).  Nothing throws across this boundary.
+ *   - Re-entrant, no global state: safe with one process per GPU or one stream per thread.
+ *   - Inputs must be finite.  A point whose projection overflows int range is dropped (the
+ *     reference's behaviour there is platform-defined; see DESIGN.md "Deviations").
+ *
+ * Numerical contract: identical to oracle/kbe_oracle.c (which is pinned bit-for-bit to the
+ * reference kernel text): z-buffer and winner indices bit-exact; degrid uses the out-of-place
+ * (Jacobi) schedule; accumulation order is the hardware's atomic order (last-ulp differences).
+ */
+#ifndef KBE_H
+#define KBE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBE_ABI_VERSION 1
+
+enum {
+    KBE_OK = 0,
+    KBE_E_INVALID = -1,   /* null pointer, non-positive size, unsupported kernel size ...   */
+    KBE_E_LAUNCH = -2,    /* hipGetLastError() != hipSuccess after a launch                  */
+    KBE_E_DEVICE = -3     /* not a gfx950 device / runtime query failed                      */
+};
+
+typedef void* kbe_stream_t;   /* hipStream_t */
+
+/* z-buffer cells are kept as order-preserving uint32 keys of the fp32 `dblError` so that the
+   reference's CAS-loop float atomicMin (common.py:275-283) becomes one native atomic. */
+#define KBE_ZKEY_EMPTY 0xC9742400u   /* key of 1000000.0f, the z-buffer's initial value (:430) */
+
+int kbe_abi_version(void);
+/* static string describing the last failing HIP call of the calling thread ("" if none) */
+const char* kbe_last_error(void);
+/* fills name (<= cap bytes) with the device's gcnArchName, returns CU count or KBE_E_DEVICE */
+int kbe_device_info(int device, char* name, int cap);
+
+/* ---------------------------------------------------------------------------------------
+ * render_pointcloud, stage by stage  (common.py:428-686)
+ * ------------------------------------------------------------------------------------- */
+
+/* zkeys[n] = KBE_ZKEY_EMPTY  -- replaces `new_zeros(...).fill_(1000000.0)` (common.py:430) */
+int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream);
+
+/* kernel_pointrender_updateZee (common.py:435-507): project every point, pick the corner
+   with the largest bilinear weight, min-splat its dblError.  If `shift3` is non-NULL (HOST
+   pointer to 3 floats) the camera shift of process_shift (common.py:104-109) is applied to
+   each point on the fly: x' = x * (z / (z + 1e-7f)) + sx, ... so the shifted cloud is never
+   materialised.  `winner` (optional, [B,N] int32) receives each point's target pixel index
+   y*W+x or -1 -- the "z-buffer index" of the parity contract. */
+int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, double baseline,
+               const float* shift3, uint32_t* zkeys, int32_t* winner, kbe_stream_t stream);
+
+/* zkeys -> fp32 z-buffer without degrid (test/debug view of the pre-degrid buffer) */
+int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_stream_t stream);
+
+/* kernel_pointrender_updateDegrid (common.py:525-568), out of place: reads keys, writes the
+   degridded fp32 z-buffer.  `zee_in_f32`, if non-NULL, is used instead of the keys. */
+int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out,
+               kbe_stream_t stream);
+
+/* kernel_pointrender_updateOutput (common.py:586-669): z-tested bilinear accumulation of
+   C data channels plus the weight channel into acc [B,C+1,H,W] (zeroed by the caller,
+   common.py:431).  data may be NULL only when C == 0. */
+int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee,
+                   int W, int H, double focal, double baseline, const float* shift3, float* acc,
+                   kbe_stream_t stream);
+
+/* common.py:686: render = acc[:, :C] / (acc[:, C:] + 1e-7f), existing = acc[:, C:] */
+int kbe_normalize(const float* acc, int B, int C, int W, int H, float* render, float* existing,
+                  kbe_stream_t stream);
+
+/* The whole of render_pointcloud.  scratch: zkeys [B*H*W] u32, zee [B*H*W] f32,
+   acc [B*(C+1)*H*W] f32 (contents on entry are irrelevant). */
+int kbe_render_pointcloud(const float* points, const float* data, int B, int N, int C, int W, int H,
+                          double focal, double baseline, uint32_t* zkeys, float* zee, float* acc,
+                          float* render, float* existing, kbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fill_disocclusion  (common.py:833-937)
+ * ------------------------------------------------------------------------------------- */
+int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, int W, int H,
+                          float* output, kbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One output frame of process_kenburns' loop body (common.py:238-255), fused:
+ *   process_shift -> render_pointcloud([image; depth]) -> fill_disocclusion -> uint8 HWC.
+ * cloud: points [3,N], image [3,N], depth [N] (tensorInpaPoints / Image / Depth).
+ * scratch: zkeys [H*W] must hold KBE_ZKEY_EMPTY everywhere on entry and is left so on exit
+ *          (call kbe_zkeys_clear once); zee [H*W]; acc [5*H*W] (contents irrelevant).
+ * outputs: frame_u8 [H,W,3]; render_f32 (optional, [4,H,W]: the filled float render, for
+ *          parity checks); existing_f32 (optional, [H*W]).
+ * ------------------------------------------------------------------------------------- */
+int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
+                     double focal, double baseline, const float* shift3, uint32_t* zkeys, float* zee,
+                     float* acc, uint8_t* frame_u8, float* render_f32, float* existing_f32,
+                     kbe_stream_t stream);
+
+/* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
+int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);
+
+/* common.py:256-257 equivalent on device: centred crop of (crop_w x crop_h) as cv2.getRectSubPix
+   samples it, then bilinear resize back to (W x H) as cv2.resize(INTER_LINEAR) does on 8-bit
+   images (fixed-point coefficients).  Parity with OpenCV is UNPINNED (OpenCV is not in the
+   image). */
+int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int crop_h,
+                       uint8_t* out_hwc, kbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * torch glue on the path
+ * ------------------------------------------------------------------------------------- */
+
+/* depth_to_points (common.py:382-392): depth [B,1,H,W] -> points [B,3,H,W].
+   `valid` (optional, [B,1,H,W]) multiplies the depth first (common.py:71). */
+int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, int H, double focal,
+                        float* points, kbe_stream_t stream);
+
+/* process_shift's tensor part (common.py:104-109), materialised (API compatibility) */
+int kbe_shift_points(const float* points, int B, int N, const float* shift3, float* out,
+                     kbe_stream_t stream);
+
+/* spatial_filter (common.py:394-426) over `planes` = B*C independent [H,W] planes.
+   kind: 0 = 'laplacian' (replicate pad, the reference's asymmetric taps),
+         3 = 'median-3', 5 = 'median-5' (reflect pad, lower median). */
+int kbe_spatial_filter(const float* in, int planes, int W, int H, int kind, float* out,
+                       kbe_stream_t stream);
+
+/* (|laplacian(x / *scale_dev)| < threshold) as 0/1 floats -- the validity mask of
+   common.py:70 and pointcloud_inpainting.py:193.  scale_dev: DEVICE pointer to one float
+   (tensor.max()), so no host sync is needed. */
+int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int W, int H,
+                        float threshold, float* valid, kbe_stream_t stream);
+
+/* PartialConv2d mask bookkeeping fused into one pass (utils/partial_conv.py:62-77,
+   multi_channel=True):  msum = box-sum of mask over Cin*k*k (zero pad);
+   um = clamp(msum, 0, 1); ratio = Cin*k*k / (msum + 1e-8) * um;
+   out = ((raw - bias) * ratio + bias) * um   (bias NULL: out = raw * ratio).
+   raw/out [B,Cout,Ho,Wo] (may alias), mask [B,Cin,H,W], um [B,1,Ho,Wo]. */
+int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H,
+                       int W, int Cout, int Ho, int Wo, int k, int stride, int pad, float* out,
+                       float* um, kbe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBE_H */

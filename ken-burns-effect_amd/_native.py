@@ -1,0 +1,268 @@
+"""ctypes binding of ``csrc/libkbe_hip.so`` (C ABI: ``include/kbe.h``).
+
+This is the only compute back end of the package.  There is deliberately no CPU or
+PyTorch fallback: :func:`load` raises if the library is missing, and every wrapper
+refuses tensors that are not contiguous fp32 CUDA(=HIP) tensors.
+
+The wrappers take torch tensors only to obtain ``data_ptr()`` and the current HIP
+stream -- the same contract the reference had with CuPy
+(``/root/reference/utils/common.py:516-521``), minus the per-shape JIT.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
+
+# every symbol include/kbe.h declares (tests check the library exports exactly these)
+SYMBOLS = (
+    'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
+    'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
+    'kbe_render_frame', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
+)
+
+ABI_VERSION = 1
+_lib = None
+
+
+class KbeError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library once; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KbeError('HIP extension not built: %s is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise KbeError('libkbe_hip.so does not export %s (stale build?)' % name)
+        getattr(lib, name).restype = ctypes.c_int
+    lib.kbe_last_error.restype = ctypes.c_char_p
+    if lib.kbe_abi_version() != ABI_VERSION:
+        raise KbeError('libkbe_hip.so ABI %d != expected %d' % (lib.kbe_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+_i, _d, _f, _z = ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_size_t
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise KbeError('kernel arguments must be contiguous %s tensors on the GPU (got %s %s on %s)'
+                       % (dtype, 'contiguous' if t.is_contiguous() else 'strided', t.dtype, t.device))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _shift(shift3):
+    if shift3 is None:
+        return None
+    if torch.is_tensor(shift3):
+        shift3 = shift3.detach().reshape(-1).tolist()     # 3 host floats (already fp32-representable)
+    return (ctypes.c_float * 3)(*[float(v) for v in shift3])
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipKernels:
+    """Tensor-level view of the C ABI.  One instance is shared by the package."""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = load()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise KbeError('%s failed (%d): %s' % (what, rc, self.lib.kbe_last_error().decode()))
+
+    # -- render_pointcloud and its stages ------------------------------------------------
+    def zsplat(self, points, W, H, focal, baseline, shift3=None, want_winner=False):
+        points = _f32c(points)
+        B, _, N = points.shape
+        zkeys = torch.empty(B, 1, H, W, dtype=torch.int32, device=points.device)
+        self._check(self.lib.kbe_zkeys_clear(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _stream()), 'kbe_zkeys_clear')
+        winner = torch.empty(B, N, dtype=torch.int32, device=points.device) if want_winner else None
+        self._check(self.lib.kbe_zsplat(_ptr(points), _i(B), _i(N), _i(W), _i(H), _d(float(focal)), _d(float(baseline)),
+                                        _shift(shift3), _ptr(zkeys, torch.int32), _ptr(winner, torch.int32), _stream()),
+                    'kbe_zsplat')
+        return zkeys, winner
+
+    def zkeys_decode(self, zkeys):
+        zee = torch.empty(zkeys.shape, dtype=torch.float32, device=zkeys.device)
+        self._check(self.lib.kbe_zkeys_decode(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _ptr(zee), _stream()),
+                    'kbe_zkeys_decode')
+        return zee
+
+    def degrid(self, zkeys=None, zee=None):
+        src = zkeys if zkeys is not None else zee
+        B, _, H, W = src.shape
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=src.device)
+        self._check(self.lib.kbe_degrid(_ptr(zkeys, torch.int32), _ptr(None if zee is None else _f32c(zee)), _i(B), _i(W),
+                                        _i(H), _ptr(out), _stream()), 'kbe_degrid')
+        return out
+
+    def accumulate(self, points, data, zee, focal, baseline, shift3=None):
+        points, data = _f32c(points), _f32c(data)
+        B, C, N = data.shape
+        _, _, H, W = zee.shape
+        acc = torch.zeros(B, C + 1, H, W, dtype=torch.float32, device=points.device)
+        self._check(self.lib.kbe_accumulate(_ptr(points), _ptr(data), _i(B), _i(N), _i(C), _ptr(_f32c(zee)), _i(W), _i(H),
+                                            _d(float(focal)), _d(float(baseline)), _shift(shift3), _ptr(acc), _stream()),
+                    'kbe_accumulate')
+        return acc
+
+    def normalize(self, acc):
+        B, C1, H, W = acc.shape
+        render = torch.empty(B, C1 - 1, H, W, dtype=torch.float32, device=acc.device)
+        existing = torch.empty(B, 1, H, W, dtype=torch.float32, device=acc.device)
+        self._check(self.lib.kbe_normalize(_ptr(_f32c(acc)), _i(B), _i(C1 - 1), _i(W), _i(H), _ptr(render), _ptr(existing),
+                                           _stream()), 'kbe_normalize')
+        return render, existing
+
+    def render_pointcloud(self, points, data, W, H, focal, baseline):
+        points, data = _f32c(points), _f32c(data)
+        B, C, N = data.shape
+        dev = points.device
+        zkeys = torch.empty(B * H * W, dtype=torch.int32, device=dev)
+        zee = torch.empty(B * H * W, dtype=torch.float32, device=dev)
+        acc = torch.empty(B * (C + 1) * H * W, dtype=torch.float32, device=dev)
+        render = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        existing = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        self._check(self.lib.kbe_render_pointcloud(_ptr(points), _ptr(data), _i(B), _i(N), _i(C), _i(W), _i(H),
+                                                   _d(float(focal)), _d(float(baseline)), _ptr(zkeys, torch.int32),
+                                                   _ptr(zee), _ptr(acc), _ptr(render), _ptr(existing), _stream()),
+                    'kbe_render_pointcloud')
+        return render, existing
+
+    # -- fill ---------------------------------------------------------------------------
+    def fill_disocclusion(self, x, depth):
+        x, depth = _f32c(x), _f32c(depth)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        self._check(self.lib.kbe_fill_disocclusion(_ptr(x), _ptr(depth), _i(B), _i(C), _i(W), _i(H), _ptr(out), _stream()),
+                    'kbe_fill_disocclusion')
+        return out
+
+    # -- fused frame --------------------------------------------------------------------
+    def prepare_cloud(self, points, image, depth, W, H):
+        """Packs tensorInpaPoints/Image/Depth into one resident [7,N] buffer (points, rgb, depth)
+        and allocates the per-view scratch once; returns the state render_frame consumes."""
+        N = points.shape[-1]
+        cloud7 = torch.cat([_f32c(points).reshape(3, N), _f32c(image).reshape(3, N), _f32c(depth).reshape(1, N)], 0).contiguous()
+        dev = cloud7.device
+        state = {'cloud7': cloud7, 'N': N, 'W': int(W), 'H': int(H),
+                 'zkeys': torch.empty(H * W, dtype=torch.int32, device=dev),
+                 'zee': torch.empty(H * W, dtype=torch.float32, device=dev),
+                 'acc': torch.empty(5 * H * W, dtype=torch.float32, device=dev),
+                 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev)}
+        self.zkeys_clear(state['zkeys'])
+        return state
+
+    def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None):
+        """One frame of common.py:238-255 (shift -> render -> fill -> uint8) -> uint8 [H,W,3] on the device."""
+        N, W, H = state['N'], state['W'], state['H']
+        base = state['cloud7'].data_ptr()
+        self._check(self.lib.kbe_render_frame(ctypes.c_void_p(base), ctypes.c_void_p(base + 12 * N),
+                                              ctypes.c_void_p(base + 24 * N), _i(N), _i(W), _i(H), _d(float(focal)),
+                                              _d(float(baseline)), _shift(shift3), _ptr(state['zkeys'], torch.int32),
+                                              _ptr(state['zee']), _ptr(state['acc']), _ptr(state['frame'], torch.uint8),
+                                              _ptr(render_f32), _ptr(existing_f32), _stream()), 'kbe_render_frame')
+        return state['frame']
+
+    def zkeys_clear(self, zkeys):
+        self._check(self.lib.kbe_zkeys_clear(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _stream()), 'kbe_zkeys_clear')
+
+    def frame_u8(self, render):
+        render = _f32c(render)
+        _, C, H, W = render.shape
+        out = torch.empty(H, W, 3, dtype=torch.uint8, device=render.device)
+        self._check(self.lib.kbe_frame_u8(_ptr(render), _i(W), _i(H), _ptr(out, torch.uint8), _stream()), 'kbe_frame_u8')
+        return out
+
+    def crop_resize_u8(self, frame, crop_w, crop_h):
+        H, W, _ = frame.shape
+        out = torch.empty_like(frame)
+        self._check(self.lib.kbe_crop_resize_u8(_ptr(frame, torch.uint8), _i(W), _i(H), _i(int(crop_w)), _i(int(crop_h)),
+                                                _ptr(out, torch.uint8), _stream()), 'kbe_crop_resize_u8')
+        return out
+
+    # -- torch glue ---------------------------------------------------------------------
+    def depth_to_points(self, depth, focal, valid=None):
+        depth = _f32c(depth)
+        B, _, H, W = depth.shape
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=depth.device)
+        self._check(self.lib.kbe_depth_to_points(_ptr(depth), _ptr(None if valid is None else _f32c(valid)), _i(B), _i(W),
+                                                 _i(H), _d(float(focal)), _ptr(out), _stream()), 'kbe_depth_to_points')
+        return out
+
+    def shift_points(self, points, shift3):
+        points = _f32c(points)
+        B, _, N = points.shape
+        out = torch.empty_like(points)
+        self._check(self.lib.kbe_shift_points(_ptr(points), _i(B), _i(N), _shift(shift3), _ptr(out), _stream()),
+                    'kbe_shift_points')
+        return out
+
+    def spatial_filter(self, x, kind):
+        code = {'laplacian': 0, 'median-3': 3, 'median-5': 5}.get(kind)
+        if code is None:
+            return None       # the reference returns None for unknown types (common.py:395,425)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        self._check(self.lib.kbe_spatial_filter(_ptr(x), _i(B * C), _i(W), _i(H), _i(code), _ptr(out), _stream()),
+                    'kbe_spatial_filter')
+        return out
+
+    def laplacian_valid(self, disparity, scale, threshold):
+        """(|laplacian(disparity / scale)| < threshold).float(); `scale` is a 0-dim device tensor."""
+        x = _f32c(disparity)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        scale = _f32c(scale).reshape(1)
+        self._check(self.lib.kbe_laplacian_valid(_ptr(x), _ptr(scale), _i(B * C), _i(W), _i(H), _f(float(threshold)), _ptr(out),
+                                                 _stream()), 'kbe_laplacian_valid')
+        return out
+
+    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding):
+        raw, mask = _f32c(raw), _f32c(mask)
+        B, Cout, Ho, Wo = raw.shape
+        _, Cin, H, W = mask.shape
+        out = torch.empty_like(raw)
+        um = torch.empty(B, 1, Ho, Wo, dtype=torch.float32, device=raw.device)
+        self._check(self.lib.kbe_pconv_epilogue(_ptr(raw), _ptr(None if bias is None else _f32c(bias)), _ptr(mask), _i(B),
+                                                _i(Cin), _i(H), _i(W), _i(Cout), _i(Ho), _i(Wo), _i(int(kernel_size)),
+                                                _i(int(stride)), _i(int(padding)), _ptr(out), _ptr(um), _stream()),
+                    'kbe_pconv_epilogue')
+        return out, um
+
+
+_kernels = None
+
+
+def kernels():
+    """The process-wide kernel set (HIP).  Raises KbeError when the extension is missing."""
+    global _kernels
+    if _kernels is None:
+        _kernels = HipKernels()
+    return _kernels

@@ -1,0 +1,139 @@
+// kbe_device.h -- device-side building blocks shared by the render kernels (gfx950 only).
+//
+// Numerical contract: oracle/kbe_oracle.c (pinned to the reference kernel text).  This
+// translation unit must be built with -ffp-contract=off: every fp32 operation below rounds
+// once, the only fused multiply-adds are the explicit __builtin_fmaf calls, and the fp64
+// sub-expressions are the ones the reference's double literals cause.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace kbe {
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+// ---------------------------------------------------------------------------------------
+// order-preserving fp32 <-> uint32 key (replaces the CAS-loop float atomicMin of
+// /root/reference/utils/common.py:275-283 by one native global/LDS atomic umin)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zkey_encode(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ float zkey_decode(uint32_t k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// ---------------------------------------------------------------------------------------
+// camera: everything the projection needs, precomputed once per launch on the host
+// ---------------------------------------------------------------------------------------
+struct Camera {
+    float focal_f;      // (float) dblFocal             common.py:447 make_float3(0, 0, F)
+    double fb;          // dblFocal * dblBaseline       common.py:470
+    double half_w;      // 0.5 * W                      common.py:467
+    double half_h;      // 0.5 * H                      common.py:468
+    int W, H;
+    int has_shift;      // apply process_shift (common.py:104-109) on the fly
+    float sx, sy, sz;
+};
+
+// process_shift's per-point arithmetic: x *= z / (z + 1e-7); y likewise; then += shift.
+__device__ __forceinline__ void apply_shift(const Camera& cam, float& x, float& y, float& z)
+{
+    if (cam.has_shift) {
+        const float r = z / (z + 0.0000001f);
+        x = x * r + cam.sx;
+        y = y * r + cam.sy;
+        z = z + cam.sz;
+    }
+}
+
+struct Proj {
+    float err;          // dblError
+    int nwx, nwy;       // north-west corner
+    float w[4];         // NW, NE, SW, SE bilinear weights
+};
+
+// common.py:447-484 (== :599-636).  Returns false when the point touches no pixel at all.
+__device__ __forceinline__ bool project(const Camera& cam, float px, float py, float pz, Proj& p)
+{
+    if (!((double) pz >= 0.001)) return false;                 // :453 (also covers :461)
+    const float lvx = 0.0f - px, lvy = 0.0f - py, lvz = 0.0f - pz;
+    const float dist = (cam.focal_f - pz) / lvz;               // :457-459
+    const float ix = __builtin_fmaf(dist, lvx, px);            // :465 as NVRTC (--fmad=true) emits it
+    const float iy = __builtin_fmaf(dist, lvy, py);
+    const float ox = (float) (((double) ix + cam.half_w) - 0.5);   // :467
+    const float oy = (float) (((double) iy + cam.half_h) - 0.5);   // :468
+    p.err = (float) (1000000.0 - (cam.fb / ((double) pz + 0.0000001)));   // :470
+    if (!(fabsf(ox) < 1.0e9f) || !(fabsf(oy) < 1.0e9f)) return false;    // see kbe.h "Inputs must be finite"
+    const float fx = floorf(ox), fy = floorf(oy);
+    p.nwx = (int) fx;
+    p.nwy = (int) fy;
+    const float ex = (float) (p.nwx + 1), ey = (float) (p.nwy + 1);      // east / south coordinates
+    p.w[0] = (ex - ox) * (ey - oy);                             // :481 NW
+    p.w[1] = (ox - fx) * (ey - oy);                             // :482 NE
+    p.w[2] = (ex - ox) * (oy - fy);                             // :483 SW
+    p.w[3] = (ox - fx) * (oy - fy);                             // :484 SE
+    return true;
+}
+
+// common.py:486-506: first of NW, NE, SW, SE whose weight is >= the other three; -1 = none
+__device__ __forceinline__ int winner_corner(const Proj& p)
+{
+    const float nw = p.w[0], ne = p.w[1], sw = p.w[2], se = p.w[3];
+    if ((nw >= ne) & (nw >= sw) & (nw >= se)) return 0;
+    if ((ne >= nw) & (ne >= sw) & (ne >= se)) return 1;
+    if ((sw >= nw) & (sw >= ne) & (sw >= se)) return 2;
+    if ((se >= nw) & (se >= ne) & (se >= sw)) return 3;
+    return -1;
+}
+
+__device__ __forceinline__ bool inside(int x, int y, int W, int H)
+{
+    return (x >= 0) & (x < W) & (y >= 0) & (y < H);
+}
+
+// common.py:542-567 for one pixel; `at(x, y)` returns the pre-degrid value of an in-image pixel.
+template <class At>
+__device__ __forceinline__ float degrid_pixel(int x, int y, int W, int H, At at)
+{
+    const float c = at(x, y);
+    int count = 0;
+    float sum = 0.0f;
+    const int ox[4] = { 1, 0, 1, 1 };
+    const int oy[4] = { 0, 1, 1, -1 };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
+        if (!inside(x1, y1, W, H) || !inside(x2, y2, W, H)) continue;
+        const float a = at(x1, y1), d = at(x2, y2);
+        if (((double) c >= (double) a + 1.0) && ((double) c >= (double) d + 1.0)) {
+            count += 2;
+            sum += a;
+            sum += d;
+        }
+    }
+    return count > 0 ? fminf(c, sum / (float) count) : c;
+}
+
+// common.py:255: (x * 255.0).clip(0.0, 255.0).astype(np.uint8)
+__device__ __forceinline__ uint8_t to_u8(float v)
+{
+    v = v * 255.0f;
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    return (uint8_t) (int) v;
+}
+
+// fire-and-forget fp32 add: the native global_atomic_add_f32 (the buffers are ordinary
+// coarse-grained device allocations, so the hardware atomic is valid)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v)
+{
+    unsafeAtomicAdd(p, v);
+}
+
+}  // namespace kbe

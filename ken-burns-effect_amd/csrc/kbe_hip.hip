@@ -1,0 +1,712 @@
+// kbe_hip.hip -- gfx950 kernels and the extern "C" entry points declared in include/kbe.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// Reference lines cited as common.py:NNN are /root/reference/utils/common.py.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "kbe.h"
+#include "kbe_device.h"
+
+#pragma clang fp contract(off)
+
+using namespace kbe;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    snprintf(g_err, sizeof(g_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    return code;
+}
+
+int launched(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? KBE_OK : fail(KBE_E_LAUNCH, what, e);
+}
+
+Camera make_camera(int W, int H, double focal, double baseline, const float* shift3)
+{
+    Camera c;
+    c.focal_f = (float) focal;
+    c.fb = focal * baseline;
+    c.half_w = 0.5 * (double) W;
+    c.half_h = 0.5 * (double) H;
+    c.W = W;
+    c.H = H;
+    c.has_shift = shift3 != nullptr;
+    c.sx = shift3 ? shift3[0] : 0.0f;
+    c.sy = shift3 ? shift3[1] : 0.0f;
+    c.sz = shift3 ? shift3[2] : 0.0f;
+    return c;
+}
+
+constexpr int kBlock = 256;
+
+inline unsigned blocks_for(size_t n, int per_block = kBlock)
+{
+    return (unsigned) ((n + per_block - 1) / per_block);
+}
+
+// ---------------------------------------------------------------------------------------
+// elementwise helpers
+// ---------------------------------------------------------------------------------------
+__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_zkeys_decode(const uint32_t* keys, size_t n, float* zee)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) zee[i] = zkey_decode(keys[i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel_pointrender_updateZee (common.py:435-507)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_zsplat(const float* __restrict__ points, int N, Camera cam,
+                                                   uint32_t* __restrict__ zkeys, int32_t* __restrict__ winner)
+{
+    const int b = blockIdx.y;
+    const float* P = points + (size_t) b * 3 * N;
+    uint32_t* Z = zkeys + (size_t) b * cam.H * cam.W;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x = P[i], y = P[(size_t) N + i], z = P[2 * (size_t) N + i];
+    apply_shift(cam, x, y, z);
+    Proj p;
+    int idx = -1;
+    if (project(cam, x, y, z, p)) {
+        const int c = winner_corner(p);
+        if (c >= 0) {
+            const int cx = p.nwx + (c & 1), cy = p.nwy + (c >> 1);
+            if (inside(cx, cy, cam.W, cam.H)) {
+                idx = cy * cam.W + cx;
+                atomicMin(&Z[idx], zkey_encode(p.err));
+            }
+        }
+    }
+    if (winner) winner[(size_t) b * N + i] = idx;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel_pointrender_updateDegrid (common.py:525-568), out of place (Jacobi schedule)
+// ---------------------------------------------------------------------------------------
+template <bool FROM_KEYS>
+__global__ void __launch_bounds__(kBlock) k_degrid(const uint32_t* __restrict__ keys, const float* __restrict__ zin,
+                                                   int W, int H, float* __restrict__ zout)
+{
+    const int b = blockIdx.y;
+    const size_t base = (size_t) b * H * W;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int y = i / W, x = i - y * W;
+    auto at = [&](int xx, int yy) -> float {
+        const size_t o = base + (size_t) yy * W + xx;
+        return FROM_KEYS ? zkey_decode(keys[o]) : zin[o];
+    };
+    zout[base + i] = degrid_pixel(x, y, W, H, at);
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel_pointrender_updateOutput (common.py:586-669), any channel count
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__ points, const float* __restrict__ data,
+                                                       int N, int C, Camera cam, const float* __restrict__ zee,
+                                                       float* __restrict__ acc)
+{
+    const int b = blockIdx.y;
+    const size_t HW = (size_t) cam.H * cam.W;
+    const float* P = points + (size_t) b * 3 * N;
+    const float* D = data + (size_t) b * C * N;
+    const float* Z = zee + (size_t) b * HW;
+    float* A = acc + (size_t) b * (C + 1) * HW;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x = P[i], y = P[(size_t) N + i], z = P[2 * (size_t) N + i];
+    apply_shift(cam, x, y, z);
+    Proj p;
+    if (!project(cam, x, y, z, p)) return;
+    bool take[4];
+    size_t px[4];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int cx = p.nwx + (c & 1), cy = p.nwy + (c >> 1);
+        take[c] = false;
+        px[c] = 0;
+        if (inside(cx, cy, cam.W, cam.H)) {
+            px[c] = (size_t) cy * cam.W + cx;
+            take[c] = (double) p.err <= (double) Z[px[c]] + 1.0;      // :639
+        }
+        any |= take[c];
+    }
+    if (!any) return;
+    for (int ch = 0; ch < C; ch++) {
+        const float v = D[(size_t) ch * N + i];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (take[c]) atomic_add_f32(&A[ch * HW + px[c]], v * p.w[c]);   // :641 product rounded, then added
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (take[c]) atomic_add_f32(&A[C * HW + px[c]], p.w[c]);            // the appended `ones` channel, :429
+}
+
+// common.py:686
+__global__ void __launch_bounds__(kBlock) k_normalize(const float* __restrict__ acc, int C, int HW,
+                                                      float* __restrict__ render, float* __restrict__ existing)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float* A = acc + (size_t) b * (C + 1) * HW;
+    const float wsum = A[(size_t) C * HW + i];
+    const float den = wsum + 0.0000001f;
+    for (int ch = 0; ch < C; ch++) render[((size_t) b * C + ch) * HW + i] = A[(size_t) ch * HW + i] / den;
+    existing[(size_t) b * HW + i] = wsum;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel_discfill_updateOutput (common.py:838-924)
+// ---------------------------------------------------------------------------------------
+struct FillDirs { float x[16], y[16]; };
+
+FillDirs make_fill_dirs()
+{
+    // common.py:859-867: the direction table, normalised in fp32 on the host with the same
+    // IEEE operations (sqrtf, divide) the kernel text performs per thread
+    const float dx[16] = { -1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3 };
+    const float dy[16] = { 1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2 };
+    FillDirs d;
+    for (int i = 0; i < 16; i++) {
+        volatile float n = sqrtf((dx[i] * dx[i]) + (dy[i] * dy[i]));
+        d.x[i] = dx[i] / n;
+        d.y[i] = dy[i] / n;
+    }
+    return d;
+}
+
+// Finds the fill source of hole pixel (x, y): returns the linear index of the pixel to copy
+// from, or -1 when every direction leaves the image on one side (common.py:913-919).
+template <class DepthAt>
+__device__ __forceinline__ int fill_source(const FillDirs& dirs, int x, int y, int W, int H, DepthAt depth_at)
+{
+    float shortest = 1000000.0f;
+    int fx = -1, fy = -1;
+    for (int d = 0; d < 16; d++) {
+        const float ddx = dirs.x[d], ddy = dirs.y[d];
+        float ax = (float) x, ay = (float) y;
+        int iax, iay;
+        float da = 0.0f;
+        for (;;) {                                              // :876-883
+            ax -= ddx; iax = (int) roundf(ax);
+            ay -= ddy; iay = (int) roundf(ay);
+            if ((iax < 0) | (iax >= W) | (iay < 0) | (iay >= H)) break;
+            da = depth_at(iax, iay);
+            if (da > 0.0f) break;
+        }
+        if ((iax < 0) | (iax >= W) | (iay < 0) | (iay >= H)) continue;      // :884-885
+        float bx = (float) x, by = (float) y;
+        int ibx, iby;
+        float db = 0.0f;
+        for (;;) {                                              // :887-894
+            bx += ddx; ibx = (int) roundf(bx);
+            by += ddy; iby = (int) roundf(by);
+            if ((ibx < 0) | (ibx >= W) | (iby < 0) | (iby >= H)) break;
+            db = depth_at(ibx, iby);
+            if (db > 0.0f) break;
+        }
+        if ((ibx < 0) | (ibx >= W) | (iby < 0) | (iby >= H)) continue;      // :895-896
+        const float ex = (float) (ibx - iax), ey = (float) (iby - iay);
+        const float dist = sqrtf(ex * ex + ey * ey);            // :898 (exact small integers)
+        if (shortest > dist) {                                  // :900
+            fx = iax; fy = iay;
+            if (da < db) { fx = ibx; fy = iby; }                // :904 the farther (background) end
+            shortest = dist;
+        }
+    }
+    return (fx < 0 || fy < 0) ? -1 : fy * W + fx;
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill(const float* __restrict__ input, const float* __restrict__ depth,
+                                                 int C, int W, int H, FillDirs dirs, float* __restrict__ output)
+{
+    const int b = blockIdx.y;
+    const int HW = W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float* Dp = depth + (size_t) b * HW;
+    const float* In = input + (size_t) b * C * HW;
+    float* Out = output + (size_t) b * C * HW;
+    int src = i;
+    if (!(Dp[i] > 0.0f)) {                                      // :850
+        const int y = i / W, x = i - y * W;
+        const int s = fill_source(dirs, x, y, W, H, [&](int xx, int yy) { return Dp[yy * W + xx]; });
+        if (s >= 0) src = s;
+    }
+    for (int ch = 0; ch < C; ch++) Out[(size_t) ch * HW + i] = In[(size_t) ch * HW + src];    // :834 clone + :921-923
+}
+
+// ---------------------------------------------------------------------------------------
+// fused frame tail: normalise (common.py:686) + hole mask (:253) + fill (:838-924) + uint8
+// (:255) straight from the accumulators.  depth used by the fill = render[3] * (w > 0),
+// which equals render[3] because render[3] is +0 wherever w == 0.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float norm_at(const float* __restrict__ acc, int HW, int ch, int px)
+{
+    return acc[(size_t) ch * HW + px] / (acc[(size_t) 4 * HW + px] + 0.0000001f);
+}
+
+__global__ void __launch_bounds__(kBlock) k_resolve_frame(const float* __restrict__ acc, int W, int H, FillDirs dirs,
+                                                          uint8_t* __restrict__ frame, float* __restrict__ render,
+                                                          float* __restrict__ existing, uint32_t* __restrict__ zkeys)
+{
+    const int HW = W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    zkeys[i] = KBE_ZKEY_EMPTY;                                  // leave the z-buffer clean for the next frame
+    const float w = acc[(size_t) 4 * HW + i];
+    float depth = norm_at(acc, HW, 3, i);
+    depth = depth * (w > 0.0f ? 1.0f : 0.0f);                   // :253
+    int src = i;
+    if (!(depth > 0.0f)) {
+        const int y = i / W, x = i - y * W;
+        const int s = fill_source(dirs, x, y, W, H, [&](int xx, int yy) {
+            const int q = yy * W + xx;
+            const float wq = acc[(size_t) 4 * HW + q];
+            return norm_at(acc, HW, 3, q) * (wq > 0.0f ? 1.0f : 0.0f);
+        });
+        if (s >= 0) src = s;
+    }
+    const float r = norm_at(acc, HW, 0, src), g = norm_at(acc, HW, 1, src), bl = norm_at(acc, HW, 2, src);
+    frame[(size_t) i * 3 + 0] = to_u8(r);
+    frame[(size_t) i * 3 + 1] = to_u8(g);
+    frame[(size_t) i * 3 + 2] = to_u8(bl);
+    if (render) {
+        render[i] = r;
+        render[(size_t) HW + i] = g;
+        render[(size_t) 2 * HW + i] = bl;
+        render[(size_t) 3 * HW + i] = norm_at(acc, HW, 3, src);
+    }
+    if (existing) existing[i] = w;
+}
+
+__global__ void __launch_bounds__(kBlock) k_frame_u8(const float* __restrict__ render, int HW, uint8_t* __restrict__ frame)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    frame[(size_t) i * 3 + 0] = to_u8(render[i]);
+    frame[(size_t) i * 3 + 1] = to_u8(render[(size_t) HW + i]);
+    frame[(size_t) i * 3 + 2] = to_u8(render[(size_t) 2 * HW + i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// cv2.getRectSubPix + cv2.resize(INTER_LINEAR) on 8-bit HWC (common.py:256-257).
+// Restated from the OpenCV algorithms as described in SURVEY.md B.7; UNPINNED.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round(float v) { return (int) rintf(v); }
+
+__device__ __forceinline__ int rect_subpix_px(const uint8_t* __restrict__ img, int W, int H, int ipx, int ipy,
+                                              int a11, int a12, int a21, int a22, int x, int y, int ch)
+{
+    // replicate border, as OpenCV does when the window leaves the image
+    const int x0 = min(max(ipx + x, 0), W - 1), x1 = min(max(ipx + x + 1, 0), W - 1);
+    const int y0 = min(max(ipy + y, 0), H - 1), y1 = min(max(ipy + y + 1, 0), H - 1);
+    const int v = img[((size_t) y0 * W + x0) * 3 + ch] * a11 + img[((size_t) y0 * W + x1) * 3 + ch] * a12 +
+                  img[((size_t) y1 * W + x0) * 3 + ch] * a21 + img[((size_t) y1 * W + x1) * 3 + ch] * a22;
+    return (v + (1 << 15)) >> 16;
+}
+
+__global__ void __launch_bounds__(kBlock) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
+                                                           uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int dy = i / W, dx = i - dy * W;
+    // getRectSubPix: top-left sample position and 16-bit fixed-point bilinear weights
+    const float cx = (float) W / 2.0f - (float) (cw - 1) * 0.5f, cy = (float) H / 2.0f - (float) (ch_ - 1) * 0.5f;
+    const int ipx = (int) floorf(cx), ipy = (int) floorf(cy);
+    const float a = cx - (float) ipx, b = cy - (float) ipy;
+    const int a11 = cv_round((1.f - a) * (1.f - b) * 65536.f), a12 = cv_round(a * (1.f - b) * 65536.f);
+    const int a21 = cv_round((1.f - a) * b * 65536.f), a22 = cv_round(a * b * 65536.f);
+    // resize INTER_LINEAR 8u: src = (dst + 0.5) * scale - 0.5, 11-bit coefficients
+    const double sx_scale = (double) cw / W, sy_scale = (double) ch_ / H;
+    float fx = (float) ((dx + 0.5) * sx_scale - 0.5);
+    int sx = (int) floorf(fx);
+    fx -= (float) sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= cw - 1) { fx = 0.f; sx = cw - 1; }
+    float fy = (float) ((dy + 0.5) * sy_scale - 0.5);
+    int sy = (int) floorf(fy);
+    fy -= (float) sy;
+    if (sy < 0) { fy = 0.f; sy = 0; }
+    if (sy >= ch_ - 1) { fy = 0.f; sy = ch_ - 1; }
+    const int ax0 = cv_round((1.f - fx) * 2048.f), ax1 = cv_round(fx * 2048.f);
+    const int by0 = cv_round((1.f - fy) * 2048.f), by1 = cv_round(fy * 2048.f);
+    const int sx1 = min(sx + 1, cw - 1), sy1 = min(sy + 1, ch_ - 1);
+    for (int c = 0; c < 3; c++) {
+        const int p00 = rect_subpix_px(img, W, H, ipx, ipy, a11, a12, a21, a22, sx, sy, c);
+        const int p01 = rect_subpix_px(img, W, H, ipx, ipy, a11, a12, a21, a22, sx1, sy, c);
+        const int p10 = rect_subpix_px(img, W, H, ipx, ipy, a11, a12, a21, a22, sx, sy1, c);
+        const int p11 = rect_subpix_px(img, W, H, ipx, ipy, a11, a12, a21, a22, sx1, sy1, c);
+        const int r0 = p00 * ax0 + p01 * ax1, r1 = p10 * ax0 + p11 * ax1;     // horizontal pass, x2048
+        const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;   // vertical pass
+        out[(size_t) i * 3 + c] = (uint8_t) min(max(v, 0), 255);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// torch glue
+// ---------------------------------------------------------------------------------------
+
+// torch.linspace(-0.5 n + 0.5, 0.5 n - 0.5, n)[i] (fp32, evaluated from both ends like ATen)
+__device__ __forceinline__ float linspace_centered(int n, int i)
+{
+    const float start = (float) ((-0.5 * n) + 0.5), end = (float) ((0.5 * n) - 0.5);
+    if (n == 1) return start;
+    const float step = (end - start) / (float) (n - 1);
+    return (i < n / 2) ? start + step * (float) i : end - step * (float) (n - 1 - i);
+}
+
+// depth_to_points (common.py:382-392)
+__global__ void __launch_bounds__(kBlock) k_depth_to_points(const float* __restrict__ depth, const float* __restrict__ valid,
+                                                            int W, int H, float inv_focal, float* __restrict__ points)
+{
+    const int b = blockIdx.y;
+    const int HW = W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const int y = i / W, x = i - y * W;
+    float d = depth[(size_t) b * HW + i];
+    if (valid) d = d * valid[(size_t) b * HW + i];
+    const float u = linspace_centered(W, x) * inv_focal;
+    const float v = linspace_centered(H, y) * inv_focal;
+    float* P = points + (size_t) b * 3 * HW;
+    P[i] = d * u;
+    P[(size_t) HW + i] = d * v;
+    P[(size_t) 2 * HW + i] = d;
+}
+
+// process_shift, materialised (common.py:104-109)
+__global__ void __launch_bounds__(kBlock) k_shift_points(const float* __restrict__ points, int N, Camera cam,
+                                                         float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* P = points + (size_t) b * 3 * N;
+    float* O = out + (size_t) b * 3 * N;
+    float x = P[i], y = P[(size_t) N + i], z = P[2 * (size_t) N + i];
+    apply_shift(cam, x, y, z);
+    O[i] = x;
+    O[(size_t) N + i] = y;
+    O[2 * (size_t) N + i] = z;
+}
+
+// spatial_filter 'laplacian' (common.py:397-409); SCALE: divide the input by *scale first and
+// emit the (|lap| < thr) mask instead (common.py:70, pointcloud_inpainting.py:193)
+template <bool MASK>
+__global__ void __launch_bounds__(kBlock) k_laplacian(const float* __restrict__ in, const float* __restrict__ scale,
+                                                      int W, int H, float thr, float* __restrict__ out)
+{
+    const int p = blockIdx.y;
+    const int HW = W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float* I = in + (size_t) p * HW;
+    const int y = i / W, x = i - y * W;
+    const int ym = max(y - 1, 0), yp = min(y + 1, H - 1), xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+    const float s = MASK ? *scale : 1.0f;
+    auto ld = [&](int yy, int xx) { const float v = I[yy * W + xx]; return MASK ? v / s : v; };
+    float a = 0.0f;
+    a = __builtin_fmaf(-1.0f, ld(ym, x), a);       // taps [0][1], [0][2], [1][0], [1][1], [2][0] (common.py:401-405)
+    a = __builtin_fmaf(-1.0f, ld(ym, xp), a);
+    a = __builtin_fmaf(-1.0f, ld(y, xm), a);
+    a = __builtin_fmaf(4.0f, ld(y, x), a);
+    a = __builtin_fmaf(-1.0f, ld(yp, xm), a);
+    out[(size_t) p * HW + i] = MASK ? (fabsf(a) < thr ? 1.0f : 0.0f) : a;
+}
+
+// spatial_filter 'median-3' / 'median-5' (common.py:411-421): reflect pad, lower median by rank
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_median(const float* __restrict__ in, int W, int H, float* __restrict__ out)
+{
+    constexpr int R = K / 2, NN = K * K;
+    const int p = blockIdx.y;
+    const int HW = W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float* I = in + (size_t) p * HW;
+    const int y = i / W, x = i - y * W;
+    float v[NN];
+#pragma unroll
+    for (int dy = -R; dy <= R; dy++) {
+        int yy = y + dy;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            int xx = x + dx;
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            v[(dy + R) * K + (dx + R)] = I[yy * W + xx];
+        }
+    }
+    // element of rank (NN-1)/2 in a stable order (value, then index)
+    float med = v[0];
+#pragma unroll
+    for (int a = 0; a < NN; a++) {
+        int rank = 0;
+#pragma unroll
+        for (int b = 0; b < NN; b++) rank += (v[b] < v[a]) | ((v[b] == v[a]) & (b < a));
+        if (rank == (NN - 1) / 2) med = v[a];
+    }
+    out[(size_t) p * HW + i] = med;
+}
+
+// PartialConv2d bookkeeping (utils/partial_conv.py:62-77)
+__global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restrict__ raw, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, int Cin, int H, int W, int Cout,
+                                                           int Ho, int Wo, int k, int stride, int pad,
+                                                           float* __restrict__ out, float* __restrict__ um_out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const int oy = i / Wo, ox = i - oy * Wo;
+    float msum = 0.0f;
+    for (int ci = 0; ci < Cin; ci++) {
+        const float* M = mask + ((size_t) b * Cin + ci) * H * W;
+        for (int ky = 0; ky < k; ky++) {
+            const int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; kx++) {
+                const int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                msum += M[(size_t) iy * W + ix];
+            }
+        }
+    }
+    float ratio = (float) (Cin * k * k) / (msum + 1e-8f);
+    const float um = msum < 0.0f ? 0.0f : (msum > 1.0f ? 1.0f : msum);
+    ratio = ratio * um;
+    um_out[(size_t) b * Ho * Wo + i] = um;
+    for (int co = 0; co < Cout; co++) {
+        const size_t o = ((size_t) b * Cout + co) * Ho * Wo + i;
+        const float r = raw[o];
+        if (bias) {
+            const float bv = bias[co];
+            out[o] = ((r - bv) * ratio + bv) * um;
+        } else {
+            out[o] = r * ratio;
+        }
+    }
+}
+
+}  // namespace
+
+// =======================================================================================
+// extern "C" entry points (include/kbe.h)
+// =======================================================================================
+#define KBE_REQUIRE(cond, what) do { if (!(cond)) return fail(KBE_E_INVALID, what); } while (0)
+
+extern "C" {
+
+int kbe_abi_version(void) { return KBE_ABI_VERSION; }
+
+const char* kbe_last_error(void) { return g_err; }
+
+int kbe_device_info(int device, char* name, int cap)
+{
+    hipDeviceProp_t prop;
+    const hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(KBE_E_DEVICE, "hipGetDeviceProperties", e);
+    if (name && cap > 0) { strncpy(name, prop.gcnArchName, (size_t) cap - 1); name[cap - 1] = 0; }
+    return prop.multiProcessorCount;
+}
+
+int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream)
+{
+    KBE_REQUIRE(zkeys && n > 0, "kbe_zkeys_clear: bad arguments");
+    const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock < 4096 ? (n + kBlock - 1) / kBlock : 4096);
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid), dim3(kBlock), 0, (hipStream_t) stream, zkeys, n, KBE_ZKEY_EMPTY);
+    return launched("kbe_zkeys_clear");
+}
+
+int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, double baseline,
+               const float* shift3, uint32_t* zkeys, int32_t* winner, kbe_stream_t stream)
+{
+    KBE_REQUIRE(points && zkeys && B > 0 && N >= 0 && W > 0 && H > 0, "kbe_zsplat: bad arguments");
+    if (N == 0) return KBE_OK;
+    const Camera cam = make_camera(W, H, focal, baseline, shift3);
+    hipLaunchKernelGGL(k_zsplat, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, N, cam, zkeys, winner);
+    return launched("kbe_zsplat");
+}
+
+int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_stream_t stream)
+{
+    KBE_REQUIRE(zkeys && zee && n > 0, "kbe_zkeys_decode: bad arguments");
+    const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock < 4096 ? (n + kBlock - 1) / kBlock : 4096);
+    hipLaunchKernelGGL(k_zkeys_decode, dim3(grid), dim3(kBlock), 0, (hipStream_t) stream, zkeys, n, zee);
+    return launched("kbe_zkeys_decode");
+}
+
+int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out, kbe_stream_t stream)
+{
+    KBE_REQUIRE((zkeys || zee_in_f32) && zee_out && B > 0 && W > 0 && H > 0, "kbe_degrid: bad arguments");
+    const dim3 grid(blocks_for((size_t) W * H), B);
+    if (zee_in_f32)
+        hipLaunchKernelGGL(k_degrid<false>, grid, dim3(kBlock), 0, (hipStream_t) stream, zkeys, zee_in_f32, W, H, zee_out);
+    else
+        hipLaunchKernelGGL(k_degrid<true>, grid, dim3(kBlock), 0, (hipStream_t) stream, zkeys, zee_in_f32, W, H, zee_out);
+    return launched("kbe_degrid");
+}
+
+int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee, int W, int H,
+                   double focal, double baseline, const float* shift3, float* acc, kbe_stream_t stream)
+{
+    KBE_REQUIRE(points && zee && acc && (data || C == 0) && B > 0 && N >= 0 && C >= 0 && W > 0 && H > 0,
+                "kbe_accumulate: bad arguments");
+    if (N == 0) return KBE_OK;
+    const Camera cam = make_camera(W, H, focal, baseline, shift3);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, data, N, C, cam,
+                       zee, acc);
+    return launched("kbe_accumulate");
+}
+
+int kbe_normalize(const float* acc, int B, int C, int W, int H, float* render, float* existing, kbe_stream_t stream)
+{
+    KBE_REQUIRE(acc && render && existing && B > 0 && C >= 0 && W > 0 && H > 0, "kbe_normalize: bad arguments");
+    hipLaunchKernelGGL(k_normalize, dim3(blocks_for((size_t) W * H), B), dim3(kBlock), 0, (hipStream_t) stream, acc, C,
+                       W * H, render, existing);
+    return launched("kbe_normalize");
+}
+
+int kbe_render_pointcloud(const float* points, const float* data, int B, int N, int C, int W, int H, double focal,
+                          double baseline, uint32_t* zkeys, float* zee, float* acc, float* render, float* existing,
+                          kbe_stream_t stream)
+{
+    KBE_REQUIRE(zkeys && zee && acc, "kbe_render_pointcloud: scratch missing");
+    int rc;
+    if ((rc = kbe_zkeys_clear(zkeys, (size_t) B * H * W, stream))) return rc;
+    const hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (size_t) B * (C + 1) * H * W, (hipStream_t) stream);
+    if (e != hipSuccess) return fail(KBE_E_LAUNCH, "hipMemsetAsync(acc)", e);
+    if ((rc = kbe_zsplat(points, B, N, W, H, focal, baseline, nullptr, zkeys, nullptr, stream))) return rc;
+    if ((rc = kbe_degrid(zkeys, nullptr, B, W, H, zee, stream))) return rc;
+    if ((rc = kbe_accumulate(points, data, B, N, C, zee, W, H, focal, baseline, nullptr, acc, stream))) return rc;
+    return kbe_normalize(acc, B, C, W, H, render, existing, stream);
+}
+
+int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, int W, int H, float* output,
+                          kbe_stream_t stream)
+{
+    KBE_REQUIRE(input && depth && output && B > 0 && C > 0 && W > 0 && H > 0, "kbe_fill_disocclusion: bad arguments");
+    static const FillDirs dirs = make_fill_dirs();
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for((size_t) W * H), B), dim3(kBlock), 0, (hipStream_t) stream, input, depth, C,
+                       W, H, dirs, output);
+    return launched("kbe_fill_disocclusion");
+}
+
+int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
+                     double baseline, const float* shift3, uint32_t* zkeys, float* zee, float* acc, uint8_t* frame_u8,
+                     float* render_f32, float* existing_f32, kbe_stream_t stream)
+{
+    KBE_REQUIRE(points && image && depth && zkeys && zee && acc && frame_u8 && N >= 0 && W > 0 && H > 0,
+                "kbe_render_frame: bad arguments");
+    KBE_REQUIRE(image + 3 * (size_t) N == depth, "kbe_render_frame: v1 wants image[3,N] and depth[N] adjacent ([4,N] data)");
+    static const FillDirs dirs = make_fill_dirs();
+    const hipStream_t s = (hipStream_t) stream;
+    int rc;
+    const hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (size_t) 5 * H * W, s);
+    if (e != hipSuccess) return fail(KBE_E_LAUNCH, "hipMemsetAsync(acc)", e);
+    if ((rc = kbe_zsplat(points, 1, N, W, H, focal, baseline, shift3, zkeys, nullptr, stream))) return rc;
+    if ((rc = kbe_degrid(zkeys, nullptr, 1, W, H, zee, stream))) return rc;
+    if ((rc = kbe_accumulate(points, image, 1, N, 4, zee, W, H, focal, baseline, shift3, acc, stream))) return rc;
+    hipLaunchKernelGGL(k_resolve_frame, dim3(blocks_for((size_t) W * H)), dim3(kBlock), 0, s, acc, W, H, dirs, frame_u8,
+                       render_f32, existing_f32, zkeys);
+    return launched("kbe_render_frame");
+}
+
+int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream)
+{
+    KBE_REQUIRE(render_chw && frame_hwc && W > 0 && H > 0, "kbe_frame_u8: bad arguments");
+    hipLaunchKernelGGL(k_frame_u8, dim3(blocks_for((size_t) W * H)), dim3(kBlock), 0, (hipStream_t) stream, render_chw,
+                       W * H, frame_hwc);
+    return launched("kbe_frame_u8");
+}
+
+int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int crop_h, uint8_t* out_hwc,
+                       kbe_stream_t stream)
+{
+    KBE_REQUIRE(frame_hwc && out_hwc && W > 0 && H > 0 && crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H,
+                "kbe_crop_resize_u8: bad arguments");
+    hipLaunchKernelGGL(k_crop_resize_u8, dim3(blocks_for((size_t) W * H)), dim3(kBlock), 0, (hipStream_t) stream, frame_hwc,
+                       W, H, crop_w, crop_h, out_hwc);
+    return launched("kbe_crop_resize_u8");
+}
+
+int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, int H, double focal, float* points,
+                        kbe_stream_t stream)
+{
+    KBE_REQUIRE(depth && points && B > 0 && W > 0 && H > 0, "kbe_depth_to_points: bad arguments");
+    const float inv = (float) (1.0 / focal);
+    hipLaunchKernelGGL(k_depth_to_points, dim3(blocks_for((size_t) W * H), B), dim3(kBlock), 0, (hipStream_t) stream, depth,
+                       valid, W, H, inv, points);
+    return launched("kbe_depth_to_points");
+}
+
+int kbe_shift_points(const float* points, int B, int N, const float* shift3, float* out, kbe_stream_t stream)
+{
+    KBE_REQUIRE(points && out && shift3 && B > 0 && N >= 0, "kbe_shift_points: bad arguments");
+    if (N == 0) return KBE_OK;
+    const Camera cam = make_camera(1, 1, 1.0, 1.0, shift3);
+    hipLaunchKernelGGL(k_shift_points, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, N, cam, out);
+    return launched("kbe_shift_points");
+}
+
+int kbe_spatial_filter(const float* in, int planes, int W, int H, int kind, float* out, kbe_stream_t stream)
+{
+    KBE_REQUIRE(in && out && planes > 0 && W > 0 && H > 0, "kbe_spatial_filter: bad arguments");
+    const dim3 grid(blocks_for((size_t) W * H), planes);
+    const hipStream_t s = (hipStream_t) stream;
+    if (kind == 0) {
+        hipLaunchKernelGGL(k_laplacian<false>, grid, dim3(kBlock), 0, s, in, (const float*) nullptr, W, H, 0.0f, out);
+    } else if (kind == 3) {
+        KBE_REQUIRE(W >= 2 && H >= 2, "median-3 needs W, H >= 2 (reflect pad)");
+        hipLaunchKernelGGL(k_median<3>, grid, dim3(kBlock), 0, s, in, W, H, out);
+    } else if (kind == 5) {
+        KBE_REQUIRE(W >= 3 && H >= 3, "median-5 needs W, H >= 3 (reflect pad)");
+        hipLaunchKernelGGL(k_median<5>, grid, dim3(kBlock), 0, s, in, W, H, out);
+    } else {
+        return fail(KBE_E_INVALID, "kbe_spatial_filter: kind must be 0, 3 or 5");
+    }
+    return launched("kbe_spatial_filter");
+}
+
+int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int W, int H, float threshold, float* valid,
+                        kbe_stream_t stream)
+{
+    KBE_REQUIRE(in && scale_dev && valid && planes > 0 && W > 0 && H > 0, "kbe_laplacian_valid: bad arguments");
+    hipLaunchKernelGGL(k_laplacian<true>, dim3(blocks_for((size_t) W * H), planes), dim3(kBlock), 0, (hipStream_t) stream, in,
+                       scale_dev, W, H, threshold, valid);
+    return launched("kbe_laplacian_valid");
+}
+
+int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H, int W, int Cout,
+                       int Ho, int Wo, int k, int stride, int pad, float* out, float* um, kbe_stream_t stream)
+{
+    KBE_REQUIRE(raw && mask && out && um && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k > 0 &&
+                    stride > 0 && pad >= 0,
+                "kbe_pconv_epilogue: bad arguments");
+    hipLaunchKernelGGL(k_pconv_epilogue, dim3(blocks_for((size_t) Ho * Wo), B), dim3(kBlock), 0, (hipStream_t) stream, raw,
+                       bias, mask, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um);
+    return launched("kbe_pconv_epilogue");
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Frames of one video sharded over the GPUs of a node.
+
+The reference is single-process, single-GPU (no torch.distributed anywhere).  The only
+state a frame needs is the final point cloud (``tensorInpaPoints/Image/Depth``, 28*N
+bytes) plus a dozen scalars, and frames are independent of each other
+(``/root/reference/utils/common.py:222-260``).  So: one process per GPU, rank 0 builds
+the cloud (the two inpaint passes are serial, ``:181-219``), ONE broadcast hands it to
+the other ranks, every rank renders its own subset of ``dblSteps``, and the uint8
+frames are optionally gathered.  No all-reduce, no per-frame collective.
+
+Backend "nccl" is RCCL on ROCm (xGMI is point-to-point; a 31 MB one-to-all broadcast
+is ~0.2 ms and happens once per video); "gloo" runs the same code on CPU tensors for
+the world_size-2 tests.
+"""
+import torch
+import torch.distributed as dist
+
+_CLOUD_KEYS = ('tensorInpaPoints', 'tensorInpaImage', 'tensorInpaDepth')
+_SCALAR_KEYS = ('dblFocal', 'dblBaseline', 'intWidth', 'intHeight')
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_steps(steps, rank=None, world_size=None):
+    """Round-robin assignment of frame indices (balances hole-count variation along the
+    trajectory; contiguous blocks would put all the wide-baseline frames on one rank).
+    Returns (indices, steps) for this rank."""
+    if rank is None:
+        rank, world_size = world()
+    idx = list(range(rank, len(steps), world_size))
+    return idx, [steps[i] for i in idx]
+
+
+def broadcast_cloud(objectCommon, device, src=0):
+    """Rank `src` holds the finished cloud in ``objectCommon``; afterwards every rank does,
+    bit-identical (so frames are byte-identical to a single-GPU run).  Two collectives: a
+    small header (N and the scalars, incl. objectDepthrange) and one packed [7,N] fp32
+    payload."""
+    rank, world_size = world()
+    if world_size == 1:
+        return objectCommon
+    header = torch.zeros(16, dtype=torch.float64, device=device)
+    if rank == src:
+        dr = objectCommon['objectDepthrange']
+        vals = [objectCommon['tensorInpaPoints'].shape[-1]] + [objectCommon[k] for k in _SCALAR_KEYS] + \
+               [dr[0], dr[1], dr[2][0], dr[2][1], dr[3][0], dr[3][1], 1.0 if isinstance(objectCommon['dblBaseline'], int) else 0.0]
+        header[:len(vals)] = torch.tensor(vals, dtype=torch.float64)
+    dist.broadcast(header, src)
+    h = header.cpu().tolist()
+    n = int(h[0])
+    if rank == src:
+        packed = torch.cat([objectCommon[k].reshape(-1, n).float() for k in _CLOUD_KEYS], 0).contiguous().to(device)
+    else:
+        packed = torch.empty(7, n, dtype=torch.float32, device=device)
+    dist.broadcast(packed, src)
+    if rank != src:
+        objectCommon['dblFocal'] = h[1]
+        objectCommon['dblBaseline'] = int(h[2]) if h[12] == 1.0 else h[2]
+        objectCommon['intWidth'], objectCommon['intHeight'] = int(h[3]), int(h[4])
+        objectCommon['objectDepthrange'] = (h[5], h[6], (int(h[7]), int(h[8])), (int(h[9]), int(h[10])))
+        objectCommon['tensorInpaPoints'] = packed[0:3].unsqueeze(0)
+        objectCommon['tensorInpaImage'] = packed[3:6].unsqueeze(0)
+        objectCommon['tensorInpaDepth'] = packed[6:7].unsqueeze(0)
+    return objectCommon
+
+
+def gather_frames(local_frames, indices, total, device, dst=0):
+    """Collects per-rank uint8 frames [n_local,H,W,3] on rank `dst` in original step order.
+    Returns the full [total,H,W,3] tensor on `dst`, None elsewhere."""
+    rank, world_size = world()
+    if world_size == 1:
+        return local_frames
+    per = (total + world_size - 1) // world_size
+    H, W = local_frames.shape[1:3]
+    padded = torch.zeros(per, H, W, 3, dtype=torch.uint8, device=device)
+    padded[:local_frames.shape[0]] = local_frames.to(device)
+    bucket = [torch.empty_like(padded) for _ in range(world_size)] if rank == dst else None
+    dist.gather(padded, bucket, dst)
+    if rank != dst:
+        return None
+    out = torch.empty(total, H, W, 3, dtype=torch.uint8, device=device)
+    for r in range(world_size):
+        idx = list(range(r, total, world_size))
+        out[idx] = bucket[r][:len(idx)]
+    return out
+
+
+def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather=True):
+    """process_kenburns over all ranks: rank 0 builds the cloud, broadcast, each rank renders its
+    round-robin share of ``dblSteps``; with ``gather`` rank 0 returns the full frame list."""
+    from . import common
+    rank, world_size = world()
+    if rank == 0 and ('boolInpaint' not in objectSettings or objectSettings['boolInpaint']):
+        common.build_pointcloud(objectSettings, objectCommon, moduleInpaint)
+    elif rank == 0:
+        if 'tensorInpaPoints' not in objectCommon:
+            common._reset_inpa(objectCommon)
+    broadcast_cloud(objectCommon, device)
+    idx, steps = shard_steps(objectSettings['dblSteps'], rank, world_size)
+    local_settings = dict(objectSettings, dblSteps=steps)
+    crop = common.crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
+    frames = common.render_frames(common.frame_cameras(local_settings, objectCommon), objectCommon, crop, keep_on_device=True)
+    if not gather:
+        return [f for f in frames.cpu().numpy()]
+    full = gather_frames(frames, idx, len(objectSettings['dblSteps']), device)
+    return None if full is None else [f for f in full.cpu().numpy()]

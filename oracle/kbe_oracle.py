@@ -158,6 +158,47 @@ def frame_u8(render):
     return out.numpy()
 
 
+def crop_resize_u8(frame, crop_w, crop_h):
+    """cv2.getRectSubPix(frame, (crop_w, crop_h), (W/2, H/2)) followed by cv2.resize(.., (W, H), INTER_LINEAR)
+    (common.py:256-257) restated from the OpenCV 8-bit algorithms: 16-bit fixed-point
+    sub-pixel weights, then 11-bit fixed-point bilinear coefficients with src = (dst + 0.5) * scale - 0.5.
+    PARITY UNPINNED: OpenCV is not available in this image; this only checks the HIP kernel against the
+    same written-down algorithm."""
+    H, W, _ = frame.shape
+    img = frame.astype(np.int64)
+    cx = np.float32(W) / np.float32(2.0) - np.float32(crop_w - 1) * np.float32(0.5)
+    cy = np.float32(H) / np.float32(2.0) - np.float32(crop_h - 1) * np.float32(0.5)
+    ipx, ipy = int(np.floor(cx)), int(np.floor(cy))
+    a, b = np.float32(cx - np.float32(ipx)), np.float32(cy - np.float32(ipy))
+    one = np.float32(1.0)
+    s16 = np.float32(65536.0)
+    a11 = int(np.rint((one - a) * (one - b) * s16)); a12 = int(np.rint(a * (one - b) * s16))
+    a21 = int(np.rint((one - a) * b * s16)); a22 = int(np.rint(a * b * s16))
+    xs0 = np.clip(ipx + np.arange(crop_w), 0, W - 1); xs1 = np.clip(ipx + np.arange(crop_w) + 1, 0, W - 1)
+    ys0 = np.clip(ipy + np.arange(crop_h), 0, H - 1); ys1 = np.clip(ipy + np.arange(crop_h) + 1, 0, H - 1)
+    patch = (img[ys0][:, xs0] * a11 + img[ys0][:, xs1] * a12 + img[ys1][:, xs0] * a21 + img[ys1][:, xs1] * a22 + (1 << 15)) >> 16
+
+    def coeffs(dst_n, src_n):
+        d = np.arange(dst_n, dtype=np.float64)
+        f = ((d + 0.5) * (float(src_n) / dst_n) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0; s[lo] = 0
+        hi = s >= src_n - 1
+        f[hi] = 0; s[hi] = src_n - 1
+        c0 = np.rint((one - f) * np.float32(2048.0)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+        return s, np.minimum(s + 1, src_n - 1), c0, c1
+
+    sx, sx1, ax0, ax1 = coeffs(W, crop_w)
+    sy, sy1, by0, by1 = coeffs(H, crop_h)
+    rows = patch[:, sx] * ax0[None, :, None] + patch[:, sx1] * ax1[None, :, None]          # [crop_h, W, 3], x2048
+    r0, r1 = rows[sy], rows[sy1]
+    v = (((by0[:, None, None] * (r0 >> 4)) >> 16) + ((by1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def pconv_epilogue(raw, bias, mask, kernel_size, stride, padding):
     raw, mask = _f32(raw), _f32(mask)
     B, Cout, Ho, Wo = raw.shape
@@ -187,8 +228,8 @@ class OracleKernels:
     def fill_disocclusion(self, x, depth):
         return fill_disocclusion(x, depth)
 
-    def depth_to_points(self, depth, focal):
-        return depth_to_points(depth, focal)
+    def depth_to_points(self, depth, focal, valid=None):
+        return depth_to_points(depth if valid is None else _f32(depth) * _f32(valid), focal)
 
     def shift_points(self, points, shift3):
         return shift_points(points, shift3)
@@ -203,13 +244,21 @@ class OracleKernels:
     def frame_u8(self, render):
         return torch.from_numpy(frame_u8(render[0]))
 
-    def render_frame(self, cloud, shift3, W, H, focal, baseline):
+    def prepare_cloud(self, points, image, depth, W, H):
+        return {'points': _f32(points).reshape(1, 3, -1), 'image': _f32(image).reshape(1, 3, -1),
+                'depth': _f32(depth).reshape(1, 1, -1), 'W': int(W), 'H': int(H)}
+
+    def render_frame(self, state, shift3, focal, baseline, want_float=False):
         """shift -> render(4 ch) -> fill -> uint8, the per-frame body of common.py:238-255."""
-        pts = shift_points(cloud['points'], shift3)
-        data = torch.cat([cloud['image'], cloud['depth']], 1)
-        render, existing = self.render_pointcloud(pts, data, W, H, focal, baseline)
+        pts = shift_points(state['points'], torch.tensor(shift3, dtype=torch.float32))
+        data = torch.cat([state['image'], state['depth']], 1)
+        render, existing = self.render_pointcloud(pts, data, state['W'], state['H'], focal, baseline)
         filled = fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())
-        return torch.from_numpy(frame_u8(filled[0]))
+        frame = torch.from_numpy(frame_u8(filled[0]))
+        return (frame, filled, existing) if want_float else frame
+
+    def crop_resize_u8(self, frame, crop_w, crop_h):
+        return torch.from_numpy(crop_resize_u8(frame.numpy(), crop_w, crop_h))
 
     def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding):
         return pconv_epilogue(raw, bias, mask, kernel_size, stride, padding)

@@ -1,0 +1,280 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): z-buffer and winner indices bit-exact; byte / index / mask work
+bit-exact; accumulated colour within fp32 summation-order noise (tolerances written at each
+assertion); frames within 1e-3 dB PSNR of the oracle's.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RENDER_CASES = ['render_f512', 'render_f409', 'render_f153', 'render_noise', 'render_b2c7']
+
+
+@pytest.fixture(scope='module')
+def K():
+    from ken_burns_effect_amd import _native
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return _native.kernels()          # raises if libkbe_hip.so is missing: no fallback
+
+
+def g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def c(t):
+    return t.detach().cpu().numpy()
+
+
+def _baseline(z):
+    b = float(z['baseline'])
+    return int(b) if bool(z['baseline_is_int']) else b
+
+
+def psnr(a, b, peak):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 200.0 if mse == 0 else 10.0 * np.log10(peak * peak / mse)
+
+
+# ---------------------------------------------------------------------------------------
+# render_pointcloud stages on the golden inputs
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_zbuffer_and_winners_bit_exact(K, oracle, case):
+    z = load_golden(case)
+    W, H, F, Bl = int(z['W']), int(z['H']), float(z['focal']), _baseline(z)
+    zkeys, winner = K.zsplat(g(z['points']), W, H, F, Bl, want_winner=True)
+    assert_bits_equal(c(K.zkeys_decode(zkeys)), z['zee_pre_fma'], 'pre-degrid z-buffer vs reference')
+    _, ow = oracle.zsplat(torch.from_numpy(z['points']), W, H, F, Bl, want_winner=True)
+    assert np.array_equal(c(winner), ow.numpy()), 'winner pixel index per point vs oracle'
+    if 'winner_fma' in z.files:
+        assert np.array_equal(c(winner), z['winner_fma']), 'winner pixel index per point vs reference'
+
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_degrid_jacobi_bit_exact(K, oracle, case):
+    z = load_golden(case)
+    pre = torch.from_numpy(z['zee_pre_fma'])
+    want = oracle.degrid(pre, 'jacobi').numpy()
+    assert_bits_equal(c(K.degrid(zee=g(z['zee_pre_fma']))), want, 'degrid from fp32')
+    zkeys, _ = K.zsplat(g(z['points']), int(z['W']), int(z['H']), float(z['focal']), _baseline(z))
+    assert_bits_equal(c(K.degrid(zkeys=zkeys)), want, 'degrid from keys')
+
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_accumulate_and_normalize(K, oracle, case):
+    z = load_golden(case)
+    F, Bl = float(z['focal']), _baseline(z)
+    # same z-buffer as the reference run (serial schedule) so that acc is comparable to the golden
+    acc = c(K.accumulate(g(z['points']), g(z['data']), g(z['zee_serial_fma']), F, Bl))
+    want = z['acc_fma']
+    # atomic order differs from point-index order: a few ulp of the largest partial sum per pixel
+    tol = 1e-5 * np.maximum(np.abs(want), 1.0)
+    assert (np.abs(acc - want) <= tol).all()
+    assert np.array_equal(acc == 0, want == 0), 'exactly the same pixels/channels are touched'
+    render, existing = K.normalize(g(want))
+    assert_bits_equal(c(render), z['render_fma'], 'normalise')
+    assert_bits_equal(c(existing), z['existing_fma'], 'existing')
+
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_render_pointcloud_whole(K, oracle, case):
+    z = load_golden(case)
+    W, H, F, Bl = int(z['W']), int(z['H']), float(z['focal']), _baseline(z)
+    render, existing = K.render_pointcloud(g(z['points']), g(z['data']), W, H, F, Bl)
+    r0, e0 = oracle.render_pointcloud(torch.from_numpy(z['points']), torch.from_numpy(z['data']), W, H, F, Bl, 'jacobi')
+    assert np.array_equal(c(existing) > 0, e0.numpy() > 0), 'hole mask identical'
+    assert np.abs(c(existing) - e0.numpy()).max() <= 1e-5 * max(1.0, float(e0.max()))
+    scale = np.maximum(np.abs(r0.numpy()), 1.0)
+    assert (np.abs(c(render) - r0.numpy()) <= 2e-5 * scale).all()
+
+
+def test_shift_fused_equals_shift_then_render(K):
+    z = load_golden('render_f512')
+    W, H, F, Bl = int(z['W']), int(z['H']), float(z['focal']), _baseline(z)
+    pts = g(z['points'])
+    shift = [3.25, -1.5, -12.0]
+    a, wa = K.zsplat(K.shift_points(pts, shift), W, H, F, Bl, want_winner=True)
+    b, wb = K.zsplat(pts, W, H, F, Bl, shift3=shift, want_winner=True)
+    assert torch.equal(a, b) and torch.equal(wa, wb)
+
+
+# ---------------------------------------------------------------------------------------
+# fill, torch glue
+# ---------------------------------------------------------------------------------------
+
+def test_fill_bit_exact(K):
+    z = load_golden('fill')
+    for tag in ('a', 'b', 'allholes'):
+        out = K.fill_disocclusion(g(z['input_' + tag]), g(z['depth_' + tag]))
+        assert_bits_equal(c(out), z['output_' + tag], 'fill ' + tag)
+    out = K.fill_disocclusion(g(z['input_allholes']), g(z['depth_allholes']) + 1.0)
+    assert_bits_equal(c(out), z['output_noholes'], 'no holes')
+
+
+def test_torch_glue_bit_exact(K, oracle):
+    z = load_golden('torch_helpers')
+    for tag in 'abc':
+        out = K.depth_to_points(g(z['d2p_depth_' + tag]), float(z['d2p_focal_' + tag]))
+        assert_bits_equal(c(out), z['d2p_points_' + tag], 'depth_to_points')
+    for i in range(3):
+        out = K.shift_points(g(z['ps_points']), g(z['ps_shift_%d' % i]))
+        assert_bits_equal(c(out), z['ps_out_%d' % i], 'process_shift')
+    for tag in 'ab':
+        x = z['sf_input_' + tag]
+        for kind in ('median-3', 'median-5'):
+            assert_bits_equal(c(K.spatial_filter(g(x), kind)), z['sf_%s_%s' % (kind, tag)], kind)
+        lap = c(K.spatial_filter(g(x), 'laplacian'))
+        assert_bits_equal(lap, oracle.spatial_filter(torch.from_numpy(x), 'laplacian').numpy(), 'laplacian vs oracle')
+        assert np.abs(lap - z['sf_laplacian_' + tag]).max() <= 16 * np.finfo(np.float32).eps * np.abs(x).max()
+    assert_bits_equal(c(K.spatial_filter(g(z['sf_input_mask']), 'median-5')), z['sf_median-5_mask'], 'median-5 mask')
+    assert K.spatial_filter(g(z['sf_input_mask']), 'gaussian') is None
+    disp = g(z['sf_input_disp'])
+    valid = c(K.laplacian_valid(disp, disp.max(), 0.03))
+    d0 = torch.from_numpy(z['sf_input_disp'])
+    want = (oracle.spatial_filter(d0 / d0.max(), 'laplacian').abs() < 0.03).float().numpy()
+    assert_bits_equal(valid, want, 'laplacian_valid vs oracle')
+    assert (valid != z['sf_valid_disp']).mean() <= 0.002
+
+
+def test_pconv_epilogue(K, oracle):
+    z = load_golden('partial_conv')
+    for tag in 'abc':
+        cin, cout, k, s, p = [int(v) for v in z['cfg_' + tag]]
+        x, m = torch.from_numpy(z['x_' + tag]), torch.from_numpy(z['m_' + tag])
+        raw = torch.nn.functional.conv2d(x * m, torch.from_numpy(z['w_' + tag]), torch.from_numpy(z['b_' + tag]), stride=s, padding=p)
+        out, um = K.pconv_epilogue(raw.cuda(), g(z['b_' + tag]), m.cuda(), k, s, p)
+        o0, u0 = oracle.pconv_epilogue(raw, torch.from_numpy(z['b_' + tag]), m, k, s, p)
+        assert_bits_equal(c(out), o0.numpy(), 'pconv out vs oracle')
+        assert_bits_equal(c(um), u0.numpy(), 'pconv mask vs oracle')
+        assert_bits_equal(c(um.expand(-1, cout, -1, -1)), z['mask_' + tag], 'update_mask vs reference')
+
+
+def test_crop_resize_matches_written_algorithm(K, oracle):
+    rng = np.random.default_rng(5)
+    for (H, W, cw, ch) in [(48, 64, 57, 43), (48, 64, 58, 44), (96, 128, 115, 86), (33, 47, 47, 33)]:
+        f = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+        out = c(K.crop_resize_u8(torch.from_numpy(f).cuda(), cw, ch))
+        assert np.array_equal(out, oracle.crop_resize_u8(f, cw, ch))
+
+
+# ---------------------------------------------------------------------------------------
+# whole frames
+# ---------------------------------------------------------------------------------------
+
+def _scene(size, seed=0, kind='smooth', dolly=False):
+    from ken_burns_effect_amd import common, synthetic
+    image, disp = synthetic.make_rgbd(size[0], size[1], seed, kind)
+    depth = (512.0 * 120) / (disp + 1e-7)
+    Kn = common._K()
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': size[1], 'intHeight': size[0],
+          'objectDepthrange': synthetic.depthrange_of(depth), 'tensorRawImage': image.cuda(),
+          'tensorRawDisparity': disp.cuda(), 'tensorRawDepth': depth.cuda()}
+    oc['tensorRawPoints'] = Kn.depth_to_points(oc['tensorRawDepth'], 512.0).view(1, 3, -1)
+    common._reset_inpa(oc)
+    ofrom, oto = synthetic.default_windows(size[0], size[1], dolly)
+    settings = {'dblSteps': [0.0, 0.5, 1.0], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': False, 'dolly': dolly,
+                'boolCrop': False}
+    return settings, oc
+
+
+@pytest.mark.parametrize('size,kind,dolly', [((96, 128), 'smooth', False), ((256, 256), 'smooth', True),
+                                              ((200, 312), 'noise', False), ((512, 512), 'smooth', False)])
+def test_frames_match_oracle(K, oracle, size, kind, dolly):
+    from ken_burns_effect_amd import common
+    settings, oc = _scene(size, 3, kind, dolly)
+    cams = common.frame_cameras(settings, oc)
+    frames = common.render_frames(cams, oc, None)
+    ok = oracle.OracleKernels('jacobi')
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), size[1], size[0])
+    src = (oc['tensorRawImage'][0].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
+    hip_state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], size[1], size[0])
+    for f, (focal, shift3) in zip(frames, cams):
+        ref, ref_float, ref_existing = ok.render_frame(state, shift3, focal, oc['dblBaseline'], want_float=True)
+        ref = ref.numpy()
+        # uint8 truncation can flip a value sitting on an integer boundary by one count
+        d = np.abs(f.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        # "within 1e-3 PSNR": both frames score the same against any third image
+        assert abs(psnr(f, src, 255.0) - psnr(ref, src, 255.0)) < 1e-3
+        # the float render behind the frame
+        rf = torch.empty(4, size[0], size[1], device='cuda')
+        ex = torch.empty(size[0] * size[1], device='cuda')
+        K.render_frame(hip_state, shift3, focal, oc['dblBaseline'], render_f32=rf, existing_f32=ex)
+        assert np.array_equal(c(ex).reshape(size) > 0, ref_existing.numpy()[0, 0] > 0), 'same holes'
+        assert psnr(c(rf)[:3], ref_float.numpy()[0, :3], 1.0) > 100.0
+
+
+def test_full_size_zbuffer_is_the_min_over_winners(K):
+    """1024x1024 (BASELINE.json size): the z-buffer must equal an independent scatter-min of
+    dblError over each point's winner pixel (torch, fp64 -> fp32), bit for bit."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene((1024, 1024), 0)
+    focal, shift3 = common.frame_cameras(settings, oc)[2]
+    pts = oc['tensorInpaPoints']
+    zkeys, winner = K.zsplat(pts, 1024, 1024, focal, 120, shift3=shift3, want_winner=True)
+    zee = K.zkeys_decode(zkeys).view(-1)
+    shifted = K.shift_points(pts, shift3)
+    err = (1000000.0 - (focal * 120) / (shifted[0, 2].double() + 0.0000001)).float()
+    w = winner[0].long()
+    keep = w >= 0
+    want = torch.full((1024 * 1024,), 1000000.0, device='cuda')
+    want.scatter_reduce_(0, w[keep], err[keep], reduce='amin')
+    assert torch.equal(zee.view(torch.int32), want.view(torch.int32))
+    assert int(keep.sum()) > 900000
+
+
+def test_full_size_identity_camera_reproduces_the_image(K):
+    """No shift, same focal: every point lands on its own pixel -> the frame is the source image."""
+    settings, oc = _scene((1024, 1024), 1)
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], 1024, 1024)
+    rf = torch.empty(4, 1024, 1024, device='cuda')
+    ex = torch.empty(1024 * 1024, device='cuda')
+    K.render_frame(state, [0.0, 0.0, 0.0], 512.0, 120, render_f32=rf, existing_f32=ex)
+    assert float((ex > 0).float().mean()) == 1.0
+    assert float((rf[:3] - oc['tensorRawImage'][0]).abs().max()) < 1e-3
+
+
+def test_full_size_linearity_in_the_data(K):
+    """accumulate + normalise are linear in the data channels (size-independent property)."""
+    settings, oc = _scene((1024, 1024), 2)
+    from ken_burns_effect_amd import common
+    focal, shift3 = common.frame_cameras(settings, oc)[1]
+    pts = K.shift_points(oc['tensorInpaPoints'], shift3)
+    d1 = oc['tensorInpaImage']
+    d2 = torch.rand_like(d1)
+    ra, _ = K.render_pointcloud(pts, d1, 1024, 1024, focal, 120)
+    rb, _ = K.render_pointcloud(pts, d2, 1024, 1024, focal, 120)
+    rc, _ = K.render_pointcloud(pts, 0.25 * d1 + 2.0 * d2, 1024, 1024, focal, 120)
+    assert float((rc - (0.25 * ra + 2.0 * rb)).abs().max()) < 1e-4
+
+
+def test_render_frame_leaves_zkeys_clean_and_is_repeatable(K):
+    settings, oc = _scene((256, 320), 4)
+    from ken_burns_effect_amd import common
+    focal, shift3 = common.frame_cameras(settings, oc)[2]
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], 320, 256)
+    a = K.render_frame(state, shift3, focal, 120).clone()
+    assert int((state['zkeys'] != -0x368BDC00).sum()) == 0       # KBE_ZKEY_EMPTY as int32
+    b = K.render_frame(state, shift3, focal, 120).clone()
+    assert (a.int() - b.int()).abs().max() <= 1
+
+
+def test_empty_and_single_point_clouds(K):
+    z, w = K.zsplat(torch.zeros(1, 3, 0, device='cuda'), 8, 6, 512.0, 120, want_winner=True)
+    assert int((K.zkeys_decode(z) != 1000000.0).sum()) == 0 and w.numel() == 0
+    pts = torch.tensor([[[0.0], [0.0], [600.0]]], device='cuda')
+    r, e = K.render_pointcloud(pts, torch.ones(1, 2, 1, device='cuda'), 8, 6, 512.0, 120)
+    assert float(e.sum()) == pytest.approx(1.0, abs=1e-6)
+
+
+def test_invalid_arguments_return_errors_not_crashes(K):
+    import ctypes
+    assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, None, None, None) == -1
+    assert b'kbe_zsplat' in K.lib.kbe_last_error()
+    assert K.lib.kbe_spatial_filter(ctypes.c_void_p(8), 1, 4, 4, 7, ctypes.c_void_p(8), None) == -1

@@ -1,0 +1,139 @@
+"""Host logic of ken_burns_effect_amd.common (camera path, point-cloud growth, frame loop) on CPU.
+
+The kernel set is substituted EXPLICITLY with the oracle here (tests only); the product has no
+CPU path.  Golden traces come from the reference's process_kenburns (serial degrid schedule,
+pre-crop frames because the generator's cv2 stand-ins were identities).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bits_equal, load_golden
+
+
+@pytest.fixture()
+def common(oracle, monkeypatch):
+    from ken_burns_effect_amd import common as C
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+    return C
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _depthrange(v):
+    return (float(v[0]), float(v[1]), (int(v[2]), int(v[3])), (int(v[4]), int(v[5])))
+
+
+def _scene(z):
+    from ken_burns_effect_amd import synthetic
+    image, disp = _t(z['image']), _t(z['disparity'])
+    H, W = image.shape[2:]
+    depth = (512.0 * 120) / (disp + 1e-7)
+    from oracle import kbe_oracle
+    pts = kbe_oracle.depth_to_points(depth, 512.0)
+    common = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H,
+              'dblDispmin': disp.min().item(), 'dblDispmax': disp.max().item(),
+              'objectDepthrange': _depthrange(z['depthrange']), 'tensorRawPoints': pts.view(1, 3, -1),
+              'tensorRawImage': image, 'tensorRawDisparity': disp, 'tensorRawDepth': depth}
+    assert synthetic.depthrange_of(depth) == common['objectDepthrange']
+    ofrom, oto = synthetic.default_windows(H, W, bool(z['dolly']))
+    settings = {'dblSteps': [float(s) for s in z['steps']], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True,
+                'dolly': bool(z['dolly']), 'boolCrop': False}
+    return settings, common
+
+
+class ReplayInpaint:
+    """Returns what the reference's Inpaint returned for the same call (recorded in the fixture)."""
+
+    def __init__(self, z):
+        self.z, self.i, self.shifts = z, 0, []
+
+    def pointcloud_inpainting(self, tensorImage, tensorDisparity, tensorShift, objectCommon, dblFocal=None):
+        out = {k: _t(self.z['inpaint%d_%s' % (self.i, k)]) for k in ('tensorExisting', 'tensorImage', 'tensorDisparity')}
+        self.i += 1
+        self.shifts.append(tensorShift.clone())
+        return out
+
+
+def test_process_shift_matches_reference(common):
+    z = load_golden('torch_helpers')
+    oc = {'dblFocal': 512.0, 'intWidth': 32, 'intHeight': 24, 'objectDepthrange': _depthrange(z['ps_depthrange'])}
+    pts = _t(z['ps_points'])
+    for i, (su, sv, ratio, focal) in enumerate(z['ps_settings']):
+        st = {'tensorPoints': pts, 'dblShiftU': float(su), 'dblShiftV': float(sv), 'dblDepthFrom': oc['objectDepthrange'][0],
+              'dblDepthTo': oc['objectDepthrange'][0] * float(ratio)}
+        out, shift = common.process_shift(st, oc) if focal < 0 else common.process_shift(st, oc, float(focal))
+        assert_bits_equal(shift.numpy(), z['ps_shift_%d' % i], 'tensorShift')
+        assert_bits_equal(out.numpy(), z['ps_out_%d' % i], 'shifted points')
+    assert_bits_equal(pts.numpy(), z['ps_points'], 'inputs are never mutated')
+
+
+def test_dolly_trace_matches_reference(common):
+    z = load_golden('kenburns_dolly')
+    settings, oc = _scene(z)
+    frames = common.process_kenburns(settings, oc, None)
+    assert len(frames) == len(z['frames'])
+    for f, g in zip(frames, z['frames']):
+        assert f.dtype == np.uint8 and np.array_equal(f, g)
+    assert oc['tensorInpaPoints'].shape[2] == z['inpa_points'].shape[2]    # dolly never inpaints (common.py:217)
+
+
+def test_kenburns_trace_matches_reference(common):
+    z = load_golden('kenburns_kbe')
+    settings, oc = _scene(z)
+    frames = common.process_kenburns(settings, oc, ReplayInpaint(z))
+    for key, name in (('tensorInpaPoints', 'inpa_points'), ('tensorInpaImage', 'inpa_image'),
+                      ('tensorInpaDepth', 'inpa_depth'), ('tensorInpaDisparity', 'inpa_disparity')):
+        assert_bits_equal(oc[key].numpy(), z[name], key)
+    for f, g in zip(frames, z['frames']):
+        assert np.array_equal(f, g)
+
+
+def test_jacobi_schedule_stays_close_to_serial(oracle, monkeypatch):
+    """The normative (out-of-place) degrid differs from the serial reference schedule only slightly;
+    the gap is reported, not hidden."""
+    from ken_burns_effect_amd import common as C
+    z = load_golden('kenburns_dolly')
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='jacobi'))
+    settings, oc = _scene(z)
+    frames = C.process_kenburns(settings, oc, None)
+    # These 40x56 scenes carry full-size disparity ranges (steep per-pixel depth steps) and white-noise
+    # colours, so they are far more degrid-sensitive than a real image: ~5-9 % of the uint8 values move.
+    # Both schedules are legal outcomes of the reference's racy in-place kernel (common.py:556-566).
+    diff = np.mean([np.mean(f != g) for f, g in zip(frames, z['frames'])])
+    assert 0.0 < diff < 0.25
+
+
+def test_crop_is_applied_by_default(common):
+    z = load_golden('kenburns_dolly')
+    settings, oc = _scene(z)
+    settings.pop('boolCrop')
+    frames = common.process_kenburns(settings, oc, None)
+    from oracle import kbe_oracle
+    cw, ch = common.crop_size(settings)
+    for f, g in zip(frames, z['frames']):
+        assert np.array_equal(f, kbe_oracle.crop_resize_u8(g, cw, ch))
+
+
+def test_process_load_with_disparity_bypass(common):
+    from ken_burns_effect_amd import synthetic
+    image, disp = synthetic.make_rgbd(40, 48, 9)
+    img8 = (image[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    oc = {}
+    common.process_load(img8, {'tensorDisparity': disp, 'device': 'cpu'}, oc)
+    for k in ('dblFocal', 'dblBaseline', 'intWidth', 'intHeight', 'dblDispmin', 'dblDispmax', 'objectDepthrange', 'tensorRawImage',
+              'tensorRawDisparity', 'tensorRawDepth', 'tensorRawPoints', 'tensorRawUnaltered', 'tensorInpaImage',
+              'tensorInpaDisparity', 'tensorInpaDepth', 'tensorInpaPoints'):
+        assert k in oc
+    assert oc['dblBaseline'] == 40.0 and oc['dblFocal'] == 512.0
+    assert oc['tensorRawPoints'].shape == (1, 3, 40 * 48)
+    assert abs(oc['dblDispmax'] - 40.0) < 1e-4
+
+
+def test_product_refuses_to_run_without_gpu_library_or_tensors():
+    """No silent fallback: CPU tensors are rejected by the HIP binding."""
+    from ken_burns_effect_amd import _native
+    with pytest.raises(_native.KbeError):
+        _native._ptr(torch.zeros(4))
