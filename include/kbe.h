@@ -38,6 +38,13 @@ extern "C" {
 
 #define KBE_ABI_VERSION 1
 
+/* the library is built with -fvisibility=hidden; only these entry points are exported */
+#if defined(__GNUC__)
+#define KBE_API __attribute__((visibility("default")))
+#else
+#define KBE_API
+#endif
+
 enum {
     KBE_OK = 0,
     KBE_E_INVALID = -1,   /* null pointer, non-positive size, unsupported kernel size ...   */
@@ -51,18 +58,18 @@ typedef void* kbe_stream_t;   /* hipStream_t */
    reference's CAS-loop float atomicMin (common.py:275-283) becomes one native atomic. */
 #define KBE_ZKEY_EMPTY 0xC9742400u   /* key of 1000000.0f, the z-buffer's initial value (:430) */
 
-int kbe_abi_version(void);
+KBE_API int kbe_abi_version(void);
 /* static string describing the last failing HIP call of the calling thread ("" if none) */
-const char* kbe_last_error(void);
+KBE_API const char* kbe_last_error(void);
 /* fills name (<= cap bytes) with the device's gcnArchName, returns CU count or KBE_E_DEVICE */
-int kbe_device_info(int device, char* name, int cap);
+KBE_API int kbe_device_info(int device, char* name, int cap);
 
 /* ---------------------------------------------------------------------------------------
  * render_pointcloud, stage by stage  (common.py:428-686)
  * ------------------------------------------------------------------------------------- */
 
 /* zkeys[n] = KBE_ZKEY_EMPTY  -- replaces `new_zeros(...).fill_(1000000.0)` (common.py:430) */
-int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream);
+KBE_API int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream);
 
 /* kernel_pointrender_updateZee (common.py:435-507): project every point, pick the corner
    with the largest bilinear weight, min-splat its dblError.  If `shift3` is non-NULL (HOST
@@ -70,38 +77,38 @@ int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream);
    each point on the fly: x' = x * (z / (z + 1e-7f)) + sx, ... so the shifted cloud is never
    materialised.  `winner` (optional, [B,N] int32) receives each point's target pixel index
    y*W+x or -1 -- the "z-buffer index" of the parity contract. */
-int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, double baseline,
+KBE_API int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, double baseline,
                const float* shift3, uint32_t* zkeys, int32_t* winner, kbe_stream_t stream);
 
 /* zkeys -> fp32 z-buffer without degrid (test/debug view of the pre-degrid buffer) */
-int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_stream_t stream);
+KBE_API int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_stream_t stream);
 
 /* kernel_pointrender_updateDegrid (common.py:525-568), out of place: reads keys, writes the
    degridded fp32 z-buffer.  `zee_in_f32`, if non-NULL, is used instead of the keys. */
-int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out,
+KBE_API int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out,
                kbe_stream_t stream);
 
 /* kernel_pointrender_updateOutput (common.py:586-669): z-tested bilinear accumulation of
    C data channels plus the weight channel into acc [B,C+1,H,W] (zeroed by the caller,
    common.py:431).  data may be NULL only when C == 0. */
-int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee,
+KBE_API int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee,
                    int W, int H, double focal, double baseline, const float* shift3, float* acc,
                    kbe_stream_t stream);
 
 /* common.py:686: render = acc[:, :C] / (acc[:, C:] + 1e-7f), existing = acc[:, C:] */
-int kbe_normalize(const float* acc, int B, int C, int W, int H, float* render, float* existing,
+KBE_API int kbe_normalize(const float* acc, int B, int C, int W, int H, float* render, float* existing,
                   kbe_stream_t stream);
 
 /* The whole of render_pointcloud.  scratch: zkeys [B*H*W] u32, zee [B*H*W] f32,
    acc [B*(C+1)*H*W] f32 (contents on entry are irrelevant). */
-int kbe_render_pointcloud(const float* points, const float* data, int B, int N, int C, int W, int H,
+KBE_API int kbe_render_pointcloud(const float* points, const float* data, int B, int N, int C, int W, int H,
                           double focal, double baseline, uint32_t* zkeys, float* zee, float* acc,
                           float* render, float* existing, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * fill_disocclusion  (common.py:833-937)
  * ------------------------------------------------------------------------------------- */
-int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, int W, int H,
+KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, int W, int H,
                           float* output, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -113,19 +120,19 @@ int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, 
  * outputs: frame_u8 [H,W,3]; render_f32 (optional, [4,H,W]: the filled float render, for
  *          parity checks); existing_f32 (optional, [H*W]).
  * ------------------------------------------------------------------------------------- */
-int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
+KBE_API int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
                      double focal, double baseline, const float* shift3, uint32_t* zkeys, float* zee,
                      float* acc, uint8_t* frame_u8, float* render_f32, float* existing_f32,
                      kbe_stream_t stream);
 
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
-int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);
+KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);
 
 /* common.py:256-257 equivalent on device: centred crop of (crop_w x crop_h) as cv2.getRectSubPix
    samples it, then bilinear resize back to (W x H) as cv2.resize(INTER_LINEAR) does on 8-bit
    images (fixed-point coefficients).  Parity with OpenCV is UNPINNED (OpenCV is not in the
    image). */
-int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int crop_h,
+KBE_API int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int crop_h,
                        uint8_t* out_hwc, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -134,23 +141,23 @@ int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int c
 
 /* depth_to_points (common.py:382-392): depth [B,1,H,W] -> points [B,3,H,W].
    `valid` (optional, [B,1,H,W]) multiplies the depth first (common.py:71). */
-int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, int H, double focal,
+KBE_API int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, int H, double focal,
                         float* points, kbe_stream_t stream);
 
 /* process_shift's tensor part (common.py:104-109), materialised (API compatibility) */
-int kbe_shift_points(const float* points, int B, int N, const float* shift3, float* out,
+KBE_API int kbe_shift_points(const float* points, int B, int N, const float* shift3, float* out,
                      kbe_stream_t stream);
 
 /* spatial_filter (common.py:394-426) over `planes` = B*C independent [H,W] planes.
    kind: 0 = 'laplacian' (replicate pad, the reference's asymmetric taps),
          3 = 'median-3', 5 = 'median-5' (reflect pad, lower median). */
-int kbe_spatial_filter(const float* in, int planes, int W, int H, int kind, float* out,
+KBE_API int kbe_spatial_filter(const float* in, int planes, int W, int H, int kind, float* out,
                        kbe_stream_t stream);
 
 /* (|laplacian(x / *scale_dev)| < threshold) as 0/1 floats -- the validity mask of
    common.py:70 and pointcloud_inpainting.py:193.  scale_dev: DEVICE pointer to one float
    (tensor.max()), so no host sync is needed. */
-int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int W, int H,
+KBE_API int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int W, int H,
                         float threshold, float* valid, kbe_stream_t stream);
 
 /* PartialConv2d mask bookkeeping fused into one pass (utils/partial_conv.py:62-77,
@@ -158,7 +165,7 @@ int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int
    um = clamp(msum, 0, 1); ratio = Cin*k*k / (msum + 1e-8) * um;
    out = ((raw - bias) * ratio + bias) * um   (bias NULL: out = raw * ratio).
    raw/out [B,Cout,Ho,Wo] (may alias), mask [B,Cin,H,W], um [B,1,Ho,Wo]. */
-int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H,
+KBE_API int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H,
                        int W, int Cout, int Ho, int Wo, int k, int stride, int pad, float* out,
                        float* um, kbe_stream_t stream);
 

@@ -542,8 +542,9 @@ int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream)
 int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, double baseline,
                const float* shift3, uint32_t* zkeys, int32_t* winner, kbe_stream_t stream)
 {
-    KBE_REQUIRE(points && zkeys && B > 0 && N >= 0 && W > 0 && H > 0, "kbe_zsplat: bad arguments");
-    if (N == 0) return KBE_OK;
+    KBE_REQUIRE(zkeys && B > 0 && N >= 0 && W > 0 && H > 0, "kbe_zsplat: bad arguments");
+    if (N == 0) return KBE_OK;      // an empty cloud touches nothing (points may be NULL then)
+    KBE_REQUIRE(points, "kbe_zsplat: points is NULL");
     const Camera cam = make_camera(W, H, focal, baseline, shift3);
     hipLaunchKernelGGL(k_zsplat, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, N, cam, zkeys, winner);
     return launched("kbe_zsplat");
@@ -571,9 +572,9 @@ int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int
 int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee, int W, int H,
                    double focal, double baseline, const float* shift3, float* acc, kbe_stream_t stream)
 {
-    KBE_REQUIRE(points && zee && acc && (data || C == 0) && B > 0 && N >= 0 && C >= 0 && W > 0 && H > 0,
-                "kbe_accumulate: bad arguments");
+    KBE_REQUIRE(zee && acc && B > 0 && N >= 0 && C >= 0 && W > 0 && H > 0, "kbe_accumulate: bad arguments");
     if (N == 0) return KBE_OK;
+    KBE_REQUIRE(points && (data || C == 0), "kbe_accumulate: points/data is NULL");
     const Camera cam = make_camera(W, H, focal, baseline, shift3);
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, data, N, C, cam,
                        zee, acc);
@@ -617,7 +618,7 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
                      double baseline, const float* shift3, uint32_t* zkeys, float* zee, float* acc, uint8_t* frame_u8,
                      float* render_f32, float* existing_f32, kbe_stream_t stream)
 {
-    KBE_REQUIRE(points && image && depth && zkeys && zee && acc && frame_u8 && N >= 0 && W > 0 && H > 0,
+    KBE_REQUIRE(zkeys && zee && acc && frame_u8 && N >= 0 && W > 0 && H > 0 && (N == 0 || (points && image && depth)),
                 "kbe_render_frame: bad arguments");
     KBE_REQUIRE(image + 3 * (size_t) N == depth, "kbe_render_frame: v1 wants image[3,N] and depth[N] adjacent ([4,N] data)");
     static const FillDirs dirs = make_fill_dirs();
@@ -663,8 +664,9 @@ int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, in
 
 int kbe_shift_points(const float* points, int B, int N, const float* shift3, float* out, kbe_stream_t stream)
 {
-    KBE_REQUIRE(points && out && shift3 && B > 0 && N >= 0, "kbe_shift_points: bad arguments");
+    KBE_REQUIRE(shift3 && B > 0 && N >= 0, "kbe_shift_points: bad arguments");
     if (N == 0) return KBE_OK;
+    KBE_REQUIRE(points && out, "kbe_shift_points: points/out is NULL");
     const Camera cam = make_camera(1, 1, 1.0, 1.0, shift3);
     hipLaunchKernelGGL(k_shift_points, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, N, cam, out);
     return launched("kbe_shift_points");

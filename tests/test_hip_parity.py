@@ -275,6 +275,6 @@ def test_empty_and_single_point_clouds(K):
 
 def test_invalid_arguments_return_errors_not_crashes(K):
     import ctypes
-    assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, None, None, None) == -1
+    assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, ctypes.c_void_p(8), None, None) == -1
     assert b'kbe_zsplat' in K.lib.kbe_last_error()
     assert K.lib.kbe_spatial_filter(ctypes.c_void_p(8), 1, 4, 4, 7, ctypes.c_void_p(8), None) == -1
