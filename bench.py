@@ -48,20 +48,18 @@ def build_scene(size, device, inpaint):
     return oc
 
 
-def time_kernels(oc, cams, reps=30):
-    """Average duration of each frame kernel from HIP events on the launch stream: `reps`
-    back-to-back launches of the same kernel between two events (so each figure includes one
-    same-stream kernel boundary, ~1.5 us).  Returns {name: seconds}."""
+def time_kernels(oc, cams, reps=40, fill_rect=None):
+    """Average GPU time of the frame launches from HIP events on the launch stream (torch's
+    current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
+    launches between two events; the tile kernel is isolated by differencing
+    (boxes + tiles) - (boxes), so it still carries one same-stream launch boundary (~1.5 us)
+    -- rocprofv3's per-kernel average (profiles/) is the cross-check.  Returns {name: seconds}."""
     from ken_burns_effect_amd import _native
     K = _native.kernels()
-    W, H, N = oc['intWidth'], oc['intHeight'], oc['tensorInpaPoints'].shape[-1]
-    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H)
+    W, H = oc['intWidth'], oc['intHeight']
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, oc['dblFocal'])
     focal, shift3 = cams[len(cams) // 2]
     Bl = oc['dblBaseline']
-    pts = state['cloud7'][0:3].unsqueeze(0)
-    data = state['cloud7'][3:7].unsqueeze(0)
-    zkeys, _ = K.zsplat(pts, W, H, focal, Bl, shift3)
-    zee = K.degrid(zkeys=zkeys)
 
     def timed(fn):
         fn()
@@ -74,20 +72,25 @@ def time_kernels(oc, cams, reps=30):
         e1.synchronize()
         return e0.elapsed_time(e1) / reps * 1e-3
 
-    import ctypes
-    lib = K.lib
-    P = _native._ptr
-    st = _native._stream
-    sh = _native._shift(shift3)
-    acc = state['acc']
-    i32 = torch.int32
+    # Every timed variant ends with the fill launch because that launch also resets the scratch
+    # (z-buffer, bucket counters); with an empty fill rectangle it does no hole work.
+    empty = (1, 1, 0, 0)
     out = {}
-    out['zsplat'] = timed(lambda: lib.kbe_zsplat(P(pts), 1, N, W, H, ctypes.c_double(focal), ctypes.c_double(Bl), sh,
-                                                 P(zkeys, i32), None, st()))
-    out['degrid'] = timed(lambda: lib.kbe_degrid(P(zkeys, i32), None, 1, W, H, P(zee), st()))
-    out['accumulate'] = timed(lambda: lib.kbe_accumulate(P(pts), P(data), 1, N, 4, P(zee), W, H, ctypes.c_double(focal),
-                                                         ctypes.c_double(Bl), sh, P(acc), st()))
-    out['frame'] = timed(lambda: K.render_frame(state, shift3, focal, Bl))
+    out['project+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=5, fill_rect=empty))
+    out['project+tiles+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty))
+    out['frame'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=fill_rect))
+    out['tiles'] = out['project+tiles+reset'] - out['project+reset']
+    out['fill'] = out['frame'] - out['project+tiles+reset']
+    frame = K.render_frame(state, shift3, focal, Bl)
+    cw, ch = int(0.9 * W), int(0.9 * H)
+    out['crop_resize'] = timed(lambda: K.crop_resize_u8(frame, cw, ch))
+    # the generic stage-by-stage path (global atomics), for comparison
+    pts = oc['tensorInpaPoints']
+    data = torch.cat([oc['tensorInpaImage'], oc['tensorInpaDepth']], 1)
+    zkeys, _ = K.zsplat(pts, W, H, focal, Bl, shift3)
+    zee = K.degrid(zkeys=zkeys)
+    out['generic_zsplat'] = timed(lambda: K.zsplat(pts, W, H, focal, Bl, shift3))
+    out['generic_accumulate'] = timed(lambda: K.accumulate(pts, data, zee, focal, Bl, shift3))
     return out
 
 
@@ -175,13 +178,17 @@ def main():
     assert frames.shape == (args.steps, size, size, 3)
 
     if rank == 0:
-        kt = time_kernels(oc, cams)
+        kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]))
         HW = size * size
-        # algorithmic bytes of the scatter (render_pointcloud, C = 4) per frame: SURVEY.md 8d
+        # The scatter (render_pointcloud: z-splat + degrid + z-tested accumulate + normalise) is the two
+        # launches k_project + k_tiles; its algorithmic bytes per frame are SURVEY.md 8d's figure,
+        # 28 N (xyz + rgb + depth, once) + 20 HW (the normalised 4-channel render + weight that
+        # render_pointcloud returns): inputs once, outputs once, no scratch.  The dominant kernel is
+        # k_tiles; it is charged the WHOLE scatter's bytes over the scatter's time (project + tiles,
+        # which includes the ~3 us scratch reset riding in the fill launch) -- conservative.
         scatter_bytes = 28 * n_points + 20 * HW
-        acc_bytes = 28 * n_points + 4 * HW + 20 * HW      # accumulate kernel alone: points+data in, zee in, acc out
-        dom = 'accumulate'
-        achieved = acc_bytes / kt[dom] / 1e9
+        dom = 'tiles'
+        achieved = scatter_bytes / kt['project+tiles+reset'] / 1e9
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
             'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
@@ -190,10 +197,9 @@ def main():
             'config': {'workload': '%dx%d %s camera path, %d points, per frame: shift+zsplat+degrid+accumulate+fill+u8%s+D2H'
                                    % (size, size, 'dolly' if args.dolly else 'KBE', n_points, '' if crop is None else '+crop/resize'),
                        'frames_per_rank': args.steps, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': acc_bytes,
-                         'kernel_us': {k: v * 1e6 for k, v in kt.items()},
-                         'scatter_GBps': scatter_bytes / (kt['zsplat'] + kt['degrid'] + kt['accumulate']) / 1e9},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom + ' (+k_project)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': scatter_bytes,
+                         'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(oc, cams, crop)

@@ -112,18 +112,55 @@ KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B,
                           float* output, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * One output frame of process_kenburns' loop body (common.py:238-255), fused:
- *   process_shift -> render_pointcloud([image; depth]) -> fill_disocclusion -> uint8 HWC.
- * cloud: points [3,N], image [3,N], depth [N] (tensorInpaPoints / Image / Depth).
- * scratch: zkeys [H*W] must hold KBE_ZKEY_EMPTY everywhere on entry and is left so on exit
- *          (call kbe_zkeys_clear once); zee [H*W]; acc [5*H*W] (contents irrelevant).
- * outputs: frame_u8 [H,W,3]; render_f32 (optional, [4,H,W]: the filled float render, for
- *          parity checks); existing_f32 (optional, [H*W]).
+ * The frame loop of process_kenburns (common.py:222-260) on the RESIDENT point cloud.
+ *
+ * One output frame = process_shift -> render_pointcloud([image; depth]) -> fill_disocclusion
+ * -> uint8 HWC (common.py:238-255), as three launches and no floating-point atomics:
+ *   1. project: every point is shifted and projected ONCE; its dblError is min-splatted into
+ *      the z-buffer (one native global atomic umin on an order-preserving key) and a 16-byte
+ *      record {ox, oy, dblError, point index} is appended to the bucket of each 32x32 target
+ *      tile whose pixels it can colour (wave-aggregated appends);
+ *   2. tiles: one workgroup per target tile loads the tile's z-buffer (+1 px halo), degrids it
+ *      in LDS, threads the tile's records into per-pixel lists in LDS and lets every pixel
+ *      gather, z-test and accumulate its contributions in registers; normalise, hole mask and
+ *      uint8 conversion follow in the same thread; pixels leave with plain coalesced stores;
+ *   3. fill: one half-wave per hole pixel (16 directions x 2 ends in parallel); the same
+ *      launch resets the z-buffer and the bucket counters for the next frame.
+ * The cloud is used in place, in the reference's layout: points [3,N] (tensorInpaPoints),
+ * image [3,N] (tensorInpaImage), depth [N] (tensorInpaDepth).  Any point order is correct;
+ * spatially coherent order (e.g. raster) is faster.
+ *
+ * scratch: kbe_frame_scratch_bytes(W, H) bytes, initialised ONCE with kbe_frame_scratch_init;
+ *          every kbe_render_frame call leaves it ready for the next one.
+ *   frame_u8      [H,W,3]   out
+ *   render_f32    [4,H,W]   optional: the filled float render (parity checks)
+ *   existing_f32  [H*W]     optional: the accumulated weight (tensorExisting)
+ *   zee_f32       [H*W]     optional: the degridded z-buffer the accumulation tested against
+ *   zee_pre_f32   [H*W]     optional: the z-buffer before degrid (bit-exact contract)
  * ------------------------------------------------------------------------------------- */
+KBE_API size_t kbe_frame_scratch_bytes(int W, int H);
+KBE_API int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream);
+
 KBE_API int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
-                     double focal, double baseline, const float* shift3, uint32_t* zkeys, float* zee,
-                     float* acc, uint8_t* frame_u8, float* render_f32, float* existing_f32,
-                     kbe_stream_t stream);
+                             double focal, double baseline, const float* shift3, void* scratch,
+                             uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
+                             float* zee_pre_f32, kbe_stream_t stream);
+
+/* The same with (a) a subset of the three launches (measurement aid: bench.py times each launch
+ * by differencing; only KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL leaves the scratch
+ * clean -- never use a subset for real frames) and (b) `fill_rect`: HOST pointer to
+ * {x0, y0, x1, y1} (inclusive) or NULL.  Holes outside the rectangle keep their rendered value
+ * instead of being filled.  A hole is never the source of another pixel's fill (sources are valid
+ * pixels of the un-filled render, common.py:921-923), so when the caller is going to crop the
+ * frame (common.py:256-257) skipping the holes the crop discards changes nothing inside the
+ * crop window. */
+#define KBE_STAGE_PROJECT 1
+#define KBE_STAGE_TILES 2
+#define KBE_STAGE_FILL 4
+KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
+                                    int H, double focal, double baseline, const float* shift3, void* scratch,
+                                    uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
+                                    float* zee_pre_f32, int stages, const int* fill_rect, kbe_stream_t stream);
 
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
 KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);

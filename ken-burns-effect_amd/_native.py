@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_render_frame', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
@@ -46,6 +46,7 @@ def load():
             raise KbeError('libkbe_hip.so does not export %s (stale build?)' % name)
         getattr(lib, name).restype = ctypes.c_int
     lib.kbe_last_error.restype = ctypes.c_char_p
+    lib.kbe_frame_scratch_bytes.restype = ctypes.c_size_t
     if lib.kbe_abi_version() != ABI_VERSION:
         raise KbeError('libkbe_hip.so ABI %d != expected %d' % (lib.kbe_abi_version(), ABI_VERSION))
     _lib = lib
@@ -163,31 +164,35 @@ class HipKernels:
                     'kbe_fill_disocclusion')
         return out
 
-    # -- fused frame --------------------------------------------------------------------
-    def prepare_cloud(self, points, image, depth, W, H):
-        """Packs tensorInpaPoints/Image/Depth into one resident [7,N] buffer (points, rgb, depth)
-        and allocates the per-view scratch once; returns the state render_frame consumes."""
+    # -- the frame loop on the resident cloud ---------------------------------------------
+    def prepare_cloud(self, points, image, depth, W, H, focal=None):
+        """Makes tensorInpaPoints/Image/Depth resident for the frame loop: contiguous fp32 views (used in
+        place, no repacking) plus the per-view scratch (z-buffer, tile buckets, hole list), initialised
+        once.  Returns the state render_frame consumes."""
+        W, H = int(W), int(H)
         N = points.shape[-1]
-        cloud7 = torch.cat([_f32c(points).reshape(3, N), _f32c(image).reshape(3, N), _f32c(depth).reshape(1, N)], 0).contiguous()
-        dev = cloud7.device
-        state = {'cloud7': cloud7, 'N': N, 'W': int(W), 'H': int(H),
-                 'zkeys': torch.empty(H * W, dtype=torch.int32, device=dev),
-                 'zee': torch.empty(H * W, dtype=torch.float32, device=dev),
-                 'acc': torch.empty(5 * H * W, dtype=torch.float32, device=dev),
-                 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev)}
-        self.zkeys_clear(state['zkeys'])
+        dev = points.device
+        state = {'points': _f32c(points).reshape(3, N), 'image': _f32c(image).reshape(3, N), 'depth': _f32c(depth).reshape(N),
+                 'N': N, 'W': W, 'H': H, 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev)}
+        nbytes = int(self.lib.kbe_frame_scratch_bytes(_i(W), _i(H)))
+        state['scratch'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._check(self.lib.kbe_frame_scratch_init(_ptr(state['scratch'], torch.uint8), _i(W), _i(H), _stream()),
+                    'kbe_frame_scratch_init')
         return state
 
-    def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None):
-        """One frame of common.py:238-255 (shift -> render -> fill -> uint8) -> uint8 [H,W,3] on the device."""
-        N, W, H = state['N'], state['W'], state['H']
-        base = state['cloud7'].data_ptr()
-        self._check(self.lib.kbe_render_frame(ctypes.c_void_p(base), ctypes.c_void_p(base + 12 * N),
-                                              ctypes.c_void_p(base + 24 * N), _i(N), _i(W), _i(H), _d(float(focal)),
-                                              _d(float(baseline)), _shift(shift3), _ptr(state['zkeys'], torch.int32),
-                                              _ptr(state['zee']), _ptr(state['acc']), _ptr(state['frame'], torch.uint8),
-                                              _ptr(render_f32), _ptr(existing_f32), _stream()), 'kbe_render_frame')
-        return state['frame']
+    def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None, zee_f32=None,
+                     zee_pre_f32=None, out=None, stages=7, fill_rect=None):
+        """One frame of common.py:238-255 (shift -> render -> fill -> uint8) -> uint8 [H,W,3] on the device.
+        fill_rect = (x0, y0, x1, y1): only holes inside are filled (see include/kbe.h)."""
+        frame = state['frame'] if out is None else out
+        rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
+        self._check(self.lib.kbe_render_frame_stages(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']),
+                                                     _i(state['N']), _i(state['W']), _i(state['H']), _d(float(focal)),
+                                                     _d(float(baseline)), _shift(shift3), _ptr(state['scratch'], torch.uint8),
+                                                     _ptr(frame, torch.uint8), _ptr(render_f32), _ptr(existing_f32),
+                                                     _ptr(zee_f32), _ptr(zee_pre_f32), _i(int(stages)), rect, _stream()),
+                    'kbe_render_frame')
+        return frame
 
     def zkeys_clear(self, zkeys):
         self._check(self.lib.kbe_zkeys_clear(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _stream()), 'kbe_zkeys_clear')

@@ -264,6 +264,28 @@ def crop_size(objectSettings):
     return (max(oFrom['intCropWidth'], oTo['intCropWidth']), max(oFrom['intCropHeight'], oTo['intCropHeight']))
 
 
+def crop_window(W, H, crop_w, crop_h):
+    """Inclusive pixel rectangle the centred crop of common.py:256 reads (cv2.getRectSubPix samples
+    pixels floor(c) .. floor(c) + size, c = W/2 - (size-1)/2), padded by one pixel."""
+    x0 = int(math.floor(W / 2.0 - (crop_w - 1) * 0.5)) - 1
+    y0 = int(math.floor(H / 2.0 - (crop_h - 1) * 0.5)) - 1
+    return (max(x0, 0), max(y0, 0), min(x0 + crop_w + 2, W - 1), min(y0 + crop_h + 2, H - 1))
+
+
+def _prepared_cloud(K, objectCommon):
+    """The chunked resident form of tensorInpa* (built once per cloud, reused by every frame and
+    by repeated calls while the three tensors stay the same objects)."""
+    tensors = tuple(objectCommon[k] for k in ('tensorInpaPoints', 'tensorInpaImage', 'tensorInpaDepth'))
+    key = (K.name, objectCommon['intWidth'], objectCommon['intHeight']) + tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
+    cached = objectCommon.get('_kbePreparedCloud')
+    if cached is None or cached[0] != key:
+        state = K.prepare_cloud(tensors[0], tensors[1], tensors[2], objectCommon['intWidth'], objectCommon['intHeight'],
+                                objectCommon['dblFocal'])
+        cached = (key, state, tensors)        # keeps the tensors alive so that data_ptr stays a valid identity
+        objectCommon['_kbePreparedCloud'] = cached
+    return cached[1]
+
+
 def render_frames(cameras, objectCommon, crop=None, keep_on_device=False):
     """The frame loop proper (common.py:238-257) for a list of (focal, shift3) cameras.
 
@@ -274,15 +296,16 @@ def render_frames(cameras, objectCommon, crop=None, keep_on_device=False):
     ``keep_on_device``)."""
     K = _K()
     W, H = objectCommon['intWidth'], objectCommon['intHeight']
-    state = K.prepare_cloud(objectCommon['tensorInpaPoints'], objectCommon['tensorInpaImage'], objectCommon['tensorInpaDepth'], W, H)
+    state = _prepared_cloud(K, objectCommon)
     device = objectCommon['tensorInpaPoints'].device
     n = len(cameras)
     if keep_on_device or device.type != 'cuda':
         out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device)
     else:
         out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
+    rect = None if crop is None else crop_window(W, H, crop[0], crop[1])
     for i, (focal, shift3) in enumerate(cameras):
-        frame = K.render_frame(state, shift3, focal, objectCommon['dblBaseline'])
+        frame = K.render_frame(state, shift3, focal, objectCommon['dblBaseline'], fill_rect=rect)
         if crop is not None:
             frame = K.crop_resize_u8(frame, crop[0], crop[1])
         out[i].copy_(frame, non_blocking=True)

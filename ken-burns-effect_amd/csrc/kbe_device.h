@@ -59,18 +59,25 @@ struct Proj {
     float w[4];         // NW, NE, SW, SE bilinear weights
 };
 
-// common.py:447-484 (== :599-636).  Returns false when the point touches no pixel at all.
-__device__ __forceinline__ bool project(const Camera& cam, float px, float py, float pz, Proj& p)
+// The projection is split in three so that callers can reject a point before paying for the
+// fp64 division: (1) cull + image-plane position, (2) corner + weights, (3) dblError.
+
+// common.py:453-468.  Returns false when the point touches no pixel at all.
+__device__ __forceinline__ bool project_xy(const Camera& cam, float px, float py, float pz, float& ox, float& oy)
 {
     if (!((double) pz >= 0.001)) return false;                 // :453 (also covers :461)
     const float lvx = 0.0f - px, lvy = 0.0f - py, lvz = 0.0f - pz;
     const float dist = (cam.focal_f - pz) / lvz;               // :457-459
     const float ix = __builtin_fmaf(dist, lvx, px);            // :465 as NVRTC (--fmad=true) emits it
     const float iy = __builtin_fmaf(dist, lvy, py);
-    const float ox = (float) (((double) ix + cam.half_w) - 0.5);   // :467
-    const float oy = (float) (((double) iy + cam.half_h) - 0.5);   // :468
-    p.err = (float) (1000000.0 - (cam.fb / ((double) pz + 0.0000001)));   // :470
-    if (!(fabsf(ox) < 1.0e9f) || !(fabsf(oy) < 1.0e9f)) return false;    // see kbe.h "Inputs must be finite"
+    ox = (float) (((double) ix + cam.half_w) - 0.5);           // :467
+    oy = (float) (((double) iy + cam.half_h) - 0.5);           // :468
+    return (fabsf(ox) < 1.0e9f) && (fabsf(oy) < 1.0e9f);       // see kbe.h "Inputs must be finite"
+}
+
+// common.py:472-484
+__device__ __forceinline__ void project_weights(float ox, float oy, Proj& p)
+{
     const float fx = floorf(ox), fy = floorf(oy);
     p.nwx = (int) fx;
     p.nwy = (int) fy;
@@ -79,6 +86,21 @@ __device__ __forceinline__ bool project(const Camera& cam, float px, float py, f
     p.w[1] = (ox - fx) * (ey - oy);                             // :482 NE
     p.w[2] = (ex - ox) * (oy - fy);                             // :483 SW
     p.w[3] = (ox - fx) * (oy - fy);                             // :484 SE
+}
+
+// common.py:470: 1000000.0 - ((F * B) / (z + 0.0000001)), fp64 throughout, one final rounding
+__device__ __forceinline__ float project_err(const Camera& cam, float pz)
+{
+    return (float) (1000000.0 - (cam.fb / ((double) pz + 0.0000001)));
+}
+
+// common.py:447-484 (== :599-636) in one piece
+__device__ __forceinline__ bool project(const Camera& cam, float px, float py, float pz, Proj& p)
+{
+    float ox, oy;
+    if (!project_xy(cam, px, py, pz, ox, oy)) return false;
+    p.err = project_err(cam, pz);
+    project_weights(ox, oy, p);
     return true;
 }
 

@@ -1,0 +1,618 @@
+// kbe_frame.hip -- the per-frame hot path on the resident point cloud (include/kbe.h, "The frame
+// loop of process_kenburns"): project + z-splat + bucket -> tile gather -> hole fill.
+//
+// Design (MI355X).  The reference scatters every point into a global z-buffer (float CAS loop)
+// and then into 5 global accumulator planes, 20 float atomics per point (common.py:435-507,
+// :586-669).  Measured on gfx950: L2 float atomics retire ~0.2 T/s (95 us per 1024^2 frame for
+// the accumulation alone) and LDS float atomics cost ~49 cycles per wave-level ds_add_f32 (a
+// tiled LDS-accumulator version kept every CU's LDS pipe busy for ~90 us).  So the scatter is
+// turned into a gather:
+//   k_project  one thread per point: shift (common.py:104-109), project (:447-484), ONE native
+//              atomic umin on the order-preserving key of dblError into the z-buffer (:486-506),
+//              and a 16-byte record {ox, oy, dblError, index} appended to the bucket of every
+//              32x32 target tile one of its four corners lies in (appends are aggregated per
+//              wave: one counter atomic per distinct tile, records stored coalesced);
+//   k_tiles    one workgroup per tile: z-buffer tile + halo -> LDS, degrid (:525-568) in LDS,
+//              records -> per-pixel linked lists in LDS (bin = north-west corner; one
+//              ds_wrxchg per record), then every pixel walks the 4 bins that can reach it,
+//              z-tests (:639) and accumulates (:641) in registers, normalises (:686), applies
+//              the hole mask (:253), converts to uint8 (:255) and stores coalesced;
+//   k_fill     one half-wave per hole (:838-924); also resets z-buffer and bucket counters.
+// No accumulator or float render ever exists in HBM and no floating-point atomic is executed.
+//
+// Numerics are those of oracle/kbe_oracle.c: the z-buffer is bit-exact (min commutes), degrid
+// is the out-of-place schedule, accumulation order is bucket order (not point order).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "kbe.h"
+#include "kbe_device.h"
+#include "kbe_fill.h"
+#include "kbe_host.h"
+
+#pragma clang fp contract(off)
+
+using namespace kbe;
+
+namespace {
+
+#ifndef KBE_TILE_W
+#define KBE_TILE_W 32
+#endif
+#ifndef KBE_TILE_H
+#define KBE_TILE_H 32
+#endif
+#ifndef KBE_TILE_THREADS
+#define KBE_TILE_THREADS 512
+#endif
+#ifndef KBE_TILE_CAP
+#define KBE_TILE_CAP 1536
+#endif
+#ifndef KBE_BUCKET_FACTOR
+#define KBE_BUCKET_FACTOR 6
+#endif
+constexpr int TW = KBE_TILE_W, TH = KBE_TILE_H;     // target tile owned by one workgroup
+constexpr int KW = TW + 2, KH = TH + 2;             // tile + the 1-px halo whose z the degrid reads
+constexpr int BW = TW + 1, BH = TH + 1;             // bins: north-west corners x0-1 .. x0+TW-1, y0-1 .. y0+TH-1
+constexpr int TILE_THREADS = KBE_TILE_THREADS;
+constexpr int PIX_PER_THREAD = TW * TH / TILE_THREADS;
+constexpr int REC_CAP = KBE_TILE_CAP;               // records a tile holds in LDS at once (more: several rounds)
+constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's bucket holds in HBM (more: brute force)
+static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS, "tile geometry");
+static_assert(REC_CAP * 4 >= TW * TH * 3, "the uint8 staging area re-uses the record index array");
+
+struct Scratch {                            // carve-out of the caller's scratch allocation
+    uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
+    int* tile_count;        // [n_tiles]  records appended to each bucket; 0 between frames
+    int* hole_count;        // [1]
+    int* holes;             // [H*W]
+    float* depth;           // [H*W]  render[3] * (existing > 0): what the fill walks on
+    float4* buckets;        // [n_tiles][BUCKET_CAP]  {ox, oy, dblError, point index}
+    int tiles_x, tiles_y;
+};
+
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t) 15; }
+
+Scratch carve(void* base, int W, int H)
+{
+    char* p = (char*) base;
+    const size_t hw = (size_t) W * H;
+    Scratch s;
+    s.tiles_x = (W + TW - 1) / TW;
+    s.tiles_y = (H + TH - 1) / TH;
+    const size_t n_tiles = (size_t) s.tiles_x * s.tiles_y;
+    s.zkeys = (uint32_t*) p;      p += align16(4 * hw);
+    s.tile_count = (int*) p;      p += align16(4 * n_tiles);
+    s.hole_count = (int*) p;      p += 16;
+    s.holes = (int*) p;           p += align16(4 * hw);
+    s.depth = (float*) p;         p += align16(4 * hw);
+    s.buckets = (float4*) p;
+    return s;
+}
+
+size_t scratch_bytes(int W, int H)
+{
+    const size_t hw = (size_t) W * H;
+    const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    return align16(4 * hw) + align16(4 * n_tiles) + 16 + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_CAP * sizeof(float4);
+}
+
+__global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = gtid; i < hw; i += stride) zkeys[i] = KBE_ZKEY_EMPTY;
+    for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i] = 0;
+    if (gtid == 0) *hole_count = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// launch 1: project every point once
+// ---------------------------------------------------------------------------------------
+struct ProjectArgs {
+    const float* points;    // [3,N]
+    int N;
+    Camera cam;
+    uint32_t* zkeys;
+    int* tile_count;
+    float4* buckets;
+    int tiles_x, tiles_y;
+    int* hole_count;
+};
+
+// Groups the lanes of a wave by target tile: for a lane that `want`s, `same` is the mask of the
+// lanes wanting the same tile and `leader` its lowest lane.  Pure cross-lane work (ballots,
+// shuffles), no memory traffic; one loop trip per distinct tile (1-3 for coherent points).
+struct TileGroup { unsigned long long same; int leader; };
+
+__device__ __forceinline__ TileGroup group_by_tile(bool want, int tile)
+{
+    TileGroup g = { 0ull, 0 };
+    unsigned long long pending = __ballot(want);
+    while (pending) {                                           // wave-uniform
+        const int leader = __ffsll((long long) pending) - 1;
+        const int t = __shfl(tile, leader);
+        const unsigned long long same = __ballot(want && tile == t);
+        if (want && tile == t) { g.same = same; g.leader = leader; }
+        pending &= ~same;
+    }
+    return g;
+}
+
+constexpr int PTS_PER_THREAD = 4;           // independent points per lane: their atomics overlap in flight
+
+// One wave handles 256 consecutive points; lane l takes l, l+64, l+128, l+192 (coalesced loads).
+// The bucket appends are organised so that ALL counter atomics of a wave are in flight together
+// (a returning global atomic is a ~2 us round trip; issued one after the other they made this
+// launch 60 us long): first every (point, tile) pair is grouped, then the group leaders fire
+// their atomicAdd back to back, then the results are consumed.
+__global__ void __launch_bounds__(256) k_project(ProjectArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const Camera& cam = a.cam;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.hole_count = 0;
+    const size_t N = (size_t) a.N;
+    for (long w0 = (long) wave * 64 * PTS_PER_THREAD; w0 < (long) a.N; w0 += (long) n_waves * 64 * PTS_PER_THREAD) {
+        float4 rec[PTS_PER_THREAD];
+        bool ok[PTS_PER_THREAD], spx[PTS_PER_THREAD], spy[PTS_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PTS_PER_THREAD; j++) {
+            const long i = w0 + lane + 64 * j;
+            ok[j] = i < (long) a.N;
+            float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f, err = 0.0f;
+            if (ok[j]) {
+                x = a.points[i]; y = a.points[N + i]; z = a.points[2 * N + i];
+                apply_shift(cam, x, y, z);
+                ok[j] = project_xy(cam, x, y, z, ox, oy);
+            }
+            Proj p;
+            p.nwx = p.nwy = 0;
+            if (ok[j]) {
+                project_weights(ox, oy, p);
+                ok[j] = (p.nwx + 1 >= 0) & (p.nwx < cam.W) & (p.nwy + 1 >= 0) & (p.nwy < cam.H);   // touches the image at all
+            }
+            if (ok[j]) {
+                err = project_err(cam, z);
+                const int k = winner_corner(p);                 // common.py:486-506
+                if (k >= 0) {
+                    const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+                    if (inside(cx, cy, cam.W, cam.H)) atomicMin(&a.zkeys[(size_t) cy * cam.W + cx], zkey_encode(err));
+                }
+            }
+            rec[j] = make_float4(ox, oy, err, __int_as_float((int) i));
+            // buckets: the tile of the north-west corner, plus the neighbour the east / south corners
+            // spill into when that corner sits in a tile's last column / row (or at -1, just outside)
+            spx[j] = ok[j] && ((p.nwx + 1) % TW == 0);
+            spy[j] = ok[j] && ((p.nwy + 1) % TH == 0);
+        }
+        // corner c of the 2x2 tile neighbourhood: (c & 1) east, (c >> 1) south
+#pragma unroll
+        for (int half = 0; half < 2; half++) {                  // c = 0,1 (always), then c = 2,3 (only rows that spill south)
+            if (half == 1) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < PTS_PER_THREAD; j++) any |= spy[j];
+                if (__ballot(any) == 0) break;                  // wave-uniform
+            }
+            TileGroup grp[PTS_PER_THREAD][2];
+            int tgt[PTS_PER_THREAD][2], base[PTS_PER_THREAD][2];
+            bool want[PTS_PER_THREAD][2];
+#pragma unroll
+            for (int j = 0; j < PTS_PER_THREAD; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int c = half * 2 + e;
+                    const int nwx = (int) floorf(rec[j].x), nwy = (int) floorf(rec[j].y);      // >= -1 when ok
+                    const int tx0 = nwx >= 0 ? nwx / TW : -1, ty0 = nwy >= 0 ? nwy / TH : -1;
+                    const int tx = tx0 + (c & 1), ty = ty0 + (c >> 1);
+                    want[j][e] = ok[j] && ((c & 1) == 0 || spx[j]) && ((c >> 1) == 0 || spy[j]) && tx >= 0 && ty >= 0 &&
+                                 tx < a.tiles_x && ty < a.tiles_y;
+                    tgt[j][e] = ty * a.tiles_x + tx;
+                    grp[j][e] = group_by_tile(want[j][e], tgt[j][e]);
+                    base[j][e] = 0;
+                }
+            // all counter atomics of this wave, back to back
+#pragma unroll
+            for (int j = 0; j < PTS_PER_THREAD; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    if (want[j][e] && lane == grp[j][e].leader) base[j][e] = atomicAdd(&a.tile_count[tgt[j][e]], __popcll(grp[j][e].same));
+            // consume: every lane learns its slot from its group's leader and stores its record (coalesced within a group)
+#pragma unroll
+            for (int j = 0; j < PTS_PER_THREAD; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int b0 = __shfl(base[j][e], grp[j][e].leader);
+                    if (want[j][e]) {
+                        const int slot = b0 + __popcll(grp[j][e].same & ((1ull << lane) - 1ull));
+                        if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[j][e] * BUCKET_CAP + slot] = rec[j];   // beyond: the tile sees count > cap
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launch 2: the tile kernel
+// ---------------------------------------------------------------------------------------
+struct TileArgs {
+    const float* points;    // [3,N]  (only the brute-force path of an overflowing bucket reads it)
+    const float* image;     // [3,N]
+    const float* depth_in;  // [N]
+    int N;
+    Camera cam;
+    const uint32_t* zkeys;
+    const int* tile_count;
+    const float4* buckets;
+    int tiles_x, tiles_y;
+    uint8_t* frame;         // [H,W,3]
+    float* depth;           // [H*W]
+    int* holes;
+    int* hole_count;
+    float* render;          // optional [4,H,W] (unfilled; the fill kernel patches the holes)
+    float* existing;        // optional [H*W]
+    float* zee;             // optional [H*W] degridded z-buffer
+    float* zee_pre;         // optional [H*W] pre-degrid z-buffer
+};
+
+// blockIdx -> tile id such that each XCD (block b runs on XCD b % 8) owns a contiguous band of
+// tile rows: the records of neighbouring tiles reference neighbouring points (shared L2 lines).
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int xcd = b & 7, j = b >> 3, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+struct TileLds {
+    float4 rec[REC_CAP];        // ox, oy, dblError, next record (int bits)
+    int rec_id[REC_CAP];        // point index (its r, g, b, depth are fetched on demand); later the uint8 staging area
+    int head[BH * BW];          // first record of each bin, -1 = empty
+    float zpre[KH * KW];        // z-buffer before degrid, tile + halo
+    float zee[TH * TW];         // degridded z-buffer
+    int nrec;
+};
+
+// threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
+__device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float oy, float err, int id, int x0, int y0)
+{
+    const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
+    L.rec_id[idx] = id;
+    const int next = atomicExch(&L.head[by * BW + bx], idx);
+    L.rec[idx] = make_float4(ox, oy, err, __int_as_float(next));
+}
+
+// z-tested bilinear accumulation (common.py:586-669) of the records now in LDS, in registers
+__device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int tid, int x0, int y0,
+                                       float (&acc)[PIX_PER_THREAD][5])
+{
+    const size_t N = (size_t) a.N;
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++) {
+        const int q = tid + m * TILE_THREADS;
+        const int ly = q / TW, lx = q - ly * TW;
+        if (!inside(x0 + lx, y0 + ly, a.cam.W, a.cam.H)) continue;
+        const double zlim = (double) L.zee[q] + 1.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // corner k of a point is this pixel  <=>  its north-west corner is (lx - (k & 1), ly - (k >> 1))
+            int idx = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
+            while (idx >= 0) {
+                const float4 r = L.rec[idx];
+                if ((double) r.z <= zlim) {                                 // :639
+                    Proj pr;
+                    project_weights(r.x, r.y, pr);
+                    const float w = pr.w[k];
+                    const int id = L.rec_id[idx];
+                    const float* I = a.image + id;                          // L1/L2-hot: four pixels share each point
+                    acc[m][0] += I[0] * w;                                  // :641 product rounded, then added
+                    acc[m][1] += I[N] * w;
+                    acc[m][2] += I[2 * N] * w;
+                    acc[m][3] += a.depth_in[id] * w;
+                    acc[m][4] += w;                                         // the `ones` channel (:429)
+                }
+                idx = __float_as_int(r.w);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
+{
+    __shared__ TileLds L;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int W = a.cam.W, H = a.cam.H;
+
+    // z-buffer tile + halo (common.py:430 for pixels outside the image: never read)
+    for (int i = tid; i < KH * KW; i += TILE_THREADS) {
+        const int py = i / KW, pxl = i - py * KW;
+        const int x = x0 - 1 + pxl, y = y0 - 1 + py;
+        L.zpre[i] = inside(x, y, W, H) ? zkey_decode(a.zkeys[(size_t) y * W + x]) : 1000000.0f;
+    }
+    __syncthreads();
+    // degrid (common.py:525-568), out of place
+    for (int i = tid; i < TH * TW; i += TILE_THREADS) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        auto at = [&](int xx, int yy) { return L.zpre[(yy - y0 + 1) * KW + (xx - x0 + 1)]; };
+        const float zd = degrid_pixel(x, y, W, H, at);
+        L.zee[i] = zd;
+        if (a.zee) a.zee[(size_t) y * W + x] = zd;
+        if (a.zee_pre) a.zee_pre[(size_t) y * W + x] = at(x, y);
+    }
+
+    float acc[PIX_PER_THREAD][5];
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++)
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) acc[m][ch] = 0.0f;
+
+    const int count = a.tile_count[tile];
+    if (count <= BUCKET_CAP) {
+        // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
+        const float4* B = a.buckets + (size_t) tile * BUCKET_CAP;
+        for (int r0 = 0; r0 == 0 || r0 < count; r0 += REC_CAP) {
+            for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+            __syncthreads();
+            const int n = min(REC_CAP, count - r0);
+            for (int i = tid; i < n; i += TILE_THREADS) {
+                const float4 r = B[r0 + i];
+                lds_insert(L, i, r.x, r.y, r.z, __float_as_int(r.w), x0, y0);
+            }
+            __syncthreads();
+            gather(a, L, tid, x0, y0, acc);
+            __syncthreads();
+        }
+    } else {
+        // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
+        // records from the whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
+        const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
+        for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+        if (tid == 0) L.nrec = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n_round; i0 += TILE_THREADS) {
+            const int i = i0 + tid;
+            bool ok = i < a.N;
+            float ox = 0.0f, oy = 0.0f, z = 0.0f;
+            if (ok) {
+                float x = a.points[i], y = a.points[(size_t) a.N + i];
+                z = a.points[2 * (size_t) a.N + i];
+                apply_shift(a.cam, x, y, z);
+                ok = project_xy(a.cam, x, y, z, ox, oy);
+            }
+            if (ok) {
+                const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
+                ok = (bx >= 0) & (bx < BW) & (by >= 0) & (by < BH);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                int base = 0;
+                const int leader = __ffsll((long long) m) - 1;
+                if (lane == leader) base = atomicAdd(&L.nrec, __popcll(m));
+                base = __shfl(base, leader);
+                if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), i, x0, y0);
+            }
+            __syncthreads();
+            if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
+                gather(a, L, tid, x0, y0, acc);
+                __syncthreads();
+                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+                if (tid == 0) L.nrec = 0;
+                __syncthreads();
+            }
+        }
+    }
+
+    // resolve: normalise (common.py:686), hole mask (:253), uint8 (:255)
+    const size_t HW = (size_t) W * H;
+    uint8_t* s_u8 = (uint8_t*) L.rec_id;          // the records are dead now
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++) {
+        const int q = tid + m * TILE_THREADS;
+        const int ly = q / TW, lx = q - ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        const bool in = x < W && y < H;
+        const float w = acc[m][4];
+        const float den = w + 0.0000001f;
+        const float r = acc[m][0] / den, g = acc[m][1] / den, b = acc[m][2] / den, d = acc[m][3] / den;
+        const float dm = d * (w > 0.0f ? 1.0f : 0.0f);
+        s_u8[q * 3] = to_u8(r); s_u8[q * 3 + 1] = to_u8(g); s_u8[q * 3 + 2] = to_u8(b);
+#if defined(KBE_PROBE_NO_HOLES)
+        const bool hole = false;
+#else
+        const bool hole = in && !(dm > 0.0f);
+#endif
+        const unsigned long long hm = __ballot(hole);
+        if (hm) {
+            int base = 0;
+            const int leader = __ffsll((long long) hm) - 1;
+            if (lane == leader) base = atomicAdd(a.hole_count, __popcll(hm));
+            base = __shfl(base, leader);
+            if (hole) a.holes[base + __popcll(hm & ((1ull << lane) - 1ull))] = y * W + x;
+        }
+        if (in) {
+            const size_t o = (size_t) y * W + x;
+            a.depth[o] = dm;
+            if (a.render) { a.render[o] = r; a.render[HW + o] = g; a.render[2 * HW + o] = b; a.render[3 * HW + o] = d; }
+            if (a.existing) a.existing[o] = w;
+        }
+    }
+    __syncthreads();
+    // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
+    const bool fast = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
+    if (fast) {
+        constexpr int DW_PER_ROW = TW * 3 / 4;
+        for (int i = tid; i < TH * DW_PER_ROW; i += TILE_THREADS) {
+            const int ly = i / DW_PER_ROW, k = i - ly * DW_PER_ROW;
+            if (y0 + ly >= H) continue;
+            uint32_t* dst = (uint32_t*) (a.frame + ((size_t) (y0 + ly) * W + x0) * 3);
+            dst[k] = ((const uint32_t*) s_u8)[ly * DW_PER_ROW + k];
+        }
+    } else {
+        for (int i = tid; i < TH * TW * 3; i += TILE_THREADS) {
+            const int q = i / 3, ch = i - q * 3;
+            const int ly = q / TW, lx = q - ly * TW;
+            if (x0 + lx < W && y0 + ly < H) a.frame[((size_t) (y0 + ly) * W + x0 + lx) * 3 + ch] = s_u8[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// hole fill: one 32-lane group per hole; lane = direction * 2 + end (0: against, 1: along)
+// (common.py:838-924; the direction loop and both ray walks run in parallel, then the
+// "strictly shorter, first direction wins" reduction picks the same source pixel)
+// ---------------------------------------------------------------------------------------
+struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are filled
+
+__global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
+                                                    const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
+                                                    uint8_t* __restrict__ frame, float* __restrict__ render,
+                                                    uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles)
+{
+    // leave the scratch ready for the next frame: empty z-buffer, empty buckets
+    {
+        const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        for (int i = gtid; i < W * H; i += gsz) zkeys[i] = KBE_ZKEY_EMPTY;
+        for (int i = gtid; i < n_tiles; i += gsz) tile_count[i] = 0;
+    }
+    const int n = *hole_count;
+    const int lane = threadIdx.x & 31;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_groups = (gridDim.x * blockDim.x) >> 5;
+    const int d = lane >> 1, end = lane & 1;
+    const float ddx = end ? dirs.x[d] : -dirs.x[d], ddy = end ? dirs.y[d] : -dirs.y[d];
+    const size_t HW = (size_t) W * H;
+    for (int h = group; h < n; h += n_groups) {
+        const int px = holes[h];
+        const int y = px / W, x = px - y * W;
+        if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1) continue;
+        float fx = (float) x, fy = (float) y;
+        int ix = 0, iy = 0;
+        bool ok = false, done = false;
+        float dv = 0.0f;
+        // common.py:876-883 / :887-894.  The positions do not depend on the data, so the walk issues
+        // kBatch depth loads at a time and then inspects them in order (the dependent-load chain
+        // of the textbook loop is what makes hole filling latency-bound).
+        constexpr int kBatch = 8;
+        while (!done) {
+            int bx[kBatch], by[kBatch];
+            float bd[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                fx += ddx; bx[k] = (int) roundf(fx);
+                fy += ddy; by[k] = (int) roundf(fy);
+                const bool in = (bx[k] >= 0) & (bx[k] < W) & (by[k] >= 0) & (by[k] < H);
+                bd[k] = in ? depth[by[k] * W + bx[k]] : -1.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                if (done) continue;
+                ix = bx[k]; iy = by[k];
+                if ((ix < 0) | (ix >= W) | (iy < 0) | (iy >= H)) { done = true; continue; }
+                if (bd[k] > 0.0f) { dv = bd[k]; ok = true; done = true; }
+            }
+        }
+        // both ends of my direction
+        const int ox = __shfl_xor(ix, 1), oy = __shfl_xor(iy, 1);
+        const bool ook = (bool) __shfl_xor((int) ok, 1);
+        const float odv = __shfl_xor(dv, 1);
+        float dist = INFINITY;
+        if (ok && ook) {
+            const float ex = (float) (ix - ox), ey = (float) (iy - oy);
+            const float t = sqrtf(ex * ex + ey * ey);           // :898
+            if (1000000.0f > t) dist = t;                       // :854 + :900 against the initial dblShortest
+        }
+        float best = dist;
+#pragma unroll
+        for (int off = 2; off < 32; off <<= 1) best = fminf(best, __shfl_xor(best, off));
+        if (best == INFINITY) continue;                         // unfillable: keeps the rendered value (:913-919)
+        const unsigned long long m = __ballot(dist == best);
+        const unsigned mine = (unsigned) (m >> (threadIdx.x & 32));     // my 32-lane half
+        const int win = __ffs((int) mine) - 1;                  // lowest lane = lowest direction, its `from` end
+        if (lane == win) {
+            // lane `win` is the `from` end (even lane); partner values are the `to` end
+            int sxp = ix, syp = iy;
+            if (dv < odv) { sxp = ox; syp = oy; }               // :904 the farther (background) end
+            const size_t s = (size_t) syp * W + sxp, o = (size_t) px;
+            frame[o * 3] = frame[s * 3]; frame[o * 3 + 1] = frame[s * 3 + 1]; frame[o * 3 + 2] = frame[s * 3 + 2];
+            if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + s];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kbe_frame_scratch_bytes(int W, int H)
+{
+    return (W <= 0 || H <= 0) ? 0 : scratch_bytes(W, H);
+}
+
+int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
+{
+    KBE_REQUIRE(scratch && W > 0 && H > 0 && ((uintptr_t) scratch & 15) == 0, "kbe_frame_scratch_init: bad arguments");
+    const Scratch sc = carve(scratch, W, H);
+    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, (hipStream_t) stream, sc.zkeys, (size_t) W * H, sc.tile_count,
+                       sc.tiles_x * sc.tiles_y, sc.hole_count);
+    return launched("kbe_frame_scratch_init");
+}
+
+int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
+                            double baseline, const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
+                            float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect,
+                            kbe_stream_t stream)
+{
+    KBE_REQUIRE(scratch && frame_u8 && N >= 0 && W > 0 && H > 0 && (size_t) W * H < (1u << 31) && ((uintptr_t) scratch & 15) == 0,
+                "kbe_render_frame: bad arguments");
+    KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame: cloud pointers are NULL");
+    static const FillDirs dirs = make_fill_dirs();
+    const hipStream_t s = (hipStream_t) stream;
+    const Scratch sc = carve(scratch, W, H);
+    const Camera cam = make_camera(W, H, focal, baseline, shift3);
+    const int n_tiles = sc.tiles_x * sc.tiles_y;
+    int rc = KBE_OK;
+
+    if (stages & KBE_STAGE_PROJECT) {
+        ProjectArgs p;
+        p.points = points; p.N = N; p.cam = cam; p.zkeys = sc.zkeys; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
+        p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
+        const unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) : 1;
+        hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, p);
+        if ((rc = launched("kbe_render_frame/project"))) return rc;
+    }
+    if (stages & KBE_STAGE_TILES) {
+        TileArgs a;
+        a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
+        a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+        a.frame = frame_u8; a.depth = sc.depth; a.holes = sc.holes; a.hole_count = sc.hole_count;
+        a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
+        hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
+        if ((rc = launched("kbe_render_frame/tiles"))) return rc;
+    }
+    if (stages & KBE_STAGE_FILL) {
+        const size_t hw = (size_t) W * H;
+        const unsigned fill_blocks = (unsigned) (hw / 64 < 2048 ? (hw / 64 > 0 ? hw / 64 : 1) : 2048);
+        FillRect rect = { 0, 0, W - 1, H - 1 };
+        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, W, H, dirs, rect,
+                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles);
+        rc = launched("kbe_render_frame/fill");
+    }
+    return rc;
+}
+
+int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
+                     double baseline, const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
+                     float* existing_f32, float* zee_f32, float* zee_pre_f32, kbe_stream_t stream)
+{
+    return kbe_render_frame_stages(points, image, depth, N, W, H, focal, baseline, shift3, scratch, frame_u8, render_f32,
+                                   existing_f32, zee_f32, zee_pre_f32, KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL,
+                                   nullptr, stream);
+}
+
+}  // extern "C"

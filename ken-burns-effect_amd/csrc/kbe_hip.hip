@@ -9,49 +9,16 @@
 
 #include "kbe.h"
 #include "kbe_device.h"
+#include "kbe_fill.h"
+#include "kbe_host.h"
 
 #pragma clang fp contract(off)
 
 using namespace kbe;
 
+thread_local char kbe::g_err[256] = "";
+
 namespace {
-
-thread_local char g_err[256] = "";
-
-int fail(int code, const char* what, hipError_t e = hipSuccess)
-{
-    snprintf(g_err, sizeof(g_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
-    return code;
-}
-
-int launched(const char* what)
-{
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? KBE_OK : fail(KBE_E_LAUNCH, what, e);
-}
-
-Camera make_camera(int W, int H, double focal, double baseline, const float* shift3)
-{
-    Camera c;
-    c.focal_f = (float) focal;
-    c.fb = focal * baseline;
-    c.half_w = 0.5 * (double) W;
-    c.half_h = 0.5 * (double) H;
-    c.W = W;
-    c.H = H;
-    c.has_shift = shift3 != nullptr;
-    c.sx = shift3 ? shift3[0] : 0.0f;
-    c.sy = shift3 ? shift3[1] : 0.0f;
-    c.sz = shift3 ? shift3[2] : 0.0f;
-    return c;
-}
-
-constexpr int kBlock = 256;
-
-inline unsigned blocks_for(size_t n, int per_block = kBlock)
-{
-    return (unsigned) ((n + per_block - 1) / per_block);
-}
 
 // ---------------------------------------------------------------------------------------
 // elementwise helpers
@@ -177,65 +144,6 @@ __global__ void __launch_bounds__(kBlock) k_normalize(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // kernel_discfill_updateOutput (common.py:838-924)
 // ---------------------------------------------------------------------------------------
-struct FillDirs { float x[16], y[16]; };
-
-FillDirs make_fill_dirs()
-{
-    // common.py:859-867: the direction table, normalised in fp32 on the host with the same
-    // IEEE operations (sqrtf, divide) the kernel text performs per thread
-    const float dx[16] = { -1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3 };
-    const float dy[16] = { 1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2 };
-    FillDirs d;
-    for (int i = 0; i < 16; i++) {
-        volatile float n = sqrtf((dx[i] * dx[i]) + (dy[i] * dy[i]));
-        d.x[i] = dx[i] / n;
-        d.y[i] = dy[i] / n;
-    }
-    return d;
-}
-
-// Finds the fill source of hole pixel (x, y): returns the linear index of the pixel to copy
-// from, or -1 when every direction leaves the image on one side (common.py:913-919).
-template <class DepthAt>
-__device__ __forceinline__ int fill_source(const FillDirs& dirs, int x, int y, int W, int H, DepthAt depth_at)
-{
-    float shortest = 1000000.0f;
-    int fx = -1, fy = -1;
-    for (int d = 0; d < 16; d++) {
-        const float ddx = dirs.x[d], ddy = dirs.y[d];
-        float ax = (float) x, ay = (float) y;
-        int iax, iay;
-        float da = 0.0f;
-        for (;;) {                                              // :876-883
-            ax -= ddx; iax = (int) roundf(ax);
-            ay -= ddy; iay = (int) roundf(ay);
-            if ((iax < 0) | (iax >= W) | (iay < 0) | (iay >= H)) break;
-            da = depth_at(iax, iay);
-            if (da > 0.0f) break;
-        }
-        if ((iax < 0) | (iax >= W) | (iay < 0) | (iay >= H)) continue;      // :884-885
-        float bx = (float) x, by = (float) y;
-        int ibx, iby;
-        float db = 0.0f;
-        for (;;) {                                              // :887-894
-            bx += ddx; ibx = (int) roundf(bx);
-            by += ddy; iby = (int) roundf(by);
-            if ((ibx < 0) | (ibx >= W) | (iby < 0) | (iby >= H)) break;
-            db = depth_at(ibx, iby);
-            if (db > 0.0f) break;
-        }
-        if ((ibx < 0) | (ibx >= W) | (iby < 0) | (iby >= H)) continue;      // :895-896
-        const float ex = (float) (ibx - iax), ey = (float) (iby - iay);
-        const float dist = sqrtf(ex * ex + ey * ey);            // :898 (exact small integers)
-        if (shortest > dist) {                                  // :900
-            fx = iax; fy = iay;
-            if (da < db) { fx = ibx; fy = iby; }                // :904 the farther (background) end
-            shortest = dist;
-        }
-    }
-    return (fx < 0 || fy < 0) ? -1 : fy * W + fx;
-}
-
 __global__ void __launch_bounds__(kBlock) k_fill(const float* __restrict__ input, const float* __restrict__ depth,
                                                  int C, int W, int H, FillDirs dirs, float* __restrict__ output)
 {
@@ -253,50 +161,6 @@ __global__ void __launch_bounds__(kBlock) k_fill(const float* __restrict__ input
         if (s >= 0) src = s;
     }
     for (int ch = 0; ch < C; ch++) Out[(size_t) ch * HW + i] = In[(size_t) ch * HW + src];    // :834 clone + :921-923
-}
-
-// ---------------------------------------------------------------------------------------
-// fused frame tail: normalise (common.py:686) + hole mask (:253) + fill (:838-924) + uint8
-// (:255) straight from the accumulators.  depth used by the fill = render[3] * (w > 0),
-// which equals render[3] because render[3] is +0 wherever w == 0.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float norm_at(const float* __restrict__ acc, int HW, int ch, int px)
-{
-    return acc[(size_t) ch * HW + px] / (acc[(size_t) 4 * HW + px] + 0.0000001f);
-}
-
-__global__ void __launch_bounds__(kBlock) k_resolve_frame(const float* __restrict__ acc, int W, int H, FillDirs dirs,
-                                                          uint8_t* __restrict__ frame, float* __restrict__ render,
-                                                          float* __restrict__ existing, uint32_t* __restrict__ zkeys)
-{
-    const int HW = W * H;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HW) return;
-    zkeys[i] = KBE_ZKEY_EMPTY;                                  // leave the z-buffer clean for the next frame
-    const float w = acc[(size_t) 4 * HW + i];
-    float depth = norm_at(acc, HW, 3, i);
-    depth = depth * (w > 0.0f ? 1.0f : 0.0f);                   // :253
-    int src = i;
-    if (!(depth > 0.0f)) {
-        const int y = i / W, x = i - y * W;
-        const int s = fill_source(dirs, x, y, W, H, [&](int xx, int yy) {
-            const int q = yy * W + xx;
-            const float wq = acc[(size_t) 4 * HW + q];
-            return norm_at(acc, HW, 3, q) * (wq > 0.0f ? 1.0f : 0.0f);
-        });
-        if (s >= 0) src = s;
-    }
-    const float r = norm_at(acc, HW, 0, src), g = norm_at(acc, HW, 1, src), bl = norm_at(acc, HW, 2, src);
-    frame[(size_t) i * 3 + 0] = to_u8(r);
-    frame[(size_t) i * 3 + 1] = to_u8(g);
-    frame[(size_t) i * 3 + 2] = to_u8(bl);
-    if (render) {
-        render[i] = r;
-        render[(size_t) HW + i] = g;
-        render[(size_t) 2 * HW + i] = bl;
-        render[(size_t) 3 * HW + i] = norm_at(acc, HW, 3, src);
-    }
-    if (existing) existing[i] = w;
 }
 
 __global__ void __launch_bounds__(kBlock) k_frame_u8(const float* __restrict__ render, int HW, uint8_t* __restrict__ frame)
@@ -514,7 +378,6 @@ __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restri
 // =======================================================================================
 // extern "C" entry points (include/kbe.h)
 // =======================================================================================
-#define KBE_REQUIRE(cond, what) do { if (!(cond)) return fail(KBE_E_INVALID, what); } while (0)
 
 extern "C" {
 
@@ -612,26 +475,6 @@ int kbe_fill_disocclusion(const float* input, const float* depth, int B, int C, 
     hipLaunchKernelGGL(k_fill, dim3(blocks_for((size_t) W * H), B), dim3(kBlock), 0, (hipStream_t) stream, input, depth, C,
                        W, H, dirs, output);
     return launched("kbe_fill_disocclusion");
-}
-
-int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
-                     double baseline, const float* shift3, uint32_t* zkeys, float* zee, float* acc, uint8_t* frame_u8,
-                     float* render_f32, float* existing_f32, kbe_stream_t stream)
-{
-    KBE_REQUIRE(zkeys && zee && acc && frame_u8 && N >= 0 && W > 0 && H > 0 && (N == 0 || (points && image && depth)),
-                "kbe_render_frame: bad arguments");
-    KBE_REQUIRE(image + 3 * (size_t) N == depth, "kbe_render_frame: v1 wants image[3,N] and depth[N] adjacent ([4,N] data)");
-    static const FillDirs dirs = make_fill_dirs();
-    const hipStream_t s = (hipStream_t) stream;
-    int rc;
-    const hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (size_t) 5 * H * W, s);
-    if (e != hipSuccess) return fail(KBE_E_LAUNCH, "hipMemsetAsync(acc)", e);
-    if ((rc = kbe_zsplat(points, 1, N, W, H, focal, baseline, shift3, zkeys, nullptr, stream))) return rc;
-    if ((rc = kbe_degrid(zkeys, nullptr, 1, W, H, zee, stream))) return rc;
-    if ((rc = kbe_accumulate(points, image, 1, N, 4, zee, W, H, focal, baseline, shift3, acc, stream))) return rc;
-    hipLaunchKernelGGL(k_resolve_frame, dim3(blocks_for((size_t) W * H)), dim3(kBlock), 0, s, acc, W, H, dirs, frame_u8,
-                       render_f32, existing_f32, zkeys);
-    return launched("kbe_render_frame");
 }
 
 int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream)

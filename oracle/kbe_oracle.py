@@ -244,11 +244,11 @@ class OracleKernels:
     def frame_u8(self, render):
         return torch.from_numpy(frame_u8(render[0]))
 
-    def prepare_cloud(self, points, image, depth, W, H):
+    def prepare_cloud(self, points, image, depth, W, H, focal=None):
         return {'points': _f32(points).reshape(1, 3, -1), 'image': _f32(image).reshape(1, 3, -1),
                 'depth': _f32(depth).reshape(1, 1, -1), 'W': int(W), 'H': int(H)}
 
-    def render_frame(self, state, shift3, focal, baseline, want_float=False):
+    def render_frame(self, state, shift3, focal, baseline, want_float=False, fill_rect=None):
         """shift -> render(4 ch) -> fill -> uint8, the per-frame body of common.py:238-255."""
         pts = shift_points(state['points'], torch.tensor(shift3, dtype=torch.float32))
         data = torch.cat([state['image'], state['depth']], 1)
