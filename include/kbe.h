@@ -201,10 +201,13 @@ KBE_API int kbe_laplacian_valid(const float* in, const float* scale_dev, int pla
    multi_channel=True):  msum = box-sum of mask over Cin*k*k (zero pad);
    um = clamp(msum, 0, 1); ratio = Cin*k*k / (msum + 1e-8) * um;
    out = ((raw - bias) * ratio + bias) * um   (bias NULL: out = raw * ratio).
-   raw/out [B,Cout,Ho,Wo] (may alias), mask [B,Cin,H,W], um [B,1,Ho,Wo]. */
-KBE_API int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H,
-                       int W, int Cout, int Ho, int Wo, int k, int stride, int pad, float* out,
-                       float* um, kbe_stream_t stream);
+   raw/out [B,Cout,Ho,Wo] (may alias); mask [B,mask_channels,H,W] with mask_channels = Cin, or 1
+   when every input channel carries the same mask (msum = Cin * single-channel box sum), or
+   NULL = no mask given (all ones, :49-56); um [B,1,Ho,Wo] optional (the reference materialises
+   Cout identical copies). */
+KBE_API int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int mask_channels, int B,
+                               int Cin, int H, int W, int Cout, int Ho, int Wo, int k, int stride, int pad,
+                               float* out, float* um, kbe_stream_t stream);
 
 #ifdef __cplusplus
 }

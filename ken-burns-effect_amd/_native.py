@@ -249,13 +249,19 @@ class HipKernels:
                                                  _stream()), 'kbe_laplacian_valid')
         return out
 
-    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding):
-        raw, mask = _f32c(raw), _f32c(mask)
+    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None):
+        """raw [B,Cout,Ho,Wo] = conv(x * mask); mask [B,Cin|1,H,W] or None (then in_channels/in_size say what x was)."""
+        raw = _f32c(raw)
         B, Cout, Ho, Wo = raw.shape
-        _, Cin, H, W = mask.shape
+        if mask is not None:
+            mask = _f32c(mask)
+            _, Cm, H, W = mask.shape
+            Cin = Cm if in_channels is None else int(in_channels)
+        else:
+            Cm, Cin, (H, W) = 1, int(in_channels), in_size
         out = torch.empty_like(raw)
         um = torch.empty(B, 1, Ho, Wo, dtype=torch.float32, device=raw.device)
-        self._check(self.lib.kbe_pconv_epilogue(_ptr(raw), _ptr(None if bias is None else _f32c(bias)), _ptr(mask), _i(B),
+        self._check(self.lib.kbe_pconv_epilogue(_ptr(raw), _ptr(None if bias is None else _f32c(bias)), _ptr(mask), _i(Cm), _i(B),
                                                 _i(Cin), _i(H), _i(W), _i(Cout), _i(Ho), _i(Wo), _i(int(kernel_size)),
                                                 _i(int(stride)), _i(int(padding)), _ptr(out), _ptr(um), _stream()),
                     'kbe_pconv_epilogue')

@@ -59,12 +59,14 @@ constexpr int TILE_THREADS = KBE_TILE_THREADS;
 constexpr int PIX_PER_THREAD = TW * TH / TILE_THREADS;
 constexpr int REC_CAP = KBE_TILE_CAP;               // records a tile holds in LDS at once (more: several rounds)
 constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's bucket holds in HBM (more: brute force)
+constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
+                                                    // the counter atomics of neighbouring tiles do not serialise in L2
 static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS, "tile geometry");
 static_assert(REC_CAP * 4 >= TW * TH * 3, "the uint8 staging area re-uses the record index array");
 
 struct Scratch {                            // carve-out of the caller's scratch allocation
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
-    int* tile_count;        // [n_tiles]  records appended to each bucket; 0 between frames
+    int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
     int* hole_count;        // [1]
     int* holes;             // [H*W]
     float* depth;           // [H*W]  render[3] * (existing > 0): what the fill walks on
@@ -83,7 +85,7 @@ Scratch carve(void* base, int W, int H)
     s.tiles_y = (H + TH - 1) / TH;
     const size_t n_tiles = (size_t) s.tiles_x * s.tiles_y;
     s.zkeys = (uint32_t*) p;      p += align16(4 * hw);
-    s.tile_count = (int*) p;      p += align16(4 * n_tiles);
+    s.tile_count = (int*) p;      p += align16(4 * n_tiles * CNT_STRIDE);
     s.hole_count = (int*) p;      p += 16;
     s.holes = (int*) p;           p += align16(4 * hw);
     s.depth = (float*) p;         p += align16(4 * hw);
@@ -95,14 +97,14 @@ size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return align16(4 * hw) + align16(4 * n_tiles) + 16 + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_CAP * sizeof(float4);
+    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_CAP * sizeof(float4);
 }
 
 __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
 {
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += stride) zkeys[i] = KBE_ZKEY_EMPTY;
-    for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i] = 0;
+    for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
     if (gtid == 0) *hole_count = 0;
 }
 
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
             for (int j = 0; j < PTS_PER_THREAD; j++)
 #pragma unroll
                 for (int e = 0; e < 2; e++)
-                    if (want[j][e] && lane == grp[j][e].leader) base[j][e] = atomicAdd(&a.tile_count[tgt[j][e]], __popcll(grp[j][e].same));
+                    if (want[j][e] && lane == grp[j][e].leader) base[j][e] = atomicAdd(&a.tile_count[tgt[j][e] * CNT_STRIDE], __popcll(grp[j][e].same));
             // consume: every lane learns its slot from its group's leader and stores its record (coalesced within a group)
 #pragma unroll
             for (int j = 0; j < PTS_PER_THREAD; j++)
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
 #pragma unroll
         for (int ch = 0; ch < 5; ch++) acc[m][ch] = 0.0f;
 
-    const int count = a.tile_count[tile];
+    const int count = a.tile_count[tile * CNT_STRIDE];
     if (count <= BUCKET_CAP) {
         // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
         const float4* B = a.buckets + (size_t) tile * BUCKET_CAP;
@@ -478,7 +480,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     {
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int i = gtid; i < W * H; i += gsz) zkeys[i] = KBE_ZKEY_EMPTY;
-        for (int i = gtid; i < n_tiles; i += gsz) tile_count[i] = 0;
+        for (int i = gtid; i < n_tiles; i += gsz) tile_count[i * CNT_STRIDE] = 0;
     }
     const int n = *hole_count;
     const int lane = threadIdx.x & 31;

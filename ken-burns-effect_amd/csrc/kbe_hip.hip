@@ -334,9 +334,11 @@ __global__ void __launch_bounds__(kBlock) k_median(const float* __restrict__ in,
     out[(size_t) p * HW + i] = med;
 }
 
-// PartialConv2d bookkeeping (utils/partial_conv.py:62-77)
+// PartialConv2d bookkeeping (utils/partial_conv.py:62-77).  mask has Cm channels: Cin (as the
+// reference materialises it), 1 (every input channel carries the same mask: the sum over channels
+// is Cin times the single-channel box sum, exact for 0/1 masks), or is NULL (no mask given: all ones).
 __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restrict__ raw, const float* __restrict__ bias,
-                                                           const float* __restrict__ mask, int Cin, int H, int W, int Cout,
+                                                           const float* __restrict__ mask, int Cm, int Cin, int H, int W, int Cout,
                                                            int Ho, int Wo, int k, int stride, int pad,
                                                            float* __restrict__ out, float* __restrict__ um_out)
 {
@@ -345,22 +347,24 @@ __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restri
     if (i >= Ho * Wo) return;
     const int oy = i / Wo, ox = i - oy * Wo;
     float msum = 0.0f;
-    for (int ci = 0; ci < Cin; ci++) {
-        const float* M = mask + ((size_t) b * Cin + ci) * H * W;
+    const int planes = mask ? Cm : 1;
+    for (int ci = 0; ci < planes; ci++) {
+        const float* M = mask ? mask + ((size_t) b * Cm + ci) * H * W : nullptr;
         for (int ky = 0; ky < k; ky++) {
             const int iy = oy * stride - pad + ky;
             if (iy < 0 || iy >= H) continue;
             for (int kx = 0; kx < k; kx++) {
                 const int ix = ox * stride - pad + kx;
                 if (ix < 0 || ix >= W) continue;
-                msum += M[(size_t) iy * W + ix];
+                msum += M ? M[(size_t) iy * W + ix] : 1.0f;
             }
         }
     }
+    if (planes != Cin) msum = (float) Cin * msum;
     float ratio = (float) (Cin * k * k) / (msum + 1e-8f);
     const float um = msum < 0.0f ? 0.0f : (msum > 1.0f ? 1.0f : msum);
     ratio = ratio * um;
-    um_out[(size_t) b * Ho * Wo + i] = um;
+    if (um_out) um_out[(size_t) b * Ho * Wo + i] = um;
     for (int co = 0; co < Cout; co++) {
         const size_t o = ((size_t) b * Cout + co) * Ho * Wo + i;
         const float r = raw[o];
@@ -543,14 +547,14 @@ int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int
     return launched("kbe_laplacian_valid");
 }
 
-int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin, int H, int W, int Cout,
-                       int Ho, int Wo, int k, int stride, int pad, float* out, float* um, kbe_stream_t stream)
+int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int mask_channels, int B, int Cin, int H, int W,
+                       int Cout, int Ho, int Wo, int k, int stride, int pad, float* out, float* um, kbe_stream_t stream)
 {
-    KBE_REQUIRE(raw && mask && out && um && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k > 0 &&
-                    stride > 0 && pad >= 0,
+    KBE_REQUIRE(raw && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k > 0 && stride > 0 && pad >= 0,
                 "kbe_pconv_epilogue: bad arguments");
+    KBE_REQUIRE(!mask || mask_channels == 1 || mask_channels == Cin, "kbe_pconv_epilogue: mask must have 1 or Cin channels");
     hipLaunchKernelGGL(k_pconv_epilogue, dim3(blocks_for((size_t) Ho * Wo), B), dim3(kBlock), 0, (hipStream_t) stream, raw,
-                       bias, mask, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um);
+                       bias, mask, mask_channels, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um);
     return launched("kbe_pconv_epilogue");
 }
 

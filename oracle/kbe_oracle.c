@@ -413,26 +413,29 @@ KBO_API void kbo_frame_u8(const float* render, int W, int H, uint8_t* frame_hwc)
    channel because weight_maskUpdater is all ones (:33); then
      ratio = winsize / (msum + 1e-8); um = clamp(msum, 0, 1); ratio *= um
      out   = ((raw - bias) * ratio + bias) * um
-   raw/out: [B,Cout,Ho,Wo]; mask: [B,Cin,H,W]; um: [B,1,Ho,Wo] (the reference materialises
-   Cout identical copies). */
-KBO_API void kbo_pconv_epilogue(const float* raw, const float* bias, const float* mask, int B, int Cin,
+   raw/out: [B,Cout,Ho,Wo]; mask: [B,Cm,H,W] with Cm = Cin, or 1 (same mask on every input
+   channel: msum = Cin * box sum), or NULL (no mask: ones, :49-56); um: [B,1,Ho,Wo] (the
+   reference materialises Cout identical copies). */
+KBO_API void kbo_pconv_epilogue(const float* raw, const float* bias, const float* mask, int Cm, int B, int Cin,
                                 int H, int W, int Cout, int Ho, int Wo, int k, int stride, int pad,
                                 float* out, float* um_out)
 {
     const float winsize = (float) (Cin * k * k);
+    const int planes = mask ? Cm : 1;
     for (int b = 0; b < B; b++)
         for (int oy = 0; oy < Ho; oy++) for (int ox = 0; ox < Wo; ox++) {
             float msum = 0.0f;
-            for (int ci = 0; ci < Cin; ci++)
+            for (int ci = 0; ci < planes; ci++)
                 for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) {
                     const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
                     if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                    msum += mask[(((size_t) b * Cin + ci) * H + iy) * W + ix];
+                    msum += mask ? mask[(((size_t) b * Cm + ci) * H + iy) * W + ix] : 1.0f;
                 }
+            if (planes != Cin) msum = (float) Cin * msum;
             float ratio = winsize / (msum + 1e-8f);
             const float um = msum < 0.0f ? 0.0f : (msum > 1.0f ? 1.0f : msum);
             ratio = ratio * um;
-            um_out[((size_t) b * Ho + oy) * Wo + ox] = um;
+            if (um_out) um_out[((size_t) b * Ho + oy) * Wo + ox] = um;
             for (int co = 0; co < Cout; co++) {
                 const size_t o = (((size_t) b * Cout + co) * Ho + oy) * Wo + ox;
                 const float bv = bias ? bias[co] : 0.0f;

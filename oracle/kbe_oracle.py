@@ -199,13 +199,18 @@ def crop_resize_u8(frame, crop_w, crop_h):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
-def pconv_epilogue(raw, bias, mask, kernel_size, stride, padding):
-    raw, mask = _f32(raw), _f32(mask)
+def pconv_epilogue(raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None):
+    raw = _f32(raw)
     B, Cout, Ho, Wo = raw.shape
-    _, Cin, H, W = mask.shape
+    if mask is not None:
+        mask = _f32(mask)
+        _, Cm, H, W = mask.shape
+        Cin = Cm if in_channels is None else int(in_channels)
+    else:
+        Cm, Cin, (H, W) = 1, int(in_channels), in_size
     out = torch.empty_like(raw)
     um = torch.empty(B, 1, Ho, Wo)
-    lib().kbo_pconv_epilogue(_p(raw), _p(None if bias is None else _f32(bias)), _p(mask), _i(B), _i(Cin), _i(H), _i(W),
+    lib().kbo_pconv_epilogue(_p(raw), _p(None if bias is None else _f32(bias)), _p(mask), _i(Cm), _i(B), _i(Cin), _i(H), _i(W),
                              _i(Cout), _i(Ho), _i(Wo), _i(kernel_size), _i(stride), _i(padding), _p(out), _p(um))
     return out, um
 
@@ -260,5 +265,5 @@ class OracleKernels:
     def crop_resize_u8(self, frame, crop_w, crop_h):
         return torch.from_numpy(crop_resize_u8(frame.numpy(), crop_w, crop_h))
 
-    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding):
-        return pconv_epilogue(raw, bias, mask, kernel_size, stride, padding)
+    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None):
+        return pconv_epilogue(raw, bias, mask, kernel_size, stride, padding, in_channels, in_size)

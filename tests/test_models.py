@@ -1,0 +1,132 @@
+"""The inpainting network against the reference (golden vectors from the reference's own modules with
+identical, name-seeded weights).  CPU only: convolutions are stock torch; the point-cloud side of
+pointcloud_inpainting runs through the oracle kernel set injected for the test."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bits_equal, load_golden
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope='module')
+def net():
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    torch.set_num_threads(1)
+    return synthetic.seeded_fill_(Inpaint().eval(), 3)
+
+
+def test_state_dict_layout_matches_reference_checkpoints(net):
+    z = load_golden('inpaint')
+    assert sorted(net.state_dict().keys()) == [str(s) for s in z['state_names']]
+    assert len(net.state_dict()) == int(z['n_state']) == 171
+    assert sum(p.numel() for p in net.parameters()) == int(z['n_params']) == 8285640
+
+
+def test_forward_on_feature_data(net):
+    z = load_golden('inpaint')
+    with torch.no_grad():
+        net.normalize_images_disp(_t(z['image']), _t(z['disparity']), not_normed=True)
+        out = net(tensorData=_t(z['fw_data']), tensorMasks=_t(z['fw_mask']))
+    assert_bits_equal(out['tensorExisting'].numpy(), z['fw_mask'], 'tensorExisting is the input mask')
+    # same torch ops in the same order; tolerance covers conv algorithm selection on another host
+    assert np.abs(out['tensorImage'].numpy() - z['fw_image']).max() < 2e-5
+    assert np.abs(out['tensorDisparity'].numpy() - z['fw_disparity']).max() < 2e-4 * max(1.0, np.abs(z['fw_disparity']).max())
+    assert out['tensorImage'].min() >= 0 and out['tensorImage'].max() <= 1 and out['tensorDisparity'].min() >= 0
+
+
+def test_forward_from_image_and_disparity(net):
+    z = load_golden('inpaint')
+    image, disp = _t(z['image']), _t(z['disparity'])
+    with torch.no_grad():
+        out = net(tensorMasks=_t(z['fw_mask']), tensorImage=image, tensorDisparity=disp)
+    assert np.abs(out['tensorImage'].numpy() - z['fi_image']).max() < 2e-5
+    assert np.abs(out['tensorDisparity'].numpy() - z['fi_disparity']).max() < 2e-4 * max(1.0, np.abs(z['fi_disparity']).max())
+    assert_bits_equal(image.numpy(), z['image'], 'inputs are not modified')
+
+
+def test_pointcloud_inpainting_matches_reference(net, oracle, monkeypatch):
+    from ken_burns_effect_amd import common as C
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+    z = load_golden('inpaint')
+    image, disp = _t(z['image']), _t(z['disparity'])
+    H, W = image.shape[2:]
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H}
+    with torch.no_grad():
+        out = net.pointcloud_inpainting(image, disp, _t(z['pi_shift']), oc)
+    # the hole mask is index work: exact
+    assert_bits_equal(out['tensorExisting'].numpy(), z['pi_existing'], 'existing mask after median-5 dilation')
+    assert np.abs(out['tensorImage'].numpy() - z['pi_image']).max() < 5e-5
+    assert np.abs(out['tensorDisparity'].numpy() - z['pi_disparity']).max() < 5e-4 * max(1.0, np.abs(z['pi_disparity']).max())
+
+
+def test_train_mode_does_not_clamp(net):
+    z = load_golden('inpaint')
+    net.train()
+    try:
+        with torch.no_grad():
+            net.normalize_images_disp(_t(z['image']), _t(z['disparity']), not_normed=True)
+            out = net(tensorData=_t(z['fw_data']), tensorMasks=_t(z['fw_mask']))
+        assert out['tensorImage'].min() < 0 or out['tensorImage'].max() > 1
+    finally:
+        net.eval()
+
+
+# ---------------------------------------------------------------------------------------
+# partial convolution (utils/partial_conv.py) and the partial-conv GridNet
+# ---------------------------------------------------------------------------------------
+
+@pytest.fixture()
+def oracle_kernels(oracle, monkeypatch):
+    from ken_burns_effect_amd import common as C
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+
+
+def test_partial_conv_matches_reference(oracle_kernels):
+    from ken_burns_effect_amd.partial_conv import PartialConv2d
+    z = load_golden('partial_conv')
+    for tag in 'abc':
+        cin, cout, k, s, p = [int(v) for v in z['cfg_' + tag]]
+        conv = PartialConv2d(cin, cout, kernel_size=k, stride=s, padding=p, bias=True, multi_channel=True, return_mask=True)
+        with torch.no_grad():
+            conv.weight.copy_(_t(z['w_' + tag]))
+            conv.bias.copy_(_t(z['b_' + tag]))
+            out, um = conv(_t(z['x_' + tag]), _t(z['m_' + tag]))
+        assert_bits_equal(um.contiguous().numpy(), z['mask_' + tag], 'update_mask')
+        assert np.abs(out.numpy() - z['out_' + tag]).max() <= 1e-5 * max(1.0, np.abs(z['out_' + tag]).max())
+        assert conv.slide_winsize == cin * k * k and tuple(conv.weight_maskUpdater.shape) == (cout, cin, k, k)
+
+
+def test_partial_conv_single_channel_mask_is_equivalent(oracle_kernels):
+    from ken_burns_effect_amd.partial_conv import PartialConv2d
+    torch.manual_seed(0)
+    with pytest.raises(NotImplementedError):
+        PartialConv2d(2, 2, kernel_size=3, padding=1, multi_channel=True)(torch.zeros(1, 2, 4, 4))     # grad mode: refuse
+    conv = PartialConv2d(6, 5, kernel_size=3, stride=1, padding=1, multi_channel=True, return_mask=True)
+    x = torch.randn(1, 6, 9, 11)
+    m1 = (torch.rand(1, 1, 9, 11) > 0.4).float()
+    with torch.no_grad():
+        a, ma = conv(x, m1.expand(-1, 6, -1, -1).contiguous())
+        b, mb = conv(x, m1)
+    assert torch.equal(a, b) and torch.equal(ma, mb)
+
+
+def test_partial_inpaint_matches_reference(oracle_kernels):
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.partial_inpainting import Inpaint
+    z = load_golden('partial_inpaint')
+    net = synthetic.seeded_fill_(Inpaint().eval(), 5)
+    assert sorted(net.state_dict().keys()) == [str(s) for s in z['state_names']]
+    assert sum(p.numel() for p in net.parameters()) == int(z['n_params']) == 8285320
+    image, disp = synthetic.make_rgbd(32, 40, 43, 'smooth')
+    with torch.no_grad():
+        net.normalize_images_disp(image, disp, not_normed=True)
+        out = net(tensorData=_t(z['fw_data']), tensorMasks=_t(z['fw_mask']))
+    assert list(out['tensorMaskOut'].shape) == [int(v) for v in z['fw_existing_shape']]     # the reference's 32-ch 'tensorExisting'
+    assert out['tensorExisting'].shape[1] == 1                                                # ours: what process_inpaint needs
+    assert np.abs(out['tensorImage'].numpy() - z['fw_image']).max() < 5e-5
+    assert np.abs(out['tensorDisparity'].numpy() - z['fw_disparity']).max() < 5e-4 * max(1.0, np.abs(z['fw_disparity']).max())
