@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')     # the (untimed) Inpaint set-up: no exhaustive conv search
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -33,8 +35,11 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def build_scene(size, device, inpaint):
-    """objectCommon for a seeded synthetic size x size RGBD image."""
+def build_scene(size, device, inpaint, settings=None):
+    """objectCommon for a seeded synthetic size x size RGBD image.  With `inpaint` the point
+    cloud is grown exactly as process_kenburns' set-up loop does (common.py:181-219): two end poses, each
+    inpainted by the Inpaint network (seeded random weights: checkpoints are a network download) and the
+    pixels that pose cannot see appended as new points."""
     from ken_burns_effect_amd import _native, common, synthetic
     K = _native.kernels()
     image, disp = synthetic.make_rgbd(size, size, seed=0)
@@ -45,6 +50,13 @@ def build_scene(size, device, inpaint):
           'tensorRawDisparity': disp.to(device), 'tensorRawDepth': depth.to(device)}
     oc['tensorRawPoints'] = K.depth_to_points(oc['tensorRawDepth'], synthetic.FOCAL).view(1, 3, -1)
     common._reset_inpa(oc)
+    if inpaint:
+        from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+        net = synthetic.seeded_fill_(Inpaint(), 3).to(device).eval()
+        with torch.no_grad():
+            common.build_pointcloud(settings, oc, net)
+        del net
+        torch.cuda.empty_cache()
     return oc
 
 
@@ -124,6 +136,10 @@ def main():
     ap.add_argument('--dolly', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-crop', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='copies on the compute stream (dev comparison)')
+    ap.add_argument('--batch', type=int, default=16, help='frames per device->host transfer')
+    ap.add_argument('--cloud', choices=['inpaint', 'raw'], default='inpaint',
+                    help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -148,15 +164,16 @@ def main():
     crop = None if args.no_crop else common.crop_size(settings)
 
     # rank 0 owns the scene; other ranks receive the cloud through the broadcast below
-    oc = build_scene(size, device, inpaint=False) if rank == 0 else {}
+    oc = build_scene(size, device, args.cloud == 'inpaint' and not args.dolly, settings) if rank == 0 else {}
     if world_size > 1:
         sharding.broadcast_cloud(oc, device)          # untimed warm-up of the communicator + fills `oc` everywhere
     n_points = oc['tensorInpaPoints'].shape[-1]
     _, my_steps = sharding.shard_steps(settings['dblSteps'], rank, world_size)
     cams = common.frame_cameras(dict(settings, dblSteps=my_steps), oc)
 
-    # warm-up (untimed)
-    common.render_frames(cams[:max(args.warmup, 1)], oc, crop)
+    # warm-up (untimed); the pinned landing buffer of the timed run is allocated here, not in the loop
+    host_out = torch.empty(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
+    common.render_frames(cams[:max(args.warmup, 1)], oc, crop, host_out=host_out[:max(args.warmup, 1)], batch=args.batch)
 
     def sync():
         torch.cuda.synchronize()
@@ -168,7 +185,7 @@ def main():
     t0 = time.perf_counter()
     if world_size > 1:
         sharding.broadcast_cloud(oc, device)          # the one exchange step of a video, inside the timed region
-    frames = common.render_frames(cams, oc, crop)       # K frames -> pinned host memory, one sync at the end
+    frames = common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=args.batch)   # K frames -> pinned host memory, one sync at the end
     sync()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
@@ -194,8 +211,8 @@ def main():
             'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%dx%d %s camera path, %d points, per frame: shift+zsplat+degrid+accumulate+fill+u8%s+D2H'
-                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, '' if crop is None else '+crop/resize'),
+            'config': {'workload': '%dx%d %s camera path, %d points (%s cloud), per frame: shift+zsplat+degrid+accumulate+fill+u8%s+D2H'
+                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, args.cloud, '' if crop is None else '+crop/resize'),
                        'frames_per_rank': args.steps, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom + ' (+k_project)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': scatter_bytes,

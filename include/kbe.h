@@ -162,6 +162,22 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
                                     float* zee_pre_f32, int stages, const int* fill_rect, kbe_stream_t stream);
 
+/* The whole frame loop of process_kenburns (common.py:222-260) for `n_frames` cameras, enqueued
+ * from native code (no per-frame host-language work): per frame kbe_render_frame_stages, then the
+ * device-side crop + resize of common.py:256-257 when crop_w/crop_h > 0 (holes the crop discards are
+ * not filled), then an asynchronous copy of the finished uint8 frame into host_out[i] (pinned host
+ * memory, [n_frames,H,W,3]).  focals [n_frames] and shifts [n_frames][3] are HOST arrays (shift as
+ * the fp32 values process_shift produces).  Frames are staged on the device in two halves of
+ * `batch` frames and leave in one transfer per half; stage: DEVICE buffer of (2*batch + 1)*H*W*3
+ * bytes.  If copy_stream differs from stream the transfers run there and overlap the rendering of
+ * the other half (the call creates and destroys four HIP events for that; cross-stream waits are
+ * per batch because they are expensive); synchronising `stream` afterwards guarantees every
+ * frame has landed. */
+KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
+                             double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
+                             int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
+                             kbe_stream_t stream, kbe_stream_t copy_stream);
+
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
 KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);
 

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_video', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
@@ -193,6 +193,30 @@ class HipKernels:
                                                      _ptr(zee_f32), _ptr(zee_pre_f32), _i(int(stages)), rect, _stream()),
                     'kbe_render_frame')
         return frame
+
+    def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=16):
+        """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
+        tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised)."""
+        n, W, H = len(cameras), state['W'], state['H']
+        dev = state['points'].device
+        if host_out is None:
+            host_out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
+        batch = max(1, int(batch))
+        if state.get('stage_batch') != batch:
+            state['stage'] = torch.empty((2 * batch + 1) * H * W * 3, dtype=torch.uint8, device=dev)
+            state['stage_batch'] = batch
+        if 'copy_stream' not in state:
+            state['copy_stream'] = torch.cuda.Stream(device=dev)
+        focals = (ctypes.c_double * max(n, 1))(*[float(c[0]) for c in cameras])
+        shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
+        cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
+        copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
+        state['copy_stream'].wait_stream(torch.cuda.current_stream())
+        self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
+                                              _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
+                                              _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
+                                              ctypes.c_void_p(host_out.data_ptr()), _stream(), copy_stream), 'kbe_render_video')
+        return host_out
 
     def zkeys_clear(self, zkeys):
         self._check(self.lib.kbe_zkeys_clear(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _stream()), 'kbe_zkeys_clear')

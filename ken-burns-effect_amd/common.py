@@ -286,31 +286,32 @@ def _prepared_cloud(K, objectCommon):
     return cached[1]
 
 
-def render_frames(cameras, objectCommon, crop=None, keep_on_device=False):
+def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_out=None, overlap=True, batch=16):
     """The frame loop proper (common.py:238-257) for a list of (focal, shift3) cameras.
 
     One fused kernel sequence per frame on the resident packed cloud; frames land in one
     pinned host buffer and the host synchronises once.  ``crop`` = (w, h) applies the
     device-side equivalent of cv2.getRectSubPix + cv2.resize (common.py:256-257); None
     returns the un-cropped frames.  Returns uint8 [n,H,W,3] (numpy, or a device tensor when
-    ``keep_on_device``)."""
+    ``keep_on_device``).  ``host_out``: optional pre-allocated pinned uint8 [n,H,W,3] tensor to land the
+    frames in (otherwise a fresh one is allocated per call)."""
     K = _K()
     W, H = objectCommon['intWidth'], objectCommon['intHeight']
     state = _prepared_cloud(K, objectCommon)
     device = objectCommon['tensorInpaPoints'].device
     n = len(cameras)
-    if keep_on_device or device.type != 'cuda':
-        out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device)
-    else:
-        out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
+    if hasattr(K, 'render_video') and not keep_on_device:
+        # the native loop: kernels + async copies enqueued from C, copies overlapped on a second stream
+        out = K.render_video(state, cameras, objectCommon['dblBaseline'], crop, host_out=host_out, overlap=overlap, batch=batch)
+        torch.cuda.current_stream().synchronize()
+        return out.numpy()
+    out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device)
     rect = None if crop is None else crop_window(W, H, crop[0], crop[1])
     for i, (focal, shift3) in enumerate(cameras):
         frame = K.render_frame(state, shift3, focal, objectCommon['dblBaseline'], fill_rect=rect)
         if crop is not None:
             frame = K.crop_resize_u8(frame, crop[0], crop[1])
-        out[i].copy_(frame, non_blocking=True)
-    if device.type == 'cuda':
-        torch.cuda.current_stream().synchronize()
+        out[i].copy_(frame)
     return out if keep_on_device else out.numpy()
 
 

@@ -617,4 +617,66 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
                                    nullptr, stream);
 }
 
+int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
+                     int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
+                     uint8_t* stage, int batch, uint8_t* host_out, kbe_stream_t stream, kbe_stream_t copy_stream)
+{
+    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 1, "kbe_render_video: bad arguments");
+    KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
+    const hipStream_t cs = (hipStream_t) stream, ds = (hipStream_t) (copy_stream ? copy_stream : stream);
+    const bool overlap = ds != cs;
+    const size_t fb = (size_t) W * H * 3;
+    const bool crop = crop_w > 0;
+    // stage = [raw frame][ring half 0: batch frames][ring half 1: batch frames].  A half is copied to the host
+    // with ONE transfer while the other half is being rendered; cross-stream events are per batch, not per
+    // frame (a cross-stream wait costs far more host time than a launch on this stack).
+    uint8_t* raw = stage;
+    uint8_t* ring[2] = { stage + fb, stage + fb + (size_t) batch * fb };
+    hipEvent_t rendered[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
+    if (overlap) {
+        for (int b = 0; b < 2; b++) {
+            if (hipEventCreateWithFlags(&rendered[b], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&copied[b], hipEventDisableTiming) != hipSuccess)
+                return fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate");
+        }
+    }
+    int rect[4] = { 0, 0, W - 1, H - 1 };
+    if (crop) {
+        // the pixels cv2.getRectSubPix reads (common.py:256), padded by one: see kbe_render_frame_stages
+        const int x0 = (int) floor(W / 2.0 - (crop_w - 1) * 0.5) - 1, y0 = (int) floor(H / 2.0 - (crop_h - 1) * 0.5) - 1;
+        rect[0] = x0 > 0 ? x0 : 0; rect[1] = y0 > 0 ? y0 : 0;
+        rect[2] = x0 + crop_w + 2 < W - 1 ? x0 + crop_w + 2 : W - 1;
+        rect[3] = y0 + crop_h + 2 < H - 1 ? y0 + crop_h + 2 : H - 1;
+    }
+    int rc = KBE_OK;
+    int n_batches = 0;
+    for (int i0 = 0; i0 < n_frames && rc == KBE_OK; i0 += batch, n_batches++) {
+        const int half = n_batches & 1;
+        const int nb = n_frames - i0 < batch ? n_frames - i0 : batch;
+        if (overlap && n_batches >= 2 && hipStreamWaitEvent(cs, copied[half], 0) != hipSuccess) { rc = fail(KBE_E_LAUNCH, "hipStreamWaitEvent"); break; }
+        for (int k = 0; k < nb && rc == KBE_OK; k++) {
+            const int i = i0 + k;
+            uint8_t* out = ring[half] + (size_t) k * fb;
+            rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
+                                         crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, stream);
+            if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
+        }
+        if (rc != KBE_OK) break;
+        if (overlap) {
+            (void) hipEventRecord(rendered[half], cs);
+            (void) hipStreamWaitEvent(ds, rendered[half], 0);
+        }
+        const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, ring[half], (size_t) nb * fb, hipMemcpyDeviceToHost, ds);
+        if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
+        if (overlap) (void) hipEventRecord(copied[half], ds);
+    }
+    if (overlap) {
+        // whoever synchronises `stream` also sees every frame in host memory
+        for (int b = 0; b < 2 && b < n_batches; b++) (void) hipStreamWaitEvent(cs, copied[(n_batches - 1 - b) & 1], 0);
+        for (int b = 0; b < 2; b++) { (void) hipEventDestroy(rendered[b]); (void) hipEventDestroy(copied[b]); }
+    }
+    return rc;
+}
+
 }  // extern "C"

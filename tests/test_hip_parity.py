@@ -278,6 +278,22 @@ def test_cropped_frames_ignore_holes_outside_the_crop(K, oracle):
         assert d.max() <= 1 and (d > 0).mean() < 2e-3
 
 
+def test_native_frame_loop_equals_per_frame_calls(K):
+    """kbe_render_video (frames + crop + overlapped copies enqueued from C) against one call per frame."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene((160, 224), 8)
+    settings = dict(settings, dblSteps=[i / 6.0 for i in range(7)])
+    cams = common.frame_cameras(settings, oc)
+    crop = common.crop_size(settings)
+    a = common.render_frames(cams, oc, crop)                               # native loop, pinned host memory
+    b = common.render_frames(cams, oc, crop, keep_on_device=True).cpu().numpy()      # python loop
+    assert a.shape == b.shape == (7, 160, 224, 3)
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    c2 = common.render_frames(cams, oc, None)
+    assert c2.shape == (7, 160, 224, 3)
+
+
 def test_render_frame_is_repeatable_and_order_independent(K):
     """Chunk order / layout only affects speed: a shuffled cloud renders the same frame."""
     settings, oc = _scene((256, 320), 4)
