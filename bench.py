@@ -60,6 +60,22 @@ def build_scene(size, device, inpaint, settings=None):
     return oc
 
 
+def measured_traffic():
+    """HBM bytes per launch of the scatter kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, calibrated and corrected by tools/pmc_report.py as MI355X_MICROARCH.md
+    prescribes).  PMC counters cannot be collected from inside this process, so the figure is read from
+    profiles/; None when the file is missing."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))['kernels']
+        return k['k_project']['hbm_bytes'] + k['k_tiles']['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def time_kernels(oc, cams, reps=40, fill_rect=None):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
@@ -206,6 +222,7 @@ def main():
         scatter_bytes = 28 * n_points + 20 * HW
         dom = 'tiles'
         achieved = scatter_bytes / kt['project+tiles+reset'] / 1e9
+        traffic, traffic_src = measured_traffic()
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
             'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
@@ -215,7 +232,8 @@ def main():
                                    % (size, size, 'dolly' if args.dolly else 'KBE', n_points, args.cloud, '' if crop is None else '+crop/resize'),
                        'frames_per_rank': args.steps, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom + ' (+k_project)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': scatter_bytes,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes': scatter_bytes,
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
         if world_size == 1 and not args.no_cpu_baseline:

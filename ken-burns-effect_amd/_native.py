@@ -201,7 +201,7 @@ class HipKernels:
         dev = state['points'].device
         if host_out is None:
             host_out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
-        batch = max(1, int(batch))
+        batch = max(0, int(batch))      # 0 = zero-copy (kernels store straight into the pinned host buffer)
         if state.get('stage_batch') != batch:
             state['stage'] = torch.empty((2 * batch + 1) * H * W * 3, dtype=torch.uint8, device=dev)
             state['stage_batch'] = batch

@@ -621,7 +621,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, kbe_stream_t stream, kbe_stream_t copy_stream)
 {
-    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 1, "kbe_render_video: bad arguments");
+    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 0, "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
     const hipStream_t cs = (hipStream_t) stream, ds = (hipStream_t) (copy_stream ? copy_stream : stream);
     const bool overlap = ds != cs;
@@ -650,6 +650,19 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     }
     int rc = KBE_OK;
     int n_batches = 0;
+    if (batch == 0) {
+        // zero-copy: the last kernel of every frame stores straight into the (device-visible) pinned host
+        // buffer; no transfer engine, no second stream, no events
+        for (int i = 0; i < n_frames && rc == KBE_OK; i++) {
+            uint8_t* out = host_out + (size_t) i * fb;
+            rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
+                                         crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, stream);
+            if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
+        }
+        if (overlap) for (int b = 0; b < 2; b++) { (void) hipEventDestroy(rendered[b]); (void) hipEventDestroy(copied[b]); }
+        return rc;
+    }
     for (int i0 = 0; i0 < n_frames && rc == KBE_OK; i0 += batch, n_batches++) {
         const int half = n_batches & 1;
         const int nb = n_frames - i0 < batch ? n_frames - i0 : batch;
