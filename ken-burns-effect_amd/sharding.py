@@ -59,7 +59,7 @@ def broadcast_cloud(objectCommon, device, src=0):
     dist.broadcast(packed, src)
     if rank != src:
         objectCommon['dblFocal'] = h[1]
-        objectCommon['dblBaseline'] = int(h[2]) if h[12] == 1.0 else h[2]
+        objectCommon['dblBaseline'] = int(h[2]) if h[11] == 1.0 else h[2]
         objectCommon['intWidth'], objectCommon['intHeight'] = int(h[3]), int(h[4])
         objectCommon['objectDepthrange'] = (h[5], h[6], (int(h[7]), int(h[8])), (int(h[9]), int(h[10])))
         objectCommon['tensorInpaPoints'] = packed[0:3].unsqueeze(0)

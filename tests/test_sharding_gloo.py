@@ -1,0 +1,91 @@
+"""Frame sharding over ranks (world_size 2, gloo, CPU): one broadcast of the cloud, round-robin frames,
+gather -- the union must equal the single-process frame list byte for byte.  Kernel set = the oracle
+(injected explicitly in every rank; the product path itself is HIP-only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _scene():
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import synthetic
+    from oracle import kbe_oracle
+    H, W = 40, 56
+    image, disp = synthetic.make_rgbd(H, W, 61)
+    depth = (512.0 * 120) / (disp + 1e-7)
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H, 'objectDepthrange': synthetic.depthrange_of(depth),
+          'tensorRawImage': image, 'tensorRawDisparity': disp, 'tensorRawDepth': depth,
+          'tensorRawPoints': kbe_oracle.depth_to_points(depth, 512.0).view(1, 3, -1)}
+    ofrom, oto = synthetic.default_windows(H, W, False)
+    settings = {'dblSteps': [i / 6.0 for i in range(7)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': False, 'dolly': False}
+    return settings, oc
+
+
+def _worker(rank, world_size, port, out_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from ken_burns_effect_amd import common, sharding
+        from oracle import kbe_oracle
+        common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+        settings, oc = _scene()
+        if rank != 0:
+            oc = {}                    # only rank 0 owns the scene; the others learn it from the broadcast
+        else:
+            common._reset_inpa(oc)
+        frames = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'))
+        idx, _ = sharding.shard_steps(settings['dblSteps'], rank, world_size)
+        assert oc['tensorInpaPoints'].shape == (1, 3, 40 * 56) and oc['intWidth'] == 56 and isinstance(oc['dblBaseline'], int)
+        if rank == 0:
+            np.save(out_path, np.stack(frames))
+        else:
+            assert frames is None and len(idx) == 3
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_render_the_same_video_as_one(tmp_path):
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import common
+    from oracle import kbe_oracle
+    out = str(tmp_path / 'frames.npy')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    sharded = np.load(out)
+    common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+    try:
+        settings, oc = _scene()
+        common._reset_inpa(oc)
+        single = np.stack(common.process_kenburns(settings, oc, None))
+    finally:
+        common._kernel_set = None
+    assert sharded.shape == single.shape == (7, 40, 56, 3)
+    assert np.array_equal(sharded, single)
+
+
+def test_shard_steps_partition():
+    from ken_burns_effect_amd import sharding
+    steps = list(range(10))
+    seen = []
+    for r in range(4):
+        idx, mine = sharding.shard_steps(steps, r, 4)
+        assert mine == [steps[i] for i in idx]
+        seen += idx
+    assert sorted(seen) == steps
+    assert sharding.shard_steps(steps, 0, 1)[0] == steps
