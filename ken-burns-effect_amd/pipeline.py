@@ -1,0 +1,112 @@
+"""Image -> disparity -> point cloud -> Ken Burns frames.
+
+Drop-in for ``/root/reference/utils/pipeline.py`` (``Pipeline`` :23-134): same constructor and
+``__call__`` arguments.  The front half (:61-100: resize, Semantics + Disparity, Refine, disparity
+normalisation, depth, unprojection, ``objectCommon``) runs as stock PyTorch-ROCm modules plus the
+HIP unprojection; the frame loop is :func:`ken_burns_effect_amd.common.process_kenburns`.
+
+Differences, on purpose: the unused Mask-RCNN of the reference (:36, deleted at :90) is not built;
+``cv2.minMaxLoc`` is replaced by :func:`synthetic.depthrange_of`; frames are written with PIL and the
+video through an ``ffmpeg`` binary if one is on PATH (OpenCV / moviepy are not dependencies) --
+otherwise only the PNG frames / an ``.npy`` stack are written.  Returns the frame list.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import torch
+
+from . import common, synthetic
+from .disparity_estimation import Disparity, Semantics
+from .disparity_refinement import Refine, RefinePretrained
+from .partial_inpainting import Inpaint as PartialInpaint
+from .pointcloud_inpainting import Inpaint
+from .utils import load_models, resize_image
+
+
+class Pipeline():
+    def __init__(self, model_paths=None, partial_inpainting=False, dolly=False, output_frames=False, pretrain=False, d2=False,
+                 device='cuda:0', steps=75):
+        self.objectCommon = {'dblFocal': 1024.0 / 2, 'dblBaseline': 120}       # pipeline.py:26-27
+        self.partial_inpainting, self.dolly, self.output_frames, self.d2 = partial_inpainting, dolly, output_frames, d2
+        self.device, self.steps = torch.device(device), steps
+        self.moduleSemantics = Semantics().to(self.device).eval()
+        self.moduleDisparity = Disparity().to(self.device).eval()
+        self.moduleRefine = (RefinePretrained() if pretrain else Refine()).to(self.device).eval()
+        self.moduleInpaint = (PartialInpaint() if partial_inpainting else Inpaint()).to(self.device).eval()
+        models_list = [{'model': self.moduleDisparity, 'type': 'disparity'}, {'model': self.moduleRefine, 'type': 'refine'},
+                       {'model': self.moduleInpaint, 'type': 'inpaint'}]
+        paths = list(model_paths) if model_paths else [None, None, None]
+        if len(paths) == 4:
+            # pipeline.py:53-55 builds a second Inpaint for depth; process_inpaint's two-network branch is
+            # broken in the reference (common.py:50-69), so the fourth checkpoint is loaded but unused
+            self.moduleInpaintDepth = Inpaint().to(self.device).eval()
+            models_list.append({'model': self.moduleInpaintDepth, 'type': 'inpaint'})
+        load_models(models_list, paths)
+        synthetic.seeded_fill_(self.moduleSemantics, 999)       # torchvision's ImageNet weights are not available offline
+
+    @torch.no_grad()
+    def estimate(self, tensorImage):
+        """pipeline.py:61-100: fills ``self.objectCommon`` from an image [1,3,H,W] in 0..1."""
+        oc = self.objectCommon
+        tensorImage = tensorImage.to(self.device).contiguous()
+        oc['intWidth'], oc['intHeight'] = tensorImage.size(3), tensorImage.size(2)
+        resized = resize_image(tensorImage, max_size=int(max(oc['intWidth'], oc['intHeight']) / 2))
+        disparity = self.moduleDisparity(resized, self.moduleSemantics(resized))
+        if self.d2:
+            disparity = torch.ones_like(disparity)
+        disparity = self.moduleRefine(tensorImage, disparity)
+        low = disparity.min()
+        if low < 0.0:
+            disparity = disparity - low
+        disparity = disparity / disparity.max() * oc['dblBaseline']
+        depth = (oc['dblFocal'] * oc['dblBaseline']) / (disparity + 1e-7)
+        points = common.depth_to_points(depth, oc['dblFocal'])
+        oc['dblDispmin'], oc['dblDispmax'] = disparity.min().item(), disparity.max().item()
+        oc['objectDepthrange'] = synthetic.depthrange_of(depth)
+        oc['tensorRawPoints'] = points.view(1, 3, -1)
+        oc['tensorRawImage'], oc['tensorRawDisparity'], oc['tensorRawDepth'] = tensorImage, disparity, depth
+        return oc
+
+    @torch.no_grad()
+    def __call__(self, tensorImage, zoom_settings, output_path=None, inpaint_depth=False, pretrained_estim=False):
+        self.estimate(tensorImage)
+        if inpaint_depth:
+            raise NotImplementedError('two-network depth inpainting is broken in the reference (common.py:50-69)')
+        frames = common.process_kenburns({'dblSteps': np.linspace(0.0, 1.0, self.steps).tolist(),
+                                          'objectFrom': zoom_settings['objectFrom'], 'objectTo': zoom_settings['objectTo'],
+                                          'boolInpaint': True, 'dolly': self.dolly}, self.objectCommon, self.moduleInpaint)
+        if output_path is not None:
+            os.makedirs(output_path, exist_ok=True)
+            # channel order on disk as the reference produces it: frames are in the INPUT's channel order
+            # (BGR from cv2.imread unless --pretrained-estim); cv2.imwrite / moviepy want BGR / RGB (:125-134)
+            to_rgb = (lambda f: f) if pretrained_estim else (lambda f: f[:, :, ::-1])
+            if self.output_frames:
+                write_frames(os.path.join(output_path, 'frames'), [to_rgb(f) for f in frames])
+            write_video(os.path.join(output_path, '3d_kbe.mp4'), [to_rgb(f) for f in frames + list(reversed(frames))[1:]], fps=25)
+        return frames
+
+
+def write_frames(frames_dir, frames_rgb):
+    from PIL import Image
+    os.makedirs(frames_dir, exist_ok=True)
+    for idx, frame in enumerate(frames_rgb):
+        Image.fromarray(np.ascontiguousarray(frame)).save(os.path.join(frames_dir, '%d.png' % idx))
+
+
+def write_video(path, frames_rgb, fps=25):
+    """mpeg4 through an ffmpeg pipe when the binary exists (what moviepy does, pipeline.py:132-134);
+    otherwise the frame stack is saved next to it as .npy and the function says so."""
+    ffmpeg = shutil.which('ffmpeg')
+    h, w = frames_rgb[0].shape[:2]
+    if ffmpeg is None:
+        np.save(os.path.splitext(path)[0] + '.npy', np.stack(frames_rgb))
+        print('ffmpeg not found: wrote %s.npy (%d frames) instead of %s' % (os.path.splitext(path)[0], len(frames_rgb), path))
+        return False
+    proc = subprocess.Popen([ffmpeg, '-y', '-loglevel', 'error', '-f', 'rawvideo', '-pix_fmt', 'rgb24', '-s', '%dx%d' % (w, h),
+                             '-r', str(fps), '-i', '-', '-c:v', 'mpeg4', path], stdin=subprocess.PIPE)
+    for frame in frames_rgb:
+        proc.stdin.write(np.ascontiguousarray(frame).tobytes())
+    proc.stdin.close()
+    return proc.wait() == 0

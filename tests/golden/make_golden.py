@@ -450,6 +450,29 @@ def gen_inpaint():
     save('partial_inpaint', **arrays)
 
 
+def gen_disparity():
+    """Disparity (6x4 GridNet) and the two Refine variants with name-seeded weights.  Semantics wraps
+    torchvision's VGG19-bn (absent here), so Disparity is fed a random semantics tensor."""
+    import models.disparity_estimation as DE
+    import models.disparity_refinement as DR
+    import models.disparity_refinement_pretrained as DRP
+    rng = np.random.default_rng(71)
+    arrays = {}
+    image = torch.from_numpy(rng.random((1, 3, 64, 96), dtype=np.float32))
+    sem = torch.from_numpy(rng.normal(0, 1, (1, 512, 4, 6)).astype(np.float32))
+    net = synthetic.seeded_fill_(DE.Disparity().eval(), 11)
+    arrays.update(image=npy(image), semantics=npy(sem), disp_out=npy(net(image, sem)),
+                  disp_names=np.array(sorted(net.state_dict().keys())), disp_params=np.int64(sum(p.numel() for p in net.parameters())))
+    coarse = torch.from_numpy((rng.random((1, 1, 16, 24), dtype=np.float32) * 50 + 5).astype(np.float32))
+    arrays['coarse'] = npy(coarse)
+    for tag, mod in (('refine', DR), ('refinep', DRP)):
+        r = synthetic.seeded_fill_(mod.Refine().eval(), 13)
+        arrays[tag + '_out'] = npy(r(image, coarse))
+        arrays[tag + '_names'] = np.array(sorted(r.state_dict().keys()))
+        arrays[tag + '_params'] = np.int64(sum(p.numel() for p in r.parameters()))
+    save('disparity', **arrays)
+
+
 class RecordedInpaint:
     """Wraps the reference Inpaint and records what pointcloud_inpainting returned."""
 
@@ -503,6 +526,6 @@ if __name__ == '__main__':
     HARNESS = Harness()
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)   # bit-stable conv results
-    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns']
+    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'disparity']
     for w in which:
         globals()['gen_' + w]()

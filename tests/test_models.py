@@ -130,3 +130,53 @@ def test_partial_inpaint_matches_reference(oracle_kernels):
     assert out['tensorExisting'].shape[1] == 1                                                # ours: what process_inpaint needs
     assert np.abs(out['tensorImage'].numpy() - z['fw_image']).max() < 5e-5
     assert np.abs(out['tensorDisparity'].numpy() - z['fw_disparity']).max() < 5e-4 * max(1.0, np.abs(z['fw_disparity']).max())
+
+
+# ---------------------------------------------------------------------------------------
+# disparity estimation / refinement (stock torch modules; checkpoint compatibility + outputs)
+# ---------------------------------------------------------------------------------------
+
+def test_disparity_network_matches_reference():
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.disparity_estimation import Disparity
+    z = load_golden('disparity')
+    net = synthetic.seeded_fill_(Disparity().eval(), 11)
+    assert sorted(net.state_dict().keys()) == [str(s) for s in z['disp_names']]
+    assert sum(p.numel() for p in net.parameters()) == int(z['disp_params'])
+    with torch.no_grad():
+        out = net(_t(z['image']), _t(z['semantics']))
+    assert out.shape == (1, 1, 32, 48)
+    assert np.abs(out.numpy() - z['disp_out']).max() < 1e-4 * max(1.0, np.abs(z['disp_out']).max())
+
+
+def test_refine_networks_match_reference():
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.disparity_refinement import Refine, RefinePretrained
+    z = load_golden('disparity')
+    for tag, cls in (('refine', Refine), ('refinep', RefinePretrained)):
+        net = synthetic.seeded_fill_(cls().eval(), 13)
+        assert sorted(net.state_dict().keys()) == [str(s) for s in z[tag + '_names']]
+        assert sum(p.numel() for p in net.parameters()) == int(z[tag + '_params'])
+        image, coarse = _t(z['image']), _t(z['coarse'])
+        with torch.no_grad():
+            out = net(image, coarse)
+        assert out.shape == (1, 1, 64, 96)
+        assert np.abs(out.numpy() - z[tag + '_out']).max() < 1e-4 * max(1.0, np.abs(z[tag + '_out']).max())
+        assert_bits_equal(coarse.numpy(), z['coarse'], 'inputs untouched')
+
+
+def test_semantics_is_vgg19_bn_up_to_the_fourth_pool():
+    from ken_burns_effect_amd.disparity_estimation import Semantics
+    net = Semantics().eval()
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert [c.out_channels for c in convs] == [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512]
+    # torchvision indices of the conv layers inside vgg19_bn().features
+    names = [k for k in net.state_dict() if k.endswith('.weight') and net.state_dict()[k].dim() == 4]
+    assert [int(k.split('.')[2]) for k in names] == [0, 3, 7, 10, 14, 17, 20, 23, 27, 30, 33, 36]
+    x = torch.rand(1, 3, 50, 70)
+    x0 = x.clone()
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (1, 512, 4, 5) and torch.equal(x, x0)          # four ceil-mode pools: 50 -> 25 -> 13 -> 7 -> 4
+    fake = {'features.' + k.split('.', 2)[2]: v.clone() + 1 for k, v in net.state_dict().items()}
+    net.load_torchvision_state_dict(fake)
