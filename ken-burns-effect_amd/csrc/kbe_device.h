@@ -120,25 +120,44 @@ __device__ __forceinline__ bool inside(int x, int y, int W, int H)
     return (x >= 0) & (x < W) & (y >= 0) & (y < H);
 }
 
+// `a + 1.0` evaluated in double (common.py:556-557, :639) equals the fp32 sum exactly when a lies in
+// [2^19, 2^20 - 1): there fp32 has a spacing of 1/16, so adding 1.0 is exact.  dblError lives in that
+// band for every point farther than F*B/475712 from the camera, and so does the empty value 1e6.
+__device__ __forceinline__ bool plus_one_is_exact(float a)
+{
+    return (a >= 524288.0f) & (a < 1048575.0f);
+}
+
 // common.py:542-567 for one pixel; `at(x, y)` returns the pre-degrid value of an in-image pixel.
+// The nine values are fetched first; when all of them allow it (wave-uniform test, the normal case)
+// the `>= ... + 1.0` comparisons run in fp32, otherwise in fp64 as written in the reference.
 template <class At>
 __device__ __forceinline__ float degrid_pixel(int x, int y, int W, int H, At at)
 {
     const float c = at(x, y);
-    int count = 0;
-    float sum = 0.0f;
     const int ox[4] = { 1, 0, 1, 1 };
     const int oy[4] = { 0, 1, 1, -1 };
+    float a[4], d[4];
+    bool use[4];
+    bool exact = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
-        if (!inside(x1, y1, W, H) || !inside(x2, y2, W, H)) continue;
-        const float a = at(x1, y1), d = at(x2, y2);
-        if (((double) c >= (double) a + 1.0) && ((double) c >= (double) d + 1.0)) {
-            count += 2;
-            sum += a;
-            sum += d;
-        }
+        use[k] = inside(x1, y1, W, H) && inside(x2, y2, W, H);
+        a[k] = use[k] ? at(x1, y1) : 1000000.0f;
+        d[k] = use[k] ? at(x2, y2) : 1000000.0f;
+        exact = exact && plus_one_is_exact(a[k]) && plus_one_is_exact(d[k]);
+    }
+    int count = 0;
+    float sum = 0.0f;
+    if (__all(exact)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (use[k] && (c >= a[k] + 1.0f) && (c >= d[k] + 1.0f)) { count += 2; sum += a[k]; sum += d[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (use[k] && ((double) c >= (double) a[k] + 1.0) && ((double) c >= (double) d[k] + 1.0)) { count += 2; sum += a[k]; sum += d[k]; }
     }
     return count > 0 ? fminf(c, sum / (float) count) : c;
 }

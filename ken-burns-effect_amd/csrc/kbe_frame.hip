@@ -62,7 +62,7 @@ constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's 
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
 static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS, "tile geometry");
-static_assert(REC_CAP * 4 >= TW * TH * 3, "the uint8 staging area re-uses the record index array");
+static_assert(REC_CAP * 16 >= TW * TH * 3, "the uint8 staging area re-uses the record data array");
 
 struct Scratch {                            // carve-out of the caller's scratch allocation
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
@@ -268,7 +268,7 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
 
 struct TileLds {
     float4 rec[REC_CAP];        // ox, oy, dblError, next record (int bits)
-    int rec_id[REC_CAP];        // point index (its r, g, b, depth are fetched on demand); later the uint8 staging area
+    float4 rgbd[REC_CAP];       // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
     int head[BH * BW];          // first record of each bin, -1 = empty
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo
     float zee[TH * TW];         // degridded z-buffer
@@ -276,41 +276,52 @@ struct TileLds {
 };
 
 // threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
-__device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float oy, float err, int id, int x0, int y0)
+__device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float oy, float err, const float4& rgbd, int x0, int y0)
 {
     const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
-    L.rec_id[idx] = id;
+    L.rgbd[idx] = rgbd;
     const int next = atomicExch(&L.head[by * BW + bx], idx);
     L.rec[idx] = make_float4(ox, oy, err, __int_as_float(next));
 }
 
-// z-tested bilinear accumulation (common.py:586-669) of the records now in LDS, in registers
+__device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
+{
+    const float* I = a.image + id;
+    const size_t N = (size_t) a.N;
+    return make_float4(I[0], I[N], I[2 * N], a.depth_in[id]);
+}
+
+// z-tested bilinear accumulation (common.py:586-669) of the records now in LDS, in registers.
+// Everything the walk touches is in LDS (a variant that fetched r, g, b, depth from global memory per
+// (pixel, record) pair spent ~13 us of the launch on those dependent loads; one that issued the loads of
+// all four bins in stages before consuming them was 25 % slower still).
 __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int tid, int x0, int y0,
                                        float (&acc)[PIX_PER_THREAD][5])
 {
-    const size_t N = (size_t) a.N;
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
         const int q = tid + m * TILE_THREADS;
         const int ly = q / TW, lx = q - ly * TW;
         if (!inside(x0 + lx, y0 + ly, a.cam.W, a.cam.H)) continue;
-        const double zlim = (double) L.zee[q] + 1.0;
+        const float zee = L.zee[q];
+        const bool exact = plus_one_is_exact(zee);                          // then zee + 1.0f IS the double sum
+        const float zlimf = zee + 1.0f;
+        const double zlim = (double) zee + 1.0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // corner k of a point is this pixel  <=>  its north-west corner is (lx - (k & 1), ly - (k >> 1))
             int idx = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
             while (idx >= 0) {
                 const float4 r = L.rec[idx];
-                if ((double) r.z <= zlim) {                                 // :639
+                if (exact ? (r.z <= zlimf) : ((double) r.z <= zlim)) {      // :639 (the fp64 side only exists for odd z)
                     Proj pr;
                     project_weights(r.x, r.y, pr);
                     const float w = pr.w[k];
-                    const int id = L.rec_id[idx];
-                    const float* I = a.image + id;                          // L1/L2-hot: four pixels share each point
-                    acc[m][0] += I[0] * w;                                  // :641 product rounded, then added
-                    acc[m][1] += I[N] * w;
-                    acc[m][2] += I[2 * N] * w;
-                    acc[m][3] += a.depth_in[id] * w;
+                    const float4 c = L.rgbd[idx];
+                    acc[m][0] += c.x * w;                                   // :641 product rounded, then added
+                    acc[m][1] += c.y * w;
+                    acc[m][2] += c.z * w;
+                    acc[m][3] += c.w * w;
                     acc[m][4] += w;                                         // the `ones` channel (:429)
                 }
                 idx = __float_as_int(r.w);
@@ -319,9 +330,18 @@ __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int 
     }
 }
 
+#if defined(KBE_PROBE_TIMING)
+#define KBE_TICK(i) do { if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + (i)] = (long long) __builtin_readcyclecounter(); } while (0)
+#else
+#define KBE_TICK(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
 {
     __shared__ TileLds L;
+#if defined(KBE_PROBE_TIMING)
+    if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + 0] = (long long) __builtin_readcyclecounter();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -329,13 +349,45 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     const int x0 = tx * TW, y0 = ty * TH;
     const int W = a.cam.W, H = a.cam.H;
 
-    // z-buffer tile + halo (common.py:430 for pixels outside the image: never read)
-    for (int i = tid; i < KH * KW; i += TILE_THREADS) {
+    // The launch is latency-bound, so every independent global load is issued before anything waits:
+    // the bucket count, then this thread's share of the z-buffer tile, then its share of the first
+    // REC_CAP records and their colours; only then the first barrier.
+    const int count = a.tile_count[tile * CNT_STRIDE];
+    const bool bucketed = count <= BUCKET_CAP;
+    const float4* B = a.buckets + (size_t) tile * BUCKET_CAP;
+    constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
+    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
+    uint32_t zk[ZPER];
+#pragma unroll
+    for (int u = 0; u < ZPER; u++) {
+        const int i = tid + u * TILE_THREADS;
         const int py = i / KW, pxl = i - py * KW;
         const int x = x0 - 1 + pxl, y = y0 - 1 + py;
-        L.zpre[i] = inside(x, y, W, H) ? zkey_decode(a.zkeys[(size_t) y * W + x]) : 1000000.0f;
+        zk[u] = (i < KH * KW && inside(x, y, W, H)) ? a.zkeys[(size_t) y * W + x] : KBE_ZKEY_EMPTY;     // common.py:430 outside
     }
+    float4 rr[PER], cc[PER];
+    // the first REC_CAP records are loaded WITHOUT waiting for the count (the bucket is at least that
+    // large, so the addresses are valid; slots past the count hold stale records and are masked below)
+    static_assert(BUCKET_CAP >= ((REC_CAP + TILE_THREADS - 1) / TILE_THREADS) * TILE_THREADS, "speculative bucket loads stay in bounds");
+#pragma unroll
+    for (int u = 0; u < PER; u++) rr[u] = B[tid + u * TILE_THREADS];
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+    if (tid == 0) L.nrec = 0;
+#pragma unroll
+    for (int u = 0; u < ZPER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        if (i < KH * KW) L.zpre[i] = zkey_decode(zk[u]);
+    }
+    KBE_TICK(1);
     __syncthreads();
+    KBE_TICK(2);
+    // the records have landed by now: fetch their colours; these loads fly while the degrid computes
+    const int n0 = bucketed ? min(REC_CAP, count) : 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        cc[u] = i < n0 ? fetch_rgbd(a, __float_as_int(rr[u].w)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     // degrid (common.py:525-568), out of place
     for (int i = tid; i < TH * TW; i += TILE_THREADS) {
         const int ly = i / TW, lx = i - ly * TW;
@@ -354,29 +406,48 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
 #pragma unroll
         for (int ch = 0; ch < 5; ch++) acc[m][ch] = 0.0f;
 
-    const int count = a.tile_count[tile * CNT_STRIDE];
-    if (count <= BUCKET_CAP) {
+    if (bucketed) {
         // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
-        const float4* B = a.buckets + (size_t) tile * BUCKET_CAP;
         for (int r0 = 0; r0 == 0 || r0 < count; r0 += REC_CAP) {
-            for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
-            __syncthreads();
             const int n = min(REC_CAP, count - r0);
-            for (int i = tid; i < n; i += TILE_THREADS) {
-                const float4 r = B[r0 + i];
-                lds_insert(L, i, r.x, r.y, r.z, __float_as_int(r.w), x0, y0);
+            if (r0 > 0) {
+                __syncthreads();                                // the previous round's gather is done with the lists
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    rr[u] = i < n ? B[r0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    cc[u] = i < n ? fetch_rgbd(a, __float_as_int(rr[u].w)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                __syncthreads();
             }
+            KBE_TICK(3);
+#if !defined(KBE_PROBE_SKIP_INSERT)
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                if (i < n) lds_insert(L, i, rr[u].x, rr[u].y, rr[u].z, cc[u], x0, y0);
+            }
+#endif
+            KBE_TICK(4);
             __syncthreads();
+            KBE_TICK(5);
+#if !defined(KBE_PROBE_SKIP_GATHER)
             gather(a, L, tid, x0, y0, acc);
-            __syncthreads();
+#endif
+            KBE_TICK(6);
         }
+        __syncthreads();
+        KBE_TICK(7);
     } else {
         // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
         // records from the whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
-        const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
-        for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
-        if (tid == 0) L.nrec = 0;
         __syncthreads();
+        const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
         for (int i0 = 0; i0 < n_round; i0 += TILE_THREADS) {
             const int i = i0 + tid;
             bool ok = i < a.N;
@@ -397,7 +468,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
                 const int leader = __ffsll((long long) m) - 1;
                 if (lane == leader) base = atomicAdd(&L.nrec, __popcll(m));
                 base = __shfl(base, leader);
-                if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), i, x0, y0);
+                if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), fetch_rgbd(a, i), x0, y0);
             }
             __syncthreads();
             if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
@@ -412,7 +483,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
 
     // resolve: normalise (common.py:686), hole mask (:253), uint8 (:255)
     const size_t HW = (size_t) W * H;
-    uint8_t* s_u8 = (uint8_t*) L.rec_id;          // the records are dead now
+    uint8_t* s_u8 = (uint8_t*) L.rgbd;            // the records are dead now
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
         const int q = tid + m * TILE_THREADS;
@@ -440,11 +511,15 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
         if (in) {
             const size_t o = (size_t) y * W + x;
             a.depth[o] = dm;
+#if !defined(KBE_PROBE_TIMING)
             if (a.render) { a.render[o] = r; a.render[HW + o] = g; a.render[2 * HW + o] = b; a.render[3 * HW + o] = d; }
+#endif
             if (a.existing) a.existing[o] = w;
         }
     }
+    KBE_TICK(8);
     __syncthreads();
+    KBE_TICK(9);
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
     const bool fast = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
     if (fast) {
@@ -462,6 +537,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
             if (x0 + lx < W && y0 + ly < H) a.frame[((size_t) (y0 + ly) * W + x0 + lx) * 3 + ch] = s_u8[i];
         }
     }
+    KBE_TICK(10);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def main():
         subprocess.check_call(cmd)
         _native._lib, _native._kernels, _native.LIB_PATH = None, None, so
         dev = torch.device('cuda:0')
-        oc = bench.build_scene(size, dev, False)
+        oc = bench.build_scene(size, dev, os.environ.get('CLOUD', 'inpaint') == 'inpaint', dict(dolly=False, objectFrom=synthetic.default_windows(size, size, False)[0], objectTo=synthetic.default_windows(size, size, False)[1]))
         ofrom, oto = synthetic.default_windows(size, size, False)
         settings = {'dblSteps': [0.0, 0.25, 0.5, 0.75, 1.0], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': False, 'dolly': False}
         cams = common.frame_cameras(settings, oc)
@@ -38,6 +38,17 @@ def main():
             cw, ch = common.crop_size(settings)
             kt = bench.time_kernels(oc, [cams[ci]], reps=20, fill_rect=common.crop_window(size, size, cw, ch))
             res[ci] = kt
+        if 'KBE_PROBE_TIMING' in flags:
+            K = _native.kernels()
+            state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], size, size)
+            dbg = torch.zeros(4, size, size, device=dev)
+            focal, shift3 = cams[2]
+            K.render_frame(state, shift3, focal, oc['dblBaseline'], render_f32=dbg, stages=3)
+            torch.cuda.synchronize()
+            t = dbg.view(torch.int64).reshape(-1)[:(size // 32) ** 2 * 16].reshape(-1, 16).cpu().numpy().astype('float64')
+            d = t[:, 1:11] - t[:, 0:10]
+            names = ['loads->lds', 'barrier1', 'degrid', 'insert', 'barrier2', 'gather', 'barrier3', 'resolve', 'barrier4', 'store']
+            print('   phases (cycles, mean over tiles): ' + ' '.join('%s=%.0f' % (n, v) for n, v in zip(names, d.mean(0))), ' total=%.0f' % (t[:, 10] - t[:, 0]).mean(), flush=True)
         print('variant %-50s' % (flags or '(default)'), ' | '.join(
             'step%d proj %.1f tiles %.1f fill %.1f frame %.1f' % (ci, r['project+reset'] * 1e6, r['tiles'] * 1e6, r['fill'] * 1e6, r['frame'] * 1e6) for ci, r in res.items()),
             flush=True)
