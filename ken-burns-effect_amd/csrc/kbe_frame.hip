@@ -50,7 +50,7 @@ namespace {
 #define KBE_TILE_CAP 1536
 #endif
 #ifndef KBE_BUCKET_FACTOR
-#define KBE_BUCKET_FACTOR 6
+#define KBE_BUCKET_FACTOR 12
 #endif
 constexpr int TW = KBE_TILE_W, TH = KBE_TILE_H;     // target tile owned by one workgroup
 constexpr int KW = TW + 2, KH = TH + 2;             // tile + the 1-px halo whose z the degrid reads
@@ -59,6 +59,11 @@ constexpr int TILE_THREADS = KBE_TILE_THREADS;
 constexpr int PIX_PER_THREAD = TW * TH / TILE_THREADS;
 constexpr int REC_CAP = KBE_TILE_CAP;               // records a tile holds in LDS at once (more: several rounds)
 constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's bucket holds in HBM (more: brute force)
+#ifndef KBE_BUCKET_PAD
+#define KBE_BUCKET_PAD 272
+#endif
+constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between two buckets: NOT a power-of-two multiple, or the
+                                                    // live head of every bucket lands on the same few HBM channels
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
 static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS, "tile geometry");
@@ -68,9 +73,10 @@ struct Scratch {                            // carve-out of the caller's scratch
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
     int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
     int* hole_count;        // [1]
+    int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
     int* holes;             // [H*W]
     float* depth;           // [H*W]  render[3] * (existing > 0): what the fill walks on
-    float4* buckets;        // [n_tiles][BUCKET_CAP]  {ox, oy, dblError, point index}
+    float4* buckets;        // [n_tiles][BUCKET_STRIDE]  {ox, oy, dblError, point index}
     int tiles_x, tiles_y;
 };
 
@@ -87,6 +93,7 @@ Scratch carve(void* base, int W, int H)
     s.zkeys = (uint32_t*) p;      p += align16(4 * hw);
     s.tile_count = (int*) p;      p += align16(4 * n_tiles * CNT_STRIDE);
     s.hole_count = (int*) p;      p += 16;
+    s.bbox = (int4*) p;           p += align16(16 * n_tiles);
     s.holes = (int*) p;           p += align16(4 * hw);
     s.depth = (float*) p;         p += align16(4 * hw);
     s.buckets = (float4*) p;
@@ -97,7 +104,7 @@ size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_CAP * sizeof(float4);
+    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
 __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
                     const int b0 = __shfl(base[j][e], grp[j][e].leader);
                     if (want[j][e]) {
                         const int slot = b0 + __popcll(grp[j][e].same & ((1ull << lane) - 1ull));
-                        if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[j][e] * BUCKET_CAP + slot] = rec[j];   // beyond: the tile sees count > cap
+                        if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[j][e] * BUCKET_STRIDE + slot] = rec[j];   // beyond: the tile sees count > cap
                     }
                 }
         }
@@ -252,6 +259,7 @@ struct TileArgs {
     float* depth;           // [H*W]
     int* holes;
     int* hole_count;
+    int4* bbox;
     float* render;          // optional [4,H,W] (unfilled; the fill kernel patches the holes)
     float* existing;        // optional [H*W]
     float* zee;             // optional [H*W] degridded z-buffer
@@ -354,7 +362,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     // REC_CAP records and their colours; only then the first barrier.
     const int count = a.tile_count[tile * CNT_STRIDE];
     const bool bucketed = count <= BUCKET_CAP;
-    const float4* B = a.buckets + (size_t) tile * BUCKET_CAP;
+    const float4* B = a.buckets + (size_t) tile * BUCKET_STRIDE;
     constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
     constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
     uint32_t zk[ZPER];
@@ -517,8 +525,39 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
             if (a.existing) a.existing[o] = w;
         }
     }
+    // bounding box of the valid pixels (depth > 0): lets the hole fill discard rays that can never hit one
+    {
+        int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) {
+            const int q = tid + m * TILE_THREADS;
+            const int ly = q / TW, lx = q - ly * TW;
+            const int x = x0 + lx, y = y0 + ly;
+            const float w = acc[m][4];
+            const bool valid = x < W && y < H && (acc[m][3] / (w + 0.0000001f)) * (w > 0.0f ? 1.0f : 0.0f) > 0.0f;
+            if (valid) { vx0 = min(vx0, x); vy0 = min(vy0, y); vx1 = max(vx1, x); vy1 = max(vy1, y); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            vx0 = min(vx0, __shfl_xor(vx0, off)); vy0 = min(vy0, __shfl_xor(vy0, off));
+            vx1 = max(vx1, __shfl_xor(vx1, off)); vy1 = max(vy1, __shfl_xor(vy1, off));
+        }
+        // per-wave boxes meet in LDS (the bin heads are dead by now), one plain 16-byte store per tile;
+        // global atomics here -- even one cache line per tile row, even with a look first -- serialised so
+        // badly across XCDs that they added 80-350 us per frame
+        int* sb = L.head;
+        if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; }
+    }
     KBE_TICK(8);
     __syncthreads();
+    if (tid == 0) {
+        const int* sb = L.head;
+        int4 bb = make_int4(W, H, -1, -1);
+        for (int w = 0; w < TILE_THREADS / 64; w++) {
+            bb.x = min(bb.x, sb[4 * w]); bb.y = min(bb.y, sb[4 * w + 1]); bb.z = max(bb.z, sb[4 * w + 2]); bb.w = max(bb.w, sb[4 * w + 3]);
+        }
+        a.bbox[tile] = bb;
+    }
     KBE_TICK(9);
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
     const bool fast = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
@@ -550,7 +589,8 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
                                                     const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
-                                                    uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles)
+                                                    uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
+                                                    const int4* __restrict__ bbox)
 {
     // leave the scratch ready for the next frame: empty z-buffer, empty buckets
     {
@@ -559,6 +599,24 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
         for (int i = gtid; i < n_tiles; i += gsz) tile_count[i * CNT_STRIDE] = 0;
     }
     const int n = *hole_count;
+    // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
+    // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
+    // (common.py:880-885) without walking there.  Exact, and it is what makes a zoomed-out (dolly) frame,
+    // where most of the image is empty border, cheap.
+    __shared__ int s_bb[4][4];
+    int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int4 bb = bbox[t];
+        bx0 = min(bx0, bb.x); by0 = min(by0, bb.y); bx1 = max(bx1, bb.z); by1 = max(by1, bb.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
+        bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_bb[threadIdx.x >> 6][0] = bx0; s_bb[threadIdx.x >> 6][1] = by0; s_bb[threadIdx.x >> 6][2] = bx1; s_bb[threadIdx.x >> 6][3] = by1; }
+    __syncthreads();
+    for (int w = 0; w < 4; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
     const int lane = threadIdx.x & 31;
     const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_groups = (gridDim.x * blockDim.x) >> 5;
     const int d = lane >> 1, end = lane & 1;
@@ -570,7 +628,10 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
         if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1) continue;
         float fx = (float) x, fy = (float) y;
         int ix = 0, iy = 0;
-        bool ok = false, done = false;
+        bool ok = false;
+        bool done = (x < bx0 && ddx <= 0.0f) || (x > bx1 && ddx >= 0.0f) || (y < by0 && ddy <= 0.0f) || (y > by1 && ddy >= 0.0f);
+        // if either end of a direction is hopeless the direction is skipped (:884-885, :895-896): do not walk the other end
+        done = done || (bool) __shfl_xor((int) done, 1);
         float dv = 0.0f;
         // common.py:876-883 / :887-894.  The positions do not depend on the data, so the walk issues
         // kBatch depth loads at a time and then inspects them in order (the dependent-load chain
@@ -593,6 +654,8 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
                 if ((ix < 0) | (ix >= W) | (iy < 0) | (iy >= H)) { done = true; continue; }
                 if (bd[k] > 0.0f) { dv = bd[k]; ok = true; done = true; }
             }
+            // left the box of valid pixels for good?
+            done = done || (ix < bx0 && ddx <= 0.0f) || (ix > bx1 && ddx >= 0.0f) || (iy < by0 && ddy <= 0.0f) || (iy > by1 && ddy >= 0.0f);
         }
         // both ends of my direction
         const int ox = __shfl_xor(ix, 1), oy = __shfl_xor(iy, 1);
@@ -667,7 +730,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         TileArgs a;
         a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
         a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
-        a.frame = frame_u8; a.depth = sc.depth; a.holes = sc.holes; a.hole_count = sc.hole_count;
+        a.frame = frame_u8; a.depth = sc.depth; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox;
         a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
         hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
         if ((rc = launched("kbe_render_frame/tiles"))) return rc;
@@ -678,7 +741,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, W, H, dirs, rect,
-                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles);
+                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
