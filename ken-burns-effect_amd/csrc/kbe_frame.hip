@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 
 #include "kbe.h"
 #include "kbe_device.h"
@@ -66,7 +67,7 @@ constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between t
                                                     // live head of every bucket lands on the same few HBM channels
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
-static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS, "tile geometry");
+static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS && TW % 32 == 0, "tile geometry");
 static_assert(REC_CAP * 16 >= TW * TH * 3, "the uint8 staging area re-uses the record data array");
 
 struct Scratch {                            // carve-out of the caller's scratch allocation
@@ -75,7 +76,8 @@ struct Scratch {                            // carve-out of the caller's scratch
     int* hole_count;        // [1]
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
     int* holes;             // [H*W]
-    float* depth;           // [H*W]  render[3] * (existing > 0): what the fill walks on
+    float* depth;           // [H*W]  render[3] * (existing > 0): the fill compares the two ends of a ray with it
+    uint32_t* mask;         // [H][ceil(W/32)]  bit = depth > 0: what the fill walks on (32x smaller than the plane)
     float4* buckets;        // [n_tiles][BUCKET_STRIDE]  {ox, oy, dblError, point index}
     int tiles_x, tiles_y;
 };
@@ -96,6 +98,7 @@ Scratch carve(void* base, int W, int H)
     s.bbox = (int4*) p;           p += align16(16 * n_tiles);
     s.holes = (int*) p;           p += align16(4 * hw);
     s.depth = (float*) p;         p += align16(4 * hw);
+    s.mask = (uint32_t*) p;       p += align16(4 * (size_t) H * ((W + 31) / 32));
     s.buckets = (float4*) p;
     return s;
 }
@@ -104,7 +107,8 @@ size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * hw) + align16(4 * hw) + n_tiles * BUCKET_STRIDE * sizeof(float4);
+    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
+           align16(4 * (size_t) H * ((W + 31) / 32)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
 __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
@@ -257,6 +261,7 @@ struct TileArgs {
     int tiles_x, tiles_y;
     uint8_t* frame;         // [H,W,3]
     float* depth;           // [H*W]
+    uint32_t* mask;         // [H][ceil(W/32)]
     int* holes;
     int* hole_count;
     int4* bbox;
@@ -516,6 +521,10 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
             base = __shfl(base, leader);
             if (hole) a.holes[base + __popcll(hm & ((1ull << lane) - 1ull))] = y * W + x;
         }
+        {   // validity bits: each 32-lane half of the wave holds 32 consecutive pixels of one row
+            const unsigned long long vm = __ballot(in && dm > 0.0f);
+            if ((lane & 31) == 0 && y < H && x < W) a.mask[(size_t) y * ((W + 31) >> 5) + (x >> 5)] = (uint32_t) (vm >> (lane & 32));
+        }
         if (in) {
             const size_t o = (size_t) y * W + x;
             a.depth[o] = dm;
@@ -587,7 +596,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
 struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are filled
 
 __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
-                                                    const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
+                                                    const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
+                                                    FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
                                                     const int4* __restrict__ bbox)
@@ -617,6 +627,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     if ((threadIdx.x & 63) == 0) { s_bb[threadIdx.x >> 6][0] = bx0; s_bb[threadIdx.x >> 6][1] = by0; s_bb[threadIdx.x >> 6][2] = bx1; s_bb[threadIdx.x >> 6][3] = by1; }
     __syncthreads();
     for (int w = 0; w < 4; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
+    const int wpr = (W + 31) >> 5;              // mask words per row
     const int lane = threadIdx.x & 31;
     const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_groups = (gridDim.x * blockDim.x) >> 5;
     const int d = lane >> 1, end = lane & 1;
@@ -632,35 +643,36 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
         bool done = (x < bx0 && ddx <= 0.0f) || (x > bx1 && ddx >= 0.0f) || (y < by0 && ddy <= 0.0f) || (y > by1 && ddy >= 0.0f);
         // if either end of a direction is hopeless the direction is skipped (:884-885, :895-896): do not walk the other end
         done = done || (bool) __shfl_xor((int) done, 1);
-        float dv = 0.0f;
-        // common.py:876-883 / :887-894.  The positions do not depend on the data, so the walk issues
-        // kBatch depth loads at a time and then inspects them in order (the dependent-load chain
-        // of the textbook loop is what makes hole filling latency-bound).
-        constexpr int kBatch = 8;
-        while (!done) {
+        // common.py:876-883 / :887-894.  The positions do not depend on the data, so the walk issues a batch
+        // of mask loads at a time and then inspects them in order (the dependent-load chain of the textbook
+        // loop is avoidable latency).  Batches of 8: larger ones (32 for rays still going) measured slower --
+        // what bounds a frame with few, long rays (one running along a thin disocclusion strip for hundreds
+        // of pixels) is the serial fp32 position update of a lone wave, not the loads.
+        auto walk = [&](auto batch_tag) {
+            constexpr int kBatch = decltype(batch_tag)::value;
             int bx[kBatch], by[kBatch];
-            float bd[kBatch];
+            uint32_t bw[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 fx += ddx; bx[k] = (int) roundf(fx);
                 fy += ddy; by[k] = (int) roundf(fy);
                 const bool in = (bx[k] >= 0) & (bx[k] < W) & (by[k] >= 0) & (by[k] < H);
-                bd[k] = in ? depth[by[k] * W + bx[k]] : -1.0f;
+                bw[k] = in ? mask[(size_t) by[k] * wpr + (bx[k] >> 5)] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 if (done) continue;
                 ix = bx[k]; iy = by[k];
                 if ((ix < 0) | (ix >= W) | (iy < 0) | (iy >= H)) { done = true; continue; }
-                if (bd[k] > 0.0f) { dv = bd[k]; ok = true; done = true; }
+                if ((bw[k] >> (ix & 31)) & 1u) { ok = true; done = true; }      // depth > 0 (common.py:882 / :893)
             }
             // left the box of valid pixels for good?
             done = done || (ix < bx0 && ddx <= 0.0f) || (ix > bx1 && ddx >= 0.0f) || (iy < by0 && ddy <= 0.0f) || (iy > by1 && ddy >= 0.0f);
-        }
+        };
+        while (!done) walk(std::integral_constant<int, 8>());
         // both ends of my direction
         const int ox = __shfl_xor(ix, 1), oy = __shfl_xor(iy, 1);
         const bool ook = (bool) __shfl_xor((int) ok, 1);
-        const float odv = __shfl_xor(dv, 1);
         float dist = INFINITY;
         if (ok && ook) {
             const float ex = (float) (ix - ox), ey = (float) (iy - oy);
@@ -677,7 +689,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
         if (lane == win) {
             // lane `win` is the `from` end (even lane); partner values are the `to` end
             int sxp = ix, syp = iy;
-            if (dv < odv) { sxp = ox; syp = oy; }               // :904 the farther (background) end
+            if (depth[(size_t) iy * W + ix] < depth[(size_t) oy * W + ox]) { sxp = ox; syp = oy; }     // :904 the farther (background) end
             const size_t s = (size_t) syp * W + sxp, o = (size_t) px;
             frame[o * 3] = frame[s * 3]; frame[o * 3 + 1] = frame[s * 3 + 1]; frame[o * 3 + 2] = frame[s * 3 + 2];
             if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + s];
@@ -730,7 +742,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         TileArgs a;
         a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
         a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
-        a.frame = frame_u8; a.depth = sc.depth; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox;
+        a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox;
         a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
         hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
         if ((rc = launched("kbe_render_frame/tiles"))) return rc;
@@ -740,7 +752,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         const unsigned fill_blocks = (unsigned) (hw / 64 < 2048 ? (hw / 64 > 0 ? hw / 64 : 1) : 2048);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, W, H, dirs, rect,
+        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox);
         rc = launched("kbe_render_frame/fill");
     }
