@@ -163,12 +163,19 @@ def main():
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     assert world_size == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world_size)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one process per GPU.  (KBE_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer
+    # GPUs than ranks -- ranks then share devices; never use that for a measurement.)
+    backend = os.environ.get('KBE_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world_size > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     from ken_burns_effect_amd import common, sharding, synthetic
 

@@ -55,7 +55,12 @@ def broadcast_cloud(objectCommon, device, src=0):
     if rank == src:
         packed = torch.cat([objectCommon[k].reshape(-1, n).float() for k in _CLOUD_KEYS], 0).contiguous().to(device)
     else:
-        packed = torch.empty(7, n, dtype=torch.float32, device=device)
+        # re-use the landing buffer of an earlier broadcast of the same size: the tensors below are views of
+        # it, so their addresses (and everything cached per cloud, e.g. the renderer's scratch) stay valid
+        packed = objectCommon.get('_kbePackedCloud')
+        if packed is None or packed.shape != (7, n) or packed.device != torch.device(device):
+            packed = torch.empty(7, n, dtype=torch.float32, device=device)
+            objectCommon['_kbePackedCloud'] = packed
     dist.broadcast(packed, src)
     if rank != src:
         objectCommon['dblFocal'] = h[1]

@@ -353,6 +353,51 @@ def test_degenerate_points_and_incoherent_clouds(K, oracle):
         assert d.max() <= 1 and (d > 0).mean() < 2e-3
 
 
+@pytest.mark.parametrize('per_pixel', [4, 16])
+def test_pile_up_paths(K, oracle, per_pixel):
+    """Many points per pixel: 4/px exceeds the tile's LDS record capacity (several insert+gather rounds),
+    16/px overflows the tile's bucket as well (brute-force path that re-derives the tile from the cloud)."""
+    g0 = torch.Generator().manual_seed(per_pixel)
+    W, H = 96, 64
+    N = per_pixel * W * H
+    u = torch.rand(N, generator=g0) * (W + 8) - 4 - W / 2 + 0.5
+    v = torch.rand(N, generator=g0) * (H + 8) - 4 - H / 2 + 0.5
+    z = torch.rand(N, generator=g0) * 400 + 600
+    pts = torch.stack([u * z / 512.0, v * z / 512.0, z]).unsqueeze(0)
+    img, dep = torch.rand(1, 3, N, generator=g0), z.view(1, 1, N).clone()
+    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+    ok = oracle.OracleKernels('jacobi')
+    ostate = ok.prepare_cloud(pts, img, dep, W, H)
+    shift3, focal = [1.5, -0.75, -20.0], 512.0
+    ex, zp, zd = (torch.empty(W * H, device='cuda') for _ in range(3))
+    rf = torch.empty(4, H, W, device='cuda')
+    f = c(K.render_frame(state, shift3, focal, 120, render_f32=rf, existing_f32=ex, zee_f32=zd, zee_pre_f32=zp))
+    ref, ref_float, ref_ex = ok.render_frame(ostate, shift3, focal, 120, want_float=True)
+    z0, _ = oracle.zsplat(oracle.shift_points(pts, torch.tensor(shift3)), W, H, focal, 120)
+    assert_bits_equal(c(zp).reshape(H, W), z0.numpy()[0, 0], 'z-buffer')
+    assert_bits_equal(c(zd).reshape(H, W), oracle.degrid(z0, 'jacobi').numpy()[0, 0], 'degridded z-buffer')
+    assert np.abs(c(ex).reshape(H, W) - ref_ex.numpy()[0, 0]).max() <= 1e-4 * float(ref_ex.max())
+    assert psnr(c(rf)[:3], ref_float.numpy()[0, :3], 1.0) > 90.0
+    d = np.abs(f.astype(np.int32) - ref.numpy().astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+def test_pipeline_on_gpu_config2_shape(K):
+    """BASELINE.json configs[1] in miniature: 256x256 image through Pipeline (seeded weights) on the GPU."""
+    from ken_burns_effect_amd import kbe, synthetic
+    from ken_burns_effect_amd.pipeline import Pipeline
+    import warnings
+    image, _ = synthetic.make_rgbd(256, 256, 9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipe = Pipeline(model_paths=None, device='cuda:0', steps=5)
+    zoom = kbe.windows_for(256, 256, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
+    frames = pipe(image, zoom)
+    assert len(frames) == 5 and frames[0].shape == (256, 256, 3) and frames[0].dtype == np.uint8
+    assert pipe.objectCommon['tensorInpaPoints'].shape[2] > 256 * 256
+    assert np.stack(frames).std() > 1.0
+
+
 def test_empty_and_single_point_clouds(K):
     z, w = K.zsplat(torch.zeros(1, 3, 0, device='cuda'), 8, 6, 512.0, 120, want_winner=True)
     assert int((K.zkeys_decode(z) != 1000000.0).sum()) == 0 and w.numel() == 0
