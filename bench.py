@@ -104,6 +104,7 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
     # (z-buffer, bucket counters); with an empty fill rectangle it does no hole work.
     empty = (1, 1, 0, 0)
     out = {}
+    out['reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty))
     out['project+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=5, fill_rect=empty))
     out['project+tiles+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty))
     out['frame'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=fill_rect))

@@ -64,6 +64,12 @@ KBE_API const char* kbe_last_error(void);
 /* fills name (<= cap bytes) with the device's gcnArchName, returns CU count or KBE_E_DEVICE */
 KBE_API int kbe_device_info(int device, char* name, int cap);
 
+/* Self-test hook: dblError = (float)(1e6 - F*B / (z + 1e-7)) (common.py:470) of n depths, once through the
+   literal fp64 expression (`exact`) and once through the division-free fast path the frame loop uses
+   (`fast`); the two must agree bit for bit. */
+KBE_API int kbe_selftest_err(const float* z, size_t n, double focal, double baseline, float* fast, float* exact,
+                             kbe_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * render_pointcloud, stage by stage  (common.py:428-686)
  * ------------------------------------------------------------------------------------- */
@@ -153,14 +159,18 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
  * instead of being filled.  A hole is never the source of another pixel's fill (sources are valid
  * pixels of the un-filled render, common.py:921-923), so when the caller is going to crop the
  * frame (common.py:256-257) skipping the holes the crop discards changes nothing inside the
- * crop window. */
+ * crop window; and (c) a layout hint: the first `raster_n` points of the cloud are a row-major
+ * raster `raster_w` wide (the image pixels, as process_kenburns builds tensorInpaPoints); 0, 0 if
+ * unknown.  The hint only changes how points are assigned to waves (32x8 patches), never the
+ * result. */
 #define KBE_STAGE_PROJECT 1
 #define KBE_STAGE_TILES 2
 #define KBE_STAGE_FILL 4
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
-                                    float* zee_pre_f32, int stages, const int* fill_rect, kbe_stream_t stream);
+                                    float* zee_pre_f32, int stages, const int* fill_rect, int raster_w, int raster_n,
+                                    kbe_stream_t stream);
 
 /* The whole frame loop of process_kenburns (common.py:222-260) for `n_frames` cameras, enqueued
  * from native code (no per-frame host-language work): per frame kbe_render_frame_stages, then the
@@ -176,7 +186,7 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
-                             kbe_stream_t stream, kbe_stream_t copy_stream);
+                             int raster_w, int raster_n, kbe_stream_t stream, kbe_stream_t copy_stream);
 
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
 KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);

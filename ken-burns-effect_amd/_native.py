@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 
 # every symbol include/kbe.h declares (tests check the library exports exactly these)
 SYMBOLS = (
-    'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
+    'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_video', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
@@ -95,6 +95,13 @@ class HipKernels:
     def _check(self, rc, what):
         if rc != 0:
             raise KbeError('%s failed (%d): %s' % (what, rc, self.lib.kbe_last_error().decode()))
+
+    def selftest_err(self, z, focal, baseline):
+        z = _f32c(z).reshape(-1)
+        fast, exact = torch.empty_like(z), torch.empty_like(z)
+        self._check(self.lib.kbe_selftest_err(_ptr(z), _z(z.numel()), _d(float(focal)), _d(float(baseline)), _ptr(fast), _ptr(exact),
+                                              _stream()), 'kbe_selftest_err')
+        return fast, exact
 
     # -- render_pointcloud and its stages ------------------------------------------------
     def zsplat(self, points, W, H, focal, baseline, shift3=None, want_winner=False):
@@ -173,7 +180,11 @@ class HipKernels:
         N = points.shape[-1]
         dev = points.device
         state = {'points': _f32c(points).reshape(3, N), 'image': _f32c(image).reshape(3, N), 'depth': _f32c(depth).reshape(N),
-                 'N': N, 'W': W, 'H': H, 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev)}
+                 'N': N, 'W': W, 'H': H, 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev),
+                 # layout hint: process_kenburns' cloud starts with the W x H image raster (common.py:176-179)
+                 'raster_w': W if N >= W * H else 0, 'raster_n': W * H if N >= W * H else 0}
+        if os.environ.get('KBE_NO_RASTER_HINT'):
+            state['raster_w'] = state['raster_n'] = 0
         nbytes = int(self.lib.kbe_frame_scratch_bytes(_i(W), _i(H)))
         state['scratch'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._check(self.lib.kbe_frame_scratch_init(_ptr(state['scratch'], torch.uint8), _i(W), _i(H), _stream()),
@@ -190,7 +201,8 @@ class HipKernels:
                                                      _i(state['N']), _i(state['W']), _i(state['H']), _d(float(focal)),
                                                      _d(float(baseline)), _shift(shift3), _ptr(state['scratch'], torch.uint8),
                                                      _ptr(frame, torch.uint8), _ptr(render_f32), _ptr(existing_f32),
-                                                     _ptr(zee_f32), _ptr(zee_pre_f32), _i(int(stages)), rect, _stream()),
+                                                     _ptr(zee_f32), _ptr(zee_pre_f32), _i(int(stages)), rect, _i(state['raster_w']),
+                                                     _i(state['raster_n']), _stream()),
                     'kbe_render_frame')
         return frame
 
@@ -215,7 +227,8 @@ class HipKernels:
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
-                                              ctypes.c_void_p(host_out.data_ptr()), _stream(), copy_stream), 'kbe_render_video')
+                                              ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
+                                              _stream(), copy_stream), 'kbe_render_video')
         return host_out
 
     def zkeys_clear(self, zkeys):

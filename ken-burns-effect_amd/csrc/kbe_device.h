@@ -34,6 +34,7 @@ __device__ __forceinline__ float zkey_decode(uint32_t k)
 // ---------------------------------------------------------------------------------------
 struct Camera {
     float focal_f;      // (float) dblFocal             common.py:447 make_float3(0, 0, F)
+    float fb_f;         // (float) fb, for the division-free fast path of dblError
     double fb;          // dblFocal * dblBaseline       common.py:470
     double half_w;      // 0.5 * W                      common.py:467
     double half_h;      // 0.5 * H                      common.py:468
@@ -92,6 +93,21 @@ __device__ __forceinline__ void project_weights(float ox, float oy, Proj& p)
 __device__ __forceinline__ float project_err(const Camera& cam, float pz)
 {
     return (float) (1000000.0 - (cam.fb / ((double) pz + 0.0000001)));
+}
+
+// The same value WITHOUT the fp64 division on the common path.  With Q = F*B / (z + 1e-7) the result is
+// fl32(1e6 - Q); for 1e6 - Q in [2^19, 2^20) that is (16e6 - round(16 Q)) / 16.  An fp32 estimate
+// q = fb_f * rcp(z) is within 4e-7 relative of Q (v_rcp_f32 1 ulp, one multiply, the rounding of fb_f, and
+// the dropped 1e-7 for z >= 16), so round(16 Q) is known for sure unless 16 q sits within that error of a
+// half-integer; those rare lanes (< 0.1 %) take the exact fp64 route.  Bit-identical to project_err
+// (tests/test_hip_parity.py::test_fast_dbl_error_is_exact sweeps the rounding boundaries).
+__device__ __forceinline__ float project_err_fast(const Camera& cam, float pz)
+{
+    const float s = 16.0f * (cam.fb_f * __builtin_amdgcn_rcpf(pz));
+    const float n = rintf(s);
+    const bool sure = (pz >= 16.0f) & (s > 0.0f) & (s < 7600000.0f) & (fabsf(s - n) < 0.5f - (s * 4.0e-7f + 2.0e-6f));
+    if (__builtin_expect(!sure, 0)) return project_err(cam, pz);
+    return (float) (16000000 - (int) n) * 0.0625f;
 }
 
 // common.py:447-484 (== :599-636) in one piece

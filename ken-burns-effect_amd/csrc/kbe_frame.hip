@@ -125,6 +125,7 @@ __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int 
 struct ProjectArgs {
     const float* points;    // [3,N]
     int N;
+    int raster_w, raster_n; // hint: the first raster_n points are a row-major raster raster_w wide (0: unknown)
     Camera cam;
     uint32_t* zkeys;
     int* tile_count;
@@ -152,7 +153,12 @@ __device__ __forceinline__ TileGroup group_by_tile(bool want, int tile)
     return g;
 }
 
-constexpr int PTS_PER_THREAD = 4;           // independent points per lane: their atomics overlap in flight
+#ifndef KBE_PTS_PER_THREAD
+#define KBE_PTS_PER_THREAD 1
+#endif
+constexpr int PTS_PER_THREAD = KBE_PTS_PER_THREAD;      // independent points per lane: their atomics overlap in flight
+constexpr int UNIT = 64 * PTS_PER_THREAD;               // points per wave unit
+constexpr int PATCH_ROWS = 2 * PTS_PER_THREAD;          // a raster unit is a 32 x PATCH_ROWS patch
 
 // One wave handles 256 consecutive points; lane l takes l, l+64, l+128, l+192 (coalesced loads).
 // The bucket appends are organised so that ALL counter atomics of a wave are in flight together
@@ -166,12 +172,28 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
     const Camera& cam = a.cam;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.hole_count = 0;
     const size_t N = (size_t) a.N;
-    for (long w0 = (long) wave * 64 * PTS_PER_THREAD; w0 < (long) a.N; w0 += (long) n_waves * 64 * PTS_PER_THREAD) {
+    // Work units of UNIT points per wave.  Where the cloud is known to start with a row-major raster (the image
+    // pixels), a unit is a 32 x PATCH_ROWS patch of it rather than UNIT consecutive pixels of a row: its points
+    // then fall into one or two target tiles, and a bucket's records reference neighbouring points.  Pure speed
+    // hint.  (One point per lane: 4 per lane needed 98-118 VGPRs, halved the occupancy of this latency-bound
+    // kernel and doubled its time, 13.8 vs 6.5 us.)
+    const int patches_x = (a.raster_w > 0 && a.raster_w % 32 == 0) ? a.raster_w / 32 : 0;
+    const int patch_rows = patches_x ? (a.raster_n / a.raster_w) / PATCH_ROWS : 0;
+    const long n_patches = (long) patches_x * patch_rows;
+    const long lin0 = n_patches * UNIT;                         // points before lin0 are covered by patches
+    const long n_units = n_patches + ((long) a.N - lin0 + UNIT - 1) / UNIT;
+    for (long unit = wave; unit < n_units; unit += n_waves) {
         float4 rec[PTS_PER_THREAD];
         bool ok[PTS_PER_THREAD], spx[PTS_PER_THREAD], spy[PTS_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < PTS_PER_THREAD; j++) {
-            const long i = w0 + lane + 64 * j;
+            long i;
+            if (unit < n_patches) {
+                const int pyb = (int) (unit / patches_x), pxb = (int) (unit - (long) pyb * patches_x);
+                i = ((long) pyb * PATCH_ROWS + (lane >> 5) + 2 * j) * a.raster_w + pxb * 32 + (lane & 31);
+            } else {
+                i = lin0 + (unit - n_patches) * UNIT + lane + 64 * j;
+            }
             ok[j] = i < (long) a.N;
             float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f, err = 0.0f;
             if (ok[j]) {
@@ -186,7 +208,11 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
                 ok[j] = (p.nwx + 1 >= 0) & (p.nwx < cam.W) & (p.nwy + 1 >= 0) & (p.nwy < cam.H);   // touches the image at all
             }
             if (ok[j]) {
+#if defined(KBE_PROBE_EXACT_ERR)
                 err = project_err(cam, z);
+#else
+                err = project_err_fast(cam, z);
+#endif
                 const int k = winner_corner(p);                 // common.py:486-506
                 if (k >= 0) {
                     const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
@@ -199,9 +225,15 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
             spx[j] = ok[j] && ((p.nwx + 1) % TW == 0);
             spy[j] = ok[j] && ((p.nwy + 1) % TH == 0);
         }
-        // corner c of the 2x2 tile neighbourhood: (c & 1) east, (c >> 1) south
+        // The point goes to the bucket of its north-west corner's tile (c = 0) and, when that corner sits in a
+        // tile's last column / row, to the east / south / south-east neighbour (c = 1, 2, 3).  The lanes of a
+        // wave share very few target tiles, so they are grouped and one leader per tile bumps the counter for
+        // all of them.  Two rounds -- {own, east}, then {south, south-east} only for the few waves that need
+        // it -- keep the live state at 2 groups per point: holding all four at once cost 118 VGPRs, halved the
+        // occupancy of this latency-bound kernel and doubled its time.  Within a round every counter atomic
+        // is issued before any result is consumed.
 #pragma unroll
-        for (int half = 0; half < 2; half++) {                  // c = 0,1 (always), then c = 2,3 (only rows that spill south)
+        for (int half = 0; half < 2; half++) {
             if (half == 1) {
                 bool any = false;
 #pragma unroll
@@ -212,26 +244,28 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
             int tgt[PTS_PER_THREAD][2], base[PTS_PER_THREAD][2];
             bool want[PTS_PER_THREAD][2];
 #pragma unroll
-            for (int j = 0; j < PTS_PER_THREAD; j++)
+            for (int j = 0; j < PTS_PER_THREAD; j++) {
+                const int nwx = (int) floorf(rec[j].x), nwy = (int) floorf(rec[j].y);      // >= -1 when ok
+                const int tx0 = nwx >= 0 ? nwx / TW : -1, ty0 = (nwy >= 0 ? nwy / TH : -1) + half;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const int c = half * 2 + e;
-                    const int nwx = (int) floorf(rec[j].x), nwy = (int) floorf(rec[j].y);      // >= -1 when ok
-                    const int tx0 = nwx >= 0 ? nwx / TW : -1, ty0 = nwy >= 0 ? nwy / TH : -1;
-                    const int tx = tx0 + (c & 1), ty = ty0 + (c >> 1);
-                    want[j][e] = ok[j] && ((c & 1) == 0 || spx[j]) && ((c >> 1) == 0 || spy[j]) && tx >= 0 && ty >= 0 &&
-                                 tx < a.tiles_x && ty < a.tiles_y;
-                    tgt[j][e] = ty * a.tiles_x + tx;
+                    const int tx = tx0 + e;
+                    want[j][e] = ok[j] && (e == 0 || spx[j]) && (half == 0 || spy[j]) && tx >= 0 && ty0 >= 0 && tx < a.tiles_x &&
+                                 ty0 < a.tiles_y;
+#if defined(KBE_PROBE_NO_SPILLS)
+                    if (half + e > 0) want[j][e] = false;
+#endif
+                    tgt[j][e] = ty0 * a.tiles_x + tx;
                     grp[j][e] = group_by_tile(want[j][e], tgt[j][e]);
                     base[j][e] = 0;
                 }
-            // all counter atomics of this wave, back to back
+            }
 #pragma unroll
             for (int j = 0; j < PTS_PER_THREAD; j++)
 #pragma unroll
                 for (int e = 0; e < 2; e++)
-                    if (want[j][e] && lane == grp[j][e].leader) base[j][e] = atomicAdd(&a.tile_count[tgt[j][e] * CNT_STRIDE], __popcll(grp[j][e].same));
-            // consume: every lane learns its slot from its group's leader and stores its record (coalesced within a group)
+                    if (want[j][e] && lane == grp[j][e].leader)
+                        base[j][e] = atomicAdd(&a.tile_count[tgt[j][e] * CNT_STRIDE], __popcll(grp[j][e].same));
 #pragma unroll
             for (int j = 0; j < PTS_PER_THREAD; j++)
 #pragma unroll
@@ -299,6 +333,9 @@ __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float 
 
 __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 {
+#if defined(KBE_PROBE_NO_RGBD)
+    return make_float4(0.5f, 0.25f, 0.125f, 700.0f + (float) (id & 1));
+#endif
     const float* I = a.image + id;
     const size_t N = (size_t) a.N;
     return make_float4(I[0], I[N], I[2 * N], a.depth_in[id]);
@@ -320,24 +357,46 @@ __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int 
         const bool exact = plus_one_is_exact(zee);                          // then zee + 1.0f IS the double sum
         const float zlimf = zee + 1.0f;
         const double zlim = (double) zee + 1.0;
+        const int X = x0 + lx, Y = y0 + ly;
+        // corner k of a point is this pixel  <=>  its north-west corner is (X - (k & 1), Y - (k >> 1)).  That pins
+        // floor(ox), floor(oy), so the bilinear weight of common.py:481-484 needs two subtractions and one
+        // product: (ex - ox | ox - fx) * (ey - oy | oy - fy) with fx = (float) nwx, ex = (float) (nwx + 1).
+        auto add = [&](int k, const float4& r, const float4& c) {
+            if (exact ? (r.z <= zlimf) : ((double) r.z <= zlim)) {          // :639 (the fp64 side only exists for odd z)
+                const float cxf = (float) (X - (k & 1) + ((k & 1) ? 0 : 1));     // k&1 ? fx : ex
+                const float cyf = (float) (Y - (k >> 1) + ((k >> 1) ? 0 : 1));   // k>>1 ? fy : ey
+                const float wx = (k & 1) ? (r.x - cxf) : (cxf - r.x);
+                const float wy = (k >> 1) ? (r.y - cyf) : (cyf - r.y);
+                const float w = wx * wy;
+                acc[m][0] += c.x * w;                                       // :641 product rounded, then added
+                acc[m][1] += c.y * w;
+                acc[m][2] += c.z * w;
+                acc[m][3] += c.w * w;
+                acc[m][4] += w;                                             // the `ones` channel (:429)
+            }
+        };
+        // LDS latency, not instruction count, bounds this walk (a cheaper weight changed nothing): the four bin
+        // heads are read together, then the four first records and colours together; only second and later
+        // records of a bin (rare: about one point lands on a pixel) are chased one by one.
+        int idx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) idx[k] = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
+        float4 r[4], c[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // corner k of a point is this pixel  <=>  its north-west corner is (lx - (k & 1), ly - (k >> 1))
-            int idx = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
-            while (idx >= 0) {
-                const float4 r = L.rec[idx];
-                if (exact ? (r.z <= zlimf) : ((double) r.z <= zlim)) {      // :639 (the fp64 side only exists for odd z)
-                    Proj pr;
-                    project_weights(r.x, r.y, pr);
-                    const float w = pr.w[k];
-                    const float4 c = L.rgbd[idx];
-                    acc[m][0] += c.x * w;                                   // :641 product rounded, then added
-                    acc[m][1] += c.y * w;
-                    acc[m][2] += c.z * w;
-                    acc[m][3] += c.w * w;
-                    acc[m][4] += w;                                         // the `ones` channel (:429)
-                }
-                idx = __float_as_int(r.w);
+            const int j = idx[k] >= 0 ? idx[k] : 0;
+            r[k] = L.rec[j];
+            c[k] = L.rgbd[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (idx[k] < 0) continue;
+            add(k, r[k], c[k]);
+            int nxt = __float_as_int(r[k].w);
+            while (nxt >= 0) {
+                const float4 rr = L.rec[nxt];
+                add(k, rr, L.rgbd[nxt]);
+                nxt = __float_as_int(rr.w);
             }
         }
     }
@@ -615,6 +674,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     // where most of the image is empty border, cheap.
     __shared__ int s_bb[4][4];
     int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
+    if ((int) (blockIdx.x * (blockDim.x >> 5)) >= n) return;    // no hole for this block (whole block: uniform)
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
         const int4 bb = bbox[t];
         bx0 = min(bx0, bb.x); by0 = min(by0, bb.y); bx1 = max(bx1, bb.z); by1 = max(by1, bb.w);
@@ -718,7 +778,7 @@ int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
 int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
                             double baseline, const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
                             float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect,
-                            kbe_stream_t stream)
+                            int raster_w, int raster_n, kbe_stream_t stream)
 {
     KBE_REQUIRE(scratch && frame_u8 && N >= 0 && W > 0 && H > 0 && (size_t) W * H < (1u << 31) && ((uintptr_t) scratch & 15) == 0,
                 "kbe_render_frame: bad arguments");
@@ -734,7 +794,9 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         ProjectArgs p;
         p.points = points; p.N = N; p.cam = cam; p.zkeys = sc.zkeys; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
         p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
-        const unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) : 1;
+        p.raster_w = 0; p.raster_n = 0;
+        if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
+        const unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) + 2 : 1;
         hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, p);
         if ((rc = launched("kbe_render_frame/project"))) return rc;
     }
@@ -765,12 +827,13 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
 {
     return kbe_render_frame_stages(points, image, depth, N, W, H, focal, baseline, shift3, scratch, frame_u8, render_f32,
                                    existing_f32, zee_f32, zee_pre_f32, KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL,
-                                   nullptr, stream);
+                                   nullptr, 0, 0, stream);
 }
 
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
-                     uint8_t* stage, int batch, uint8_t* host_out, kbe_stream_t stream, kbe_stream_t copy_stream)
+                     uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
+                     kbe_stream_t copy_stream)
 {
     KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 0, "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
@@ -808,7 +871,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             uint8_t* out = host_out + (size_t) i * fb;
             rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
                                          crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, stream);
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
+                                         stream);
             if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
         }
         if (overlap) for (int b = 0; b < 2; b++) { (void) hipEventDestroy(rendered[b]); (void) hipEventDestroy(copied[b]); }
@@ -823,7 +887,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             uint8_t* out = ring[half] + (size_t) k * fb;
             rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
                                          crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, stream);
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
+                                         stream);
             if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
         }
         if (rc != KBE_OK) break;

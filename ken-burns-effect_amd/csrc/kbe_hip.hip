@@ -35,6 +35,16 @@ __global__ void k_zkeys_decode(const uint32_t* keys, size_t n, float* zee)
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) zee[i] = zkey_decode(keys[i]);
 }
 
+// self-test: dblError of each z through the exact fp64 expression and through the fast path
+__global__ void k_selftest_err(const float* __restrict__ z, size_t n, Camera cam, float* __restrict__ fast, float* __restrict__ exact)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fast[i] = project_err_fast(cam, z[i]);
+        exact[i] = project_err(cam, z[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel_pointrender_updateZee (common.py:435-507)
 // ---------------------------------------------------------------------------------------
@@ -432,6 +442,14 @@ int kbe_device_info(int device, char* name, int cap)
     if (e != hipSuccess) return fail(KBE_E_DEVICE, "hipGetDeviceProperties", e);
     if (name && cap > 0) { strncpy(name, prop.gcnArchName, (size_t) cap - 1); name[cap - 1] = 0; }
     return prop.multiProcessorCount;
+}
+
+int kbe_selftest_err(const float* z, size_t n, double focal, double baseline, float* fast, float* exact, kbe_stream_t stream)
+{
+    KBE_REQUIRE(z && fast && exact && n > 0, "kbe_selftest_err: bad arguments");
+    const Camera cam = make_camera(1, 1, focal, baseline, nullptr);
+    hipLaunchKernelGGL(k_selftest_err, dim3(2048), dim3(kBlock), 0, (hipStream_t) stream, z, n, cam, fast, exact);
+    return launched("kbe_selftest_err");
 }
 
 int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream)

@@ -27,6 +27,7 @@ inline Camera make_camera(int W, int H, double focal, double baseline, const flo
     Camera c;
     c.focal_f = (float) focal;
     c.fb = focal * baseline;
+    c.fb_f = (float) c.fb;
     c.half_w = 0.5 * (double) W;
     c.half_h = 0.5 * (double) H;
     c.W = W;

@@ -94,6 +94,29 @@ def test_render_pointcloud_whole(K, oracle, case):
     assert (np.abs(c(render) - r0.numpy()) <= 2e-5 * scale).all()
 
 
+@pytest.mark.parametrize('focal,baseline', [(512.0, 120), (409.6, 120), (153.60000000000002, 40.0), (192.0, 120)])
+def test_fast_dbl_error_is_exact(K, focal, baseline):
+    """The division-free dblError of the frame loop against the literal fp64 expression (on the GPU and in
+    numpy): random depths, tiny / huge depths, and depths placed right on the fp32 rounding boundaries of
+    1e6 - F*B/z (where the fast path must notice that it cannot decide and fall back)."""
+    rng = np.random.default_rng(11)
+    fb = focal * baseline
+    zs = [rng.uniform(16.0, 60000.0, 4_000_000), rng.uniform(0.001, 20.0, 200_000), 10.0 ** rng.uniform(-3, 7, 200_000)]
+    # boundaries: Q = (n + 0.5) / 16  <=>  z = fb / Q - 1e-7; take the floats around each
+    n = rng.integers(1, 16 * 4000, 300_000).astype(np.float64)
+    zb = (fb / ((n + 0.5) / 16.0) - 1e-7).astype(np.float32)
+    for k in range(-3, 4):
+        z = zb.copy()
+        for _ in range(abs(k)):
+            z = np.nextafter(z, np.float32(np.inf if k > 0 else -np.inf))
+        zs.append(z)
+    z = np.concatenate([np.asarray(v, dtype=np.float32) for v in zs])
+    fast, exact = K.selftest_err(torch.from_numpy(z).cuda(), focal, baseline)
+    want = (1000000.0 - fb / (z.astype(np.float64) + 0.0000001)).astype(np.float32)
+    assert_bits_equal(c(exact), want, 'fp64 expression on the GPU vs numpy')
+    assert_bits_equal(c(fast), want, 'fast path')
+
+
 def test_shift_fused_equals_shift_then_render(K):
     z = load_golden('render_f512')
     W, H, F, Bl = int(z['W']), int(z['H']), float(z['focal']), _baseline(z)

@@ -36,7 +36,7 @@ def main():
         res = {}
         for ci in (0, 2, 4):
             cw, ch = common.crop_size(settings)
-            kt = bench.time_kernels(oc, [cams[ci]], reps=20, fill_rect=common.crop_window(size, size, cw, ch))
+            kt = bench.time_kernels(oc, [cams[ci]], reps=int(os.environ.get('REPS', '60')), fill_rect=common.crop_window(size, size, cw, ch))
             res[ci] = kt
         if 'KBE_PROBE_TIMING' in flags:
             K = _native.kernels()
@@ -50,7 +50,7 @@ def main():
             names = ['loads->lds', 'barrier1', 'degrid', 'insert', 'barrier2', 'gather', 'barrier3', 'resolve', 'barrier4', 'store']
             print('   phases (cycles, mean over tiles): ' + ' '.join('%s=%.0f' % (n, v) for n, v in zip(names, d.mean(0))), ' total=%.0f' % (t[:, 10] - t[:, 0]).mean(), flush=True)
         print('variant %-50s' % (flags or '(default)'), ' | '.join(
-            'step%d proj %.1f tiles %.1f fill %.1f frame %.1f' % (ci, r['project+reset'] * 1e6, r['tiles'] * 1e6, r['fill'] * 1e6, r['frame'] * 1e6) for ci, r in res.items()),
+            'step%d reset %.1f proj %.1f tiles %.1f fill %.1f frame %.1f' % (ci, r['reset'] * 1e6, (r['project+reset'] - r['reset']) * 1e6, r['tiles'] * 1e6, r['fill'] * 1e6, r['frame'] * 1e6) for ci, r in res.items()),
             flush=True)
 
 
