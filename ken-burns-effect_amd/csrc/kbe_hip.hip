@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(CR_TW * CR_TH) k_crop_resize_u8(const uint8_t*
                                                                   uint8_t* __restrict__ out)
 {
     __shared__ uint32_t s_raw[CR_ROWS][CR_ROW_BYTES / 4 + 1];
+    __shared__ uint32_t s_out[CR_TH][CR_TW * 3 / 4];            // finished pixels leave as dwords (byte stores are slow)
     const int tid = threadIdx.x;
     const int dx = blockIdx.x * CR_TW + (tid & (CR_TW - 1)), dy = blockIdx.y * CR_TH + (tid / CR_TW);
     // getRectSubPix: top-left sample position and 16-bit fixed-point bilinear weights
@@ -234,43 +235,78 @@ __global__ void __launch_bounds__(CR_TW * CR_TH) k_crop_resize_u8(const uint8_t*
     const int ry0 = min(max(ipy + py_lo, 0), H - 1), ry1 = min(max(ipy + py_hi, 0), H - 1);
     const int n_rows = ry1 - ry0 + 1;                                   // <= CR_ROWS
     const size_t frame_bytes = (size_t) W * H * 3;
-    for (int r = 0; r < n_rows; r++) {
-        const size_t b0 = ((size_t) (ry0 + r) * W + rx0) * 3, b1 = ((size_t) (ry0 + r) * W + rx1) * 3 + 3;
-        const size_t a0 = b0 & ~(size_t) 3;
-        const int n_dw = (int) ((b1 - a0 + 3) >> 2);                    // <= CR_ROW_BYTES / 4 + 1
-        for (int k = tid; k < n_dw; k += CR_TW * CR_TH) {
-            const size_t off = a0 + 4 * (size_t) k;
-            uint32_t v = 0;
-            if (off + 4 <= frame_bytes) v = *(const uint32_t*) (img + off);
-            else for (int t = 0; t < 4; t++) if (off + t < frame_bytes) v |= (uint32_t) img[off + t] << (8 * t);
-            s_raw[r][k] = v;
+    // every row of the staging rectangle is at most CR_ROW_BYTES / 4 + 1 dwords: one dword per thread and row.
+    // All loads are issued before the first LDS store (a load-store-load-store loop serialised 7 memory
+    // latencies and made this trivial kernel take 16 us).
+    uint32_t stage[CR_ROWS];
+#pragma unroll
+    for (int r = 0; r < CR_ROWS; r++) {
+        stage[r] = 0;
+        if (r < n_rows) {
+            const size_t b0 = ((size_t) (ry0 + r) * W + rx0) * 3, b1 = ((size_t) (ry0 + r) * W + rx1) * 3 + 3;
+            const size_t a0 = b0 & ~(size_t) 3;
+            const int n_dw = (int) ((b1 - a0 + 3) >> 2);                // <= CR_ROW_BYTES / 4 + 1
+            if (tid < n_dw) {
+                const size_t off = a0 + 4 * (size_t) tid;
+                if (off + 4 <= frame_bytes) stage[r] = *(const uint32_t*) (img + off);
+                else for (int t = 0; t < 4; t++) if (off + t < frame_bytes) stage[r] |= (uint32_t) img[off + t] << (8 * t);
+            }
         }
     }
+#pragma unroll
+    for (int r = 0; r < CR_ROWS; r++)
+        if (r < n_rows && tid <= CR_ROW_BYTES / 4) s_raw[r][tid] = stage[r];
     __syncthreads();
-    if (dx >= W || dy >= H) return;
-    auto raw_at = [&](int x, int y, int c) -> int {                     // replicate border, as OpenCV does
-        const int xx = min(max(x, 0), W - 1), yy = min(max(y, 0), H - 1);
-        const size_t a0 = (((size_t) yy * W + rx0) * 3) & ~(size_t) 3;
-        const int byte = (int) (((size_t) yy * W + xx) * 3 + c - a0);
-        return ((const uint8_t*) s_raw[yy - ry0])[byte];
-    };
-    auto patch_at = [&](int x, int y, int c) -> int {
-        const int v = raw_at(ipx + x, ipy + y, c) * a11 + raw_at(ipx + x + 1, ipy + y, c) * a12 +
-                      raw_at(ipx + x, ipy + y + 1, c) * a21 + raw_at(ipx + x + 1, ipy + y + 1, c) * a22;
-        return (v + (1 << 15)) >> 16;
-    };
-    int sx, sx1, ax0, ax1, sy, sy1, by0, by1;
+    const bool live = dx < W && dy < H;
+    int sx = 0, sx1 = 0, ax0 = 0, ax1 = 0, sy = 0, sy1 = 0, by0 = 0, by1 = 0;
+    if (live) {
     resize_coeff(dx, sx_scale, cw, sx, sx1, ax0, ax1);
     resize_coeff(dy, sy_scale, ch_, sy, sy1, by0, by1);
+    }
+    // the 4 x 4 raw taps of this pixel (2 resize taps x 2 sub-pixel taps per axis), as LDS byte offsets of
+    // channel 0: computed once, replicate border as OpenCV does
+    int xo[4], yo[4];
+    const int px_[4] = { ipx + sx, ipx + sx + 1, ipx + sx1, ipx + sx1 + 1 };
+    const int py_[4] = { ipy + sy, ipy + sy + 1, ipy + sy1, ipy + sy1 + 1 };
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        xo[t] = (min(max(px_[t], 0), W - 1) - rx0) * 3;
+        const int yy = min(max(py_[t], 0), H - 1);
+        // row yy starts at byte ((yy * W + rx0) * 3) & 3 of its staging row
+        yo[t] = (yy - ry0) * (int) sizeof(s_raw[0]) + (int) ((((size_t) yy * W + rx0) * 3) & 3);
+        if (!live) { xo[t] = 0; yo[t] = 0; }                            // threads past the image edge only keep the barriers company
+    }
+    const uint8_t* raw = (const uint8_t*) s_raw;
     uint8_t px[3];
+#pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int r0 = patch_at(sx, sy, c) * ax0 + patch_at(sx1, sy, c) * ax1;         // horizontal pass, x2048
-        const int r1 = patch_at(sx, sy1, c) * ax0 + patch_at(sx1, sy1, c) * ax1;
-        const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;   // vertical pass
+        int p[2][2];                                                    // patch pixels (sy|sy1, sx|sx1), rounded as cast_8u does
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = raw[yo[2 * v] + xo[2 * u] + c] * a11 + raw[yo[2 * v] + xo[2 * u + 1] + c] * a12 +
+                              raw[yo[2 * v + 1] + xo[2 * u] + c] * a21 + raw[yo[2 * v + 1] + xo[2 * u + 1] + c] * a22;
+                p[v][u] = (t + (1 << 15)) >> 16;
+            }
+        const int r0 = p[0][0] * ax0 + p[0][1] * ax1, r1 = p[1][0] * ax0 + p[1][1] * ax1;     // horizontal pass, x2048
+        const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;        // vertical pass
         px[c] = (uint8_t) min(max(v, 0), 255);
     }
-    const size_t o = ((size_t) dy * W + dx) * 3;
-    out[o] = px[0]; out[o + 1] = px[1]; out[o + 2] = px[2];
+    uint8_t* so = (uint8_t*) s_out[tid / CR_TW] + (tid & (CR_TW - 1)) * 3;
+    so[0] = px[0]; so[1] = px[1]; so[2] = px[2];
+    __syncthreads();
+    const int bx = blockIdx.x * CR_TW, byy = blockIdx.y * CR_TH;
+    if ((W & 3) == 0 && bx + CR_TW <= W) {
+        constexpr int DW = CR_TW * 3 / 4;
+        for (int i = tid; i < CR_TH * DW; i += CR_TW * CR_TH) {
+            const int r = i / DW, k = i - r * DW;
+            if (byy + r < H) ((uint32_t*) (out + ((size_t) (byy + r) * W + bx) * 3))[k] = s_out[r][k];
+        }
+    } else if (live) {
+        const size_t o = ((size_t) dy * W + dx) * 3;
+        out[o] = px[0]; out[o + 1] = px[1]; out[o + 2] = px[2];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
