@@ -208,12 +208,17 @@ class HipKernels:
 
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=16):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
-        tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised)."""
+        tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
+        also be a DEVICE tensor: the frames then stay in HBM (the last kernel of every frame stores straight into
+        it, no transfer)."""
         n, W, H = len(cameras), state['W'], state['H']
         dev = state['points'].device
         if host_out is None:
             host_out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
+        assert host_out.dtype == torch.uint8 and host_out.is_contiguous() and host_out.numel() >= n * H * W * 3
         batch = max(0, int(batch))      # 0 = zero-copy (kernels store straight into the pinned host buffer)
+        if host_out.is_cuda:
+            batch, overlap = 0, False
         if state.get('stage_batch') != batch:
             state['stage'] = torch.empty((2 * batch + 1) * H * W * 3, dtype=torch.uint8, device=dev)
             state['stage_batch'] = batch

@@ -293,15 +293,19 @@ def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_o
     pinned host buffer and the host synchronises once.  ``crop`` = (w, h) applies the
     device-side equivalent of cv2.getRectSubPix + cv2.resize (common.py:256-257); None
     returns the un-cropped frames.  Returns uint8 [n,H,W,3] (numpy, or a device tensor when
-    ``keep_on_device``).  ``host_out``: optional pre-allocated pinned uint8 [n,H,W,3] tensor to land the
-    frames in (otherwise a fresh one is allocated per call)."""
+    ``keep_on_device``).  ``host_out``: optional pre-allocated uint8 [n,H,W,3] tensor to land the frames in
+    (pinned host memory, or device memory with ``keep_on_device``; otherwise a fresh one is allocated per call)."""
     K = _K()
     W, H = objectCommon['intWidth'], objectCommon['intHeight']
     state = _prepared_cloud(K, objectCommon)
     device = objectCommon['tensorInpaPoints'].device
     n = len(cameras)
-    if hasattr(K, 'render_video') and not keep_on_device:
+    if hasattr(K, 'render_video'):
         # the native loop: kernels + async copies enqueued from C, copies overlapped on a second stream
+        # (keep_on_device: the frames stay in HBM, e.g. for a device-side encoder or the gather of the sharded path)
+        if keep_on_device:
+            out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device) if host_out is None else host_out
+            return K.render_video(state, cameras, objectCommon['dblBaseline'], crop, host_out=out)[:n]
         out = K.render_video(state, cameras, objectCommon['dblBaseline'], crop, host_out=host_out, overlap=overlap, batch=batch)
         torch.cuda.current_stream().synchronize()
         return out.numpy()

@@ -453,8 +453,12 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     KBE_TICK(1);
     __syncthreads();
     KBE_TICK(2);
-    // the records have landed by now: fetch their colours; these loads fly while the degrid computes
+    // the records have landed by now: fetch their colours; these loads fly while the degrid computes.
+    // The explicit wait tells the compiler so: without it its wait-count bookkeeping, merging the taken and
+    // not-taken sides of the `i < n0` branches below, re-waited for the RECORD loads after the colour loads
+    // were issued -- i.e. for the colour loads themselves, in front of the degrid instead of behind it.
     const int n0 = bucketed ? min(REC_CAP, count) : 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = tid + u * TILE_THREADS;

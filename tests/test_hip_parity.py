@@ -309,10 +309,15 @@ def test_native_frame_loop_equals_per_frame_calls(K):
     cams = common.frame_cameras(settings, oc)
     crop = common.crop_size(settings)
     a = common.render_frames(cams, oc, crop)                               # native loop, pinned host memory
-    b = common.render_frames(cams, oc, crop, keep_on_device=True).cpu().numpy()      # python loop
-    assert a.shape == b.shape == (7, 160, 224, 3)
-    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    state = common._prepared_cloud(K, oc)
+    rect = common.crop_window(224, 160, crop[0], crop[1])
+    b = np.stack([K.crop_resize_u8(K.render_frame(state, sh, f, oc['dblBaseline'], fill_rect=rect), crop[0], crop[1]).cpu().numpy()
+                  for f, sh in cams])                                      # one C call per kernel sequence
+    dev = common.render_frames(cams, oc, crop, keep_on_device=True)        # native loop, frames left in HBM
+    assert dev.is_cuda and a.shape == b.shape == tuple(dev.shape) == (7, 160, 224, 3)
+    for other in (b, dev.cpu().numpy()):
+        d = np.abs(a.astype(np.int32) - other.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
     c2 = common.render_frames(cams, oc, None)
     assert c2.shape == (7, 160, 224, 3)
 

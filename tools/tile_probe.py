@@ -11,6 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CSRC = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
@@ -48,6 +49,28 @@ def main():
             t = dbg.view(torch.int64).reshape(-1)[:(size // 32) ** 2 * 16].reshape(-1, 16).cpu().numpy().astype('float64')
             d = t[:, 1:11] - t[:, 0:10]
             names = ['loads->lds', 'barrier1', 'degrid', 'insert', 'barrier2', 'gather', 'barrier3', 'resolve', 'barrier4', 'store']
+            span = t[:, 10].max() - t[:, 0].min()
+            starts = np.sort(t[:, 0] - t[:, 0].min())
+            print('   span=%.0f cycles; WG start quartiles %s; WG duration min/med/max %.0f %.0f %.0f' % (
+                span, np.percentile(starts, [0, 25, 50, 75, 100]).round().tolist(),
+                (t[:, 10] - t[:, 0]).min(), np.median(t[:, 10] - t[:, 0]), (t[:, 10] - t[:, 0]).max()), flush=True)
+            nt = t.shape[0]
+            xcd = np.arange(nt) & 7
+            spans = [t[xcd == k, 10].max() - t[xcd == k, 0].min() for k in range(8)]
+            print('   per-XCD span (cycles):', [int(v) for v in spans], flush=True)
+            cnt = state['scratch'].view(torch.int32)[size * size:size * size + nt * 32:32].cpu().numpy()
+            b = np.arange(nt); q, r = nt >> 3, nt & 7
+            tile_of = np.where((b & 7) < r, (b & 7) * (q + 1), r * (q + 1) + ((b & 7) - r) * q) + (b >> 3)
+            c = cnt[tile_of]; dur = t[:, 10] - t[:, 0]
+            for lo, hi in ((0, 600), (600, 900), (900, 1100), (1100, 1300), (1300, 1536), (1536, 3072), (3072, 1 << 30)):
+                m = (c >= lo) & (c < hi)
+                if m.any():
+                    print('   count [%d,%d): %d tiles, duration mean %.0f max %.0f; gather %.0f insert %.0f degrid %.0f' % (
+                        lo, hi, m.sum(), dur[m].mean(), dur[m].max(), d[m, 5].mean(), d[m, 3].mean(), d[m, 2].mean()), flush=True)
+            k0 = xcd == 0
+            st = t[k0, 0] - t[k0, 0].min()
+            print('   XCD0 starts:', np.sort(st).astype(int)[::8].tolist(), flush=True)
+            print('   XCD0 ends  :', np.sort(t[k0, 10] - t[k0, 0].min()).astype(int)[::8].tolist(), flush=True)
             print('   phases (cycles, mean over tiles): ' + ' '.join('%s=%.0f' % (n, v) for n, v in zip(names, d.mean(0))), ' total=%.0f' % (t[:, 10] - t[:, 0]).mean(), flush=True)
         print('variant %-50s' % (flags or '(default)'), ' | '.join(
             'step%d reset %.1f proj %.1f tiles %.1f fill %.1f frame %.1f' % (ci, r['reset'] * 1e6, (r['project+reset'] - r['reset']) * 1e6, r['tiles'] * 1e6, r['fill'] * 1e6, r['frame'] * 1e6) for ci, r in res.items()),
