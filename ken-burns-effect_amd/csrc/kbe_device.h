@@ -178,6 +178,31 @@ __device__ __forceinline__ float degrid_pixel(int x, int y, int W, int H, At at)
     return count > 0 ? fminf(c, sum / (float) count) : c;
 }
 
+// The same pixel when all nine values lie in [2^19, 1e6] (tested once per tile by the caller): the `+ 1.0`
+// comparisons are exact in fp32 (plus_one_is_exact), a neighbour outside the image reads as the empty value 1e6
+// and can then never pass `c >= 1e6 + 1`, which is how the reference's bounds test (:548-553) drops its pair,
+// and the mean needs no division: with y = RN(1 / (2n)), q = s y, q' = fma(fma(-2n, q, s), y, q) IS the
+// correctly rounded s / (2n) (Markstein; checked for every float s in [1, 1.7e7] and n = 1..4 by
+// tests/markstein_check.c).  Branch-free; bit-identical to degrid_pixel.
+__device__ __forceinline__ float degrid_pixel_fast(float c, const float (&a)[4], const float (&d)[4])
+{
+    int n = 0;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool t = (c >= a[k] + 1.0f) & (c >= d[k] + 1.0f);
+        n += t ? 1 : 0;
+        s += t ? a[k] : 0.0f;                                   // s + 0.0f == s: same sum, same order as :559-560
+        s += t ? d[k] : 0.0f;
+    }
+    const float y = n == 3 ? 0.16666667f : (n == 1 ? 0.5f : (n == 2 ? 0.25f : 0.125f));
+    const float q = s * y;
+    const float mean = __builtin_fmaf(__builtin_fmaf(-(float) (2 * n), q, s), y, q);
+    return n > 0 ? fminf(c, mean) : c;
+}
+
+__device__ __forceinline__ bool degrid_fast_ok(float z) { return (z >= 524288.0f) & (z <= 1000000.0f); }
+
 // common.py:255: (x * 255.0).clip(0.0, 255.0).astype(np.uint8)
 __device__ __forceinline__ uint8_t to_u8(float v)
 {

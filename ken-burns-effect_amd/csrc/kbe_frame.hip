@@ -320,6 +320,7 @@ struct TileLds {
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo
     float zee[TH * TW];         // degridded z-buffer
     int nrec;
+    int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code)
 };
 
 // threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
@@ -343,8 +344,15 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 
 // z-tested bilinear accumulation (common.py:586-669) of the records now in LDS, in registers.
 // Everything the walk touches is in LDS (a variant that fetched r, g, b, depth from global memory per
-// (pixel, record) pair spent ~13 us of the launch on those dependent loads; one that issued the loads of
-// all four bins in stages before consuming them was 25 % slower still).
+// (pixel, record) pair spent ~13 us of the launch on those dependent loads).
+// The launch is bound by instruction issue and LDS latency (PMC: the SIMDs issue ~85 % of the time, a wave
+// waits ~46 % of its life), so the walk is branch-free and as parallel as the data allows: the heads of the four
+// bins that can reach a pixel are read together, then one record of EACH bin together, and a record that
+// fails the z test (or a bin that has run out: index -1 reads record 0 as a dummy) contributes with weight 0
+// -- adding c * 0 leaves the accumulator bits unchanged, so the sums are those of the branching loop.  The
+// trip count is the longest of the four lists, not their sum.  FAST: every z of the tile is in the band where
+// `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
+template <bool FAST>
 __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int tid, int x0, int y0,
                                        float (&acc)[PIX_PER_THREAD][5])
 {
@@ -354,51 +362,41 @@ __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int 
         const int ly = q / TW, lx = q - ly * TW;
         if (!inside(x0 + lx, y0 + ly, a.cam.W, a.cam.H)) continue;
         const float zee = L.zee[q];
-        const bool exact = plus_one_is_exact(zee);                          // then zee + 1.0f IS the double sum
+        const bool exact = FAST || plus_one_is_exact(zee);                  // then zee + 1.0f IS the double sum
         const float zlimf = zee + 1.0f;
         const double zlim = (double) zee + 1.0;
-        const int X = x0 + lx, Y = y0 + ly;
+        const float Xf = (float) (x0 + lx), Yf = (float) (y0 + ly);
         // corner k of a point is this pixel  <=>  its north-west corner is (X - (k & 1), Y - (k >> 1)).  That pins
         // floor(ox), floor(oy), so the bilinear weight of common.py:481-484 needs two subtractions and one
         // product: (ex - ox | ox - fx) * (ey - oy | oy - fy) with fx = (float) nwx, ex = (float) (nwx + 1).
-        auto add = [&](int k, const float4& r, const float4& c) {
-            if (exact ? (r.z <= zlimf) : ((double) r.z <= zlim)) {          // :639 (the fp64 side only exists for odd z)
-                const float cxf = (float) (X - (k & 1) + ((k & 1) ? 0 : 1));     // k&1 ? fx : ex
-                const float cyf = (float) (Y - (k >> 1) + ((k >> 1) ? 0 : 1));   // k>>1 ? fy : ey
-                const float wx = (k & 1) ? (r.x - cxf) : (cxf - r.x);
-                const float wy = (k >> 1) ? (r.y - cyf) : (cyf - r.y);
-                const float w = wx * wy;
-                acc[m][0] += c.x * w;                                       // :641 product rounded, then added
-                acc[m][1] += c.y * w;
-                acc[m][2] += c.z * w;
-                acc[m][3] += c.w * w;
-                acc[m][4] += w;                                             // the `ones` channel (:429)
-            }
+        auto add = [&](int k, bool on, const float4& r, const float4& c) {
+            const bool pass = on && (exact ? (r.z <= zlimf) : ((double) r.z <= zlim));    // :639
+            const float wx = (k & 1) ? (r.x - (Xf - 1.0f)) : ((Xf + 1.0f) - r.x);          // k & 1 ? ox - fx : ex - ox
+            const float wy = (k >> 1) ? (r.y - (Yf - 1.0f)) : ((Yf + 1.0f) - r.y);
+            const float w = pass ? wx * wy : 0.0f;
+            acc[m][0] += c.x * w;                                           // :641 product rounded, then added
+            acc[m][1] += c.y * w;
+            acc[m][2] += c.z * w;
+            acc[m][3] += c.w * w;
+            acc[m][4] += w;                                                 // the `ones` channel (:429)
         };
-        // LDS latency, not instruction count, bounds this walk (a cheaper weight changed nothing): the four bin
-        // heads are read together, then the four first records and colours together; only second and later
-        // records of a bin (rare: about one point lands on a pixel) are chased one by one.
-        int idx[4];
+        int nx[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) idx[k] = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
-        float4 r[4], c[4];
+        for (int k = 0; k < 4; k++) nx[k] = L.head[(ly + 1 - (k >> 1)) * BW + (lx + 1 - (k & 1))];
+        do {
+            float4 r[4], c[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = idx[k] >= 0 ? idx[k] : 0;
-            r[k] = L.rec[j];
-            c[k] = L.rgbd[j];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (idx[k] < 0) continue;
-            add(k, r[k], c[k]);
-            int nxt = __float_as_int(r[k].w);
-            while (nxt >= 0) {
-                const float4 rr = L.rec[nxt];
-                add(k, rr, L.rgbd[nxt]);
-                nxt = __float_as_int(rr.w);
+            for (int k = 0; k < 4; k++) {
+                const int j = max(nx[k], 0);
+                r[k] = L.rec[j];
+                c[k] = L.rgbd[j];
             }
-        }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                add(k, nx[k] >= 0, r[k], c[k]);
+                nx[k] = nx[k] >= 0 ? __float_as_int(r[k].w) : -1;
+            }
+        } while ((nx[0] & nx[1] & nx[2] & nx[3]) >= 0);                     // some list goes on
     }
 }
 
@@ -408,11 +406,14 @@ __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int 
 #define KBE_TICK(i) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tiles(TileArgs a)
 {
     __shared__ TileLds L;
 #if defined(KBE_PROBE_TIMING)
-    if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + 0] = (long long) __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && a.render) {
+        ((long long*) a.render)[(size_t) blockIdx.x * 16 + 0] = (long long) __builtin_readcyclecounter();
+        ((long long*) a.render)[(size_t) blockIdx.x * 16 + 11] = (long long) wall_clock64();
+    }
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -421,59 +422,102 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     const int x0 = tx * TW, y0 = ty * TH;
     const int W = a.cam.W, H = a.cam.H;
 
-    // The launch is latency-bound, so every independent global load is issued before anything waits:
-    // the bucket count, then this thread's share of the z-buffer tile, then its share of the first
-    // REC_CAP records and their colours; only then the first barrier.
+    // The launch is latency-bound, so the loads are ordered by what depends on them: the bucket count and this
+    // thread's share of the first REC_CAP records first (the colour fetch needs the point indices in them),
+    // then its share of the z-buffer tile; the colour loads are issued as soon as the records are in and fly
+    // during the z-buffer decode, the first barrier and the degrid.  None of these loads sits under a branch:
+    // the compiler's wait-count bookkeeping is per program point, and a load that MAY have been issued makes
+    // every later wait on an older load a wait for everything (measured: the colour loads were waited for
+    // in front of the degrid instead of behind it).
     const int count = a.tile_count[tile * CNT_STRIDE];
     const bool bucketed = count <= BUCKET_CAP;
     const float4* B = a.buckets + (size_t) tile * BUCKET_STRIDE;
     constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
     constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
-    uint32_t zk[ZPER];
-#pragma unroll
-    for (int u = 0; u < ZPER; u++) {
-        const int i = tid + u * TILE_THREADS;
-        const int py = i / KW, pxl = i - py * KW;
-        const int x = x0 - 1 + pxl, y = y0 - 1 + py;
-        zk[u] = (i < KH * KW && inside(x, y, W, H)) ? a.zkeys[(size_t) y * W + x] : KBE_ZKEY_EMPTY;     // common.py:430 outside
-    }
     float4 rr[PER], cc[PER];
     // the first REC_CAP records are loaded WITHOUT waiting for the count (the bucket is at least that
     // large, so the addresses are valid; slots past the count hold stale records and are masked below)
     static_assert(BUCKET_CAP >= ((REC_CAP + TILE_THREADS - 1) / TILE_THREADS) * TILE_THREADS, "speculative bucket loads stay in bounds");
 #pragma unroll
     for (int u = 0; u < PER; u++) rr[u] = B[tid + u * TILE_THREADS];
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
-    if (tid == 0) L.nrec = 0;
+    uint32_t zk[ZPER];
 #pragma unroll
     for (int u = 0; u < ZPER; u++) {
         const int i = tid + u * TILE_THREADS;
-        if (i < KH * KW) L.zpre[i] = zkey_decode(zk[u]);
+        const int py = i / KW, pxl = i - py * KW;
+        const int x = min(max(x0 - 1 + pxl, 0), W - 1), y = min(max(y0 - 1 + py, 0), H - 1);     // clamped: always a valid address
+        zk[u] = a.zkeys[(size_t) y * W + x];
+    }
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+    if (tid == 0) {
+        L.nrec = 0;
+        // record 0 doubles as the dummy an exhausted list reads in the gather: finite even if the tile stays empty
+        L.rec[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+        L.rgbd[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // colours of the records (slots past the count: point 0, discarded later; the host never passes a NULL cloud)
+    const int n0 = bucketed ? min(REC_CAP, count) : 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        cc[u] = fetch_rgbd(a, i < n0 ? __float_as_int(rr[u].w) : 0);
+    }
+    bool band = true;
+#pragma unroll
+    for (int u = 0; u < ZPER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        const int py = i / KW, pxl = i - py * KW;
+        if (i < KH * KW) {
+            const float z = zkey_decode(inside(x0 - 1 + pxl, y0 - 1 + py, W, H) ? zk[u] : KBE_ZKEY_EMPTY);     // common.py:430 outside
+            L.zpre[i] = z;
+            band = band && degrid_fast_ok(z);
+        }
+    }
+    {
+        const unsigned long long odd = __ballot(!band);
+        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
     }
     KBE_TICK(1);
     __syncthreads();
     KBE_TICK(2);
-    // the records have landed by now: fetch their colours; these loads fly while the degrid computes.
-    // The explicit wait tells the compiler so: without it its wait-count bookkeeping, merging the taken and
-    // not-taken sides of the `i < n0` branches below, re-waited for the RECORD loads after the colour loads
-    // were issued -- i.e. for the colour loads themselves, in front of the degrid instead of behind it.
-    const int n0 = bucketed ? min(REC_CAP, count) : 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+    // one decision per tile: every z of tile + halo in [2^19, 1e6] (any scene whose points are farther than
+    // F*B/475712 from the camera) -> fp32-only, branch-free degrid and z test
+    bool fast = true;
 #pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int i = tid + u * TILE_THREADS;
-        cc[u] = i < n0 ? fetch_rgbd(a, __float_as_int(rr[u].w)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
+#if defined(KBE_PROBE_NO_FAST)
+    fast = false;
+#endif
+    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
     // degrid (common.py:525-568), out of place
-    for (int i = tid; i < TH * TW; i += TILE_THREADS) {
-        const int ly = i / TW, lx = i - ly * TW;
-        const int x = x0 + lx, y = y0 + ly;
-        if (x >= W || y >= H) continue;
-        auto at = [&](int xx, int yy) { return L.zpre[(yy - y0 + 1) * KW + (xx - x0 + 1)]; };
-        const float zd = degrid_pixel(x, y, W, H, at);
-        L.zee[i] = zd;
-        if (a.zee) a.zee[(size_t) y * W + x] = zd;
-        if (a.zee_pre) a.zee_pre[(size_t) y * W + x] = at(x, y);
+#if defined(KBE_PROBE_SKIP_DEGRID)
+    for (int i = tid; i < TH * TW; i += TILE_THREADS) L.zee[i] = L.zpre[(i / TW + 1) * KW + (i % TW) + 1];
+    if (false) {
+#else
+    if (fast && !a.zee_pre) {
+#endif
+#pragma unroll
+        for (int u = 0; u < PIX_PER_THREAD; u++) {
+            const int i = tid + u * TILE_THREADS;
+            const int ly = i / TW, lx = i - ly * TW;
+            const float* z = &L.zpre[(ly + 1) * KW + (lx + 1)];
+            const float nb_a[4] = { z[1], z[KW], z[KW + 1], z[1 - KW] };            // (+1, 0) (0, +1) (+1, +1) (+1, -1)
+            const float nb_d[4] = { z[-1], z[-KW], z[-KW - 1], z[KW - 1] };         // their mirror images
+            const float zd = degrid_pixel_fast(z[0], nb_a, nb_d);
+            L.zee[i] = zd;                                                          // pixels past the image edge: never read
+            if (a.zee && x0 + lx < W && y0 + ly < H) a.zee[(size_t) (y0 + ly) * W + x0 + lx] = zd;
+        }
+    } else {
+        for (int i = tid; i < TH * TW; i += TILE_THREADS) {
+            const int ly = i / TW, lx = i - ly * TW;
+            const int x = x0 + lx, y = y0 + ly;
+            if (x >= W || y >= H) continue;
+            auto at = [&](int xx, int yy) { return L.zpre[(yy - y0 + 1) * KW + (xx - x0 + 1)]; };
+            const float zd = degrid_pixel(x, y, W, H, at);
+            L.zee[i] = zd;
+            if (a.zee) a.zee[(size_t) y * W + x] = zd;
+            if (a.zee_pre) a.zee_pre[(size_t) y * W + x] = at(x, y);
+        }
     }
 
     float acc[PIX_PER_THREAD][5];
@@ -513,7 +557,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
             __syncthreads();
             KBE_TICK(5);
 #if !defined(KBE_PROBE_SKIP_GATHER)
-            gather(a, L, tid, x0, y0, acc);
+            if (fast) gather<true>(a, L, tid, x0, y0, acc);
+            else gather<false>(a, L, tid, x0, y0, acc);
 #endif
             KBE_TICK(6);
         }
@@ -548,7 +593,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
             }
             __syncthreads();
             if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
-                gather(a, L, tid, x0, y0, acc);
+                gather<false>(a, L, tid, x0, y0, acc);
                 __syncthreads();
                 for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
                 if (tid == 0) L.nrec = 0;
@@ -560,55 +605,58 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     // resolve: normalise (common.py:686), hole mask (:253), uint8 (:255)
     const size_t HW = (size_t) W * H;
     uint8_t* s_u8 = (uint8_t*) L.rgbd;            // the records are dead now
+    float res[PIX_PER_THREAD][4], dms[PIX_PER_THREAD];
+    bool hole[PIX_PER_THREAD], valid[PIX_PER_THREAD];
+    unsigned long long hm[PIX_PER_THREAD];
+    int n_holes = 0;
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++) {
+        const int q = tid + m * TILE_THREADS;
+        const int ly = q / TW, lx = q - ly * TW;
+        const bool in = x0 + lx < W && y0 + ly < H;
+        const float w = acc[m][4];
+        const float den = w + 0.0000001f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) res[m][ch] = acc[m][ch] / den;
+        dms[m] = res[m][3] * (w > 0.0f ? 1.0f : 0.0f);
+        valid[m] = in && dms[m] > 0.0f;
+#if defined(KBE_PROBE_NO_HOLES)
+        hole[m] = false;
+#else
+        hole[m] = in && !(dms[m] > 0.0f);
+#endif
+        hm[m] = __ballot(hole[m]);
+        n_holes += __popcll(hm[m]);
+    }
+    // ONE returning atomic per wave reserves its slots in the hole list; it is issued here and its result is
+    // only consumed after the stores and the bounding-box reduction below (a ~2 us round trip otherwise
+    // spent waiting)
+    int hole_base = 0;
+    if (n_holes > 0 && lane == 0) hole_base = atomicAdd(a.hole_count, n_holes);
+    int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
         const int q = tid + m * TILE_THREADS;
         const int ly = q / TW, lx = q - ly * TW;
         const int x = x0 + lx, y = y0 + ly;
         const bool in = x < W && y < H;
-        const float w = acc[m][4];
-        const float den = w + 0.0000001f;
-        const float r = acc[m][0] / den, g = acc[m][1] / den, b = acc[m][2] / den, d = acc[m][3] / den;
-        const float dm = d * (w > 0.0f ? 1.0f : 0.0f);
-        s_u8[q * 3] = to_u8(r); s_u8[q * 3 + 1] = to_u8(g); s_u8[q * 3 + 2] = to_u8(b);
-#if defined(KBE_PROBE_NO_HOLES)
-        const bool hole = false;
-#else
-        const bool hole = in && !(dm > 0.0f);
-#endif
-        const unsigned long long hm = __ballot(hole);
-        if (hm) {
-            int base = 0;
-            const int leader = __ffsll((long long) hm) - 1;
-            if (lane == leader) base = atomicAdd(a.hole_count, __popcll(hm));
-            base = __shfl(base, leader);
-            if (hole) a.holes[base + __popcll(hm & ((1ull << lane) - 1ull))] = y * W + x;
-        }
+        s_u8[q * 3] = to_u8(res[m][0]); s_u8[q * 3 + 1] = to_u8(res[m][1]); s_u8[q * 3 + 2] = to_u8(res[m][2]);
         {   // validity bits: each 32-lane half of the wave holds 32 consecutive pixels of one row
-            const unsigned long long vm = __ballot(in && dm > 0.0f);
-            if ((lane & 31) == 0 && y < H && x < W) a.mask[(size_t) y * ((W + 31) >> 5) + (x >> 5)] = (uint32_t) (vm >> (lane & 32));
+            const unsigned long long vm = __ballot(valid[m]);
+            if ((lane & 31) == 0 && in) a.mask[(size_t) y * ((W + 31) >> 5) + (x >> 5)] = (uint32_t) (vm >> (lane & 32));
         }
         if (in) {
             const size_t o = (size_t) y * W + x;
-            a.depth[o] = dm;
+            a.depth[o] = dms[m];
 #if !defined(KBE_PROBE_TIMING)
-            if (a.render) { a.render[o] = r; a.render[HW + o] = g; a.render[2 * HW + o] = b; a.render[3 * HW + o] = d; }
+            if (a.render) { a.render[o] = res[m][0]; a.render[HW + o] = res[m][1]; a.render[2 * HW + o] = res[m][2]; a.render[3 * HW + o] = res[m][3]; }
 #endif
-            if (a.existing) a.existing[o] = w;
+            if (a.existing) a.existing[o] = acc[m][4];
         }
+        // bounding box of the valid pixels (depth > 0): lets the hole fill discard rays that can never hit one
+        if (valid[m]) { vx0 = min(vx0, x); vy0 = min(vy0, y); vx1 = max(vx1, x); vy1 = max(vy1, y); }
     }
-    // bounding box of the valid pixels (depth > 0): lets the hole fill discard rays that can never hit one
     {
-        int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
-#pragma unroll
-        for (int m = 0; m < PIX_PER_THREAD; m++) {
-            const int q = tid + m * TILE_THREADS;
-            const int ly = q / TW, lx = q - ly * TW;
-            const int x = x0 + lx, y = y0 + ly;
-            const float w = acc[m][4];
-            const bool valid = x < W && y < H && (acc[m][3] / (w + 0.0000001f)) * (w > 0.0f ? 1.0f : 0.0f) > 0.0f;
-            if (valid) { vx0 = min(vx0, x); vy0 = min(vy0, y); vx1 = max(vx1, x); vy1 = max(vy1, y); }
-        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             vx0 = min(vx0, __shfl_xor(vx0, off)); vy0 = min(vy0, __shfl_xor(vy0, off));
@@ -619,6 +667,16 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
         // badly across XCDs that they added 80-350 us per frame
         int* sb = L.head;
         if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; }
+    }
+    if (n_holes > 0) {                              // wave-uniform
+        int base = __shfl(hole_base, 0);
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) {
+            const int q = tid + m * TILE_THREADS;
+            const int ly = q / TW, lx = q - ly * TW;
+            if (hole[m]) a.holes[base + __popcll(hm[m] & ((1ull << lane) - 1ull))] = (y0 + ly) * W + x0 + lx;
+            base += __popcll(hm[m]);
+        }
     }
     KBE_TICK(8);
     __syncthreads();
@@ -632,8 +690,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
     }
     KBE_TICK(9);
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
-    const bool fast = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
-    if (fast) {
+    const bool dword_rows = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
+    if (dword_rows) {
         constexpr int DW_PER_ROW = TW * 3 / 4;
         for (int i = tid; i < TH * DW_PER_ROW; i += TILE_THREADS) {
             const int ly = i / DW_PER_ROW, k = i - ly * DW_PER_ROW;
@@ -649,6 +707,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_tiles(TileArgs a)
         }
     }
     KBE_TICK(10);
+#if defined(KBE_PROBE_TIMING)
+    if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + 12] = (long long) wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -807,6 +868,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     if (stages & KBE_STAGE_TILES) {
         TileArgs a;
         a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
+        if (N == 0) a.points = a.image = a.depth_in = (const float*) sc.zkeys;     // never dereferenced for a record, but never NULL
         a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
         a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox;
         a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;

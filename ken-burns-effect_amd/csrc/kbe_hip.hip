@@ -202,110 +202,127 @@ __device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, int
     c1 = cv_round(f * 2048.f);
 }
 
-// One workgroup = a 64 x 4 tile of the output.  The raw-frame rows it needs are staged in LDS with
-// coalesced dword loads (the straightforward one-thread-per-pixel version issued 48 byte gathers
-// per output pixel and was load-instruction bound at 25 us per 1024^2 frame).
-constexpr int CR_TW = 64, CR_TH = 4, CR_ROWS = CR_TH + 3, CR_ROW_BYTES = (CR_TW + 4) * 3 + 8;
+// One workgroup = a 64 x 8 tile of the output, in the two steps OpenCV takes but without the intermediate
+// image: (0) the raw-frame rows the tile needs are staged in LDS with coalesced dword loads, (1) the
+// getRectSubPix patch pixels under the tile (each the rounded 16-bit fixed-point blend of 2 x 2 raw pixels) are
+// computed ONCE into LDS, (2) every output pixel blends 2 x 2 of those.  (One thread per output pixel doing
+// all 16 raw taps itself was instruction-bound: 400 VALU instructions per wave, 14.5 us per 1024^2 frame;
+// before the LDS staging it issued 48 byte gathers per pixel and took 25 us.)  The resize coefficients of the
+// tile's 64 columns and 8 rows are computed once, by 72 threads, not per pixel.
+constexpr int CR_TW = 64, CR_TH = 8, CR_THREADS = 256;
+constexpr int CR_PROWS = CR_TH + 2, CR_PCOLS = CR_TW + 2;              // patch pixels under a tile (scale <= 1)
+constexpr int CR_PBYTES = CR_PCOLS * 3, CR_PSTRIDE = (CR_PBYTES + 3) / 4 + 1;      // dwords per patch row in LDS
+constexpr int CR_RROWS = CR_PROWS + 1, CR_RDW = ((CR_PCOLS + 1) * 3 + 3 + 3) / 4 + 1;  // raw rows / dwords per raw row
+static_assert(CR_RROWS * CR_RDW <= 3 * CR_THREADS && CR_THREADS == 4 * CR_TW && CR_TH == 8, "crop tile geometry");
 
-__global__ void __launch_bounds__(CR_TW * CR_TH) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
-                                                                  uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
+                                                               uint8_t* __restrict__ out)
 {
-    __shared__ uint32_t s_raw[CR_ROWS][CR_ROW_BYTES / 4 + 1];
+    __shared__ uint32_t s_raw[CR_RROWS][CR_RDW];
+    __shared__ uint32_t s_patch[CR_PROWS][CR_PSTRIDE];
     __shared__ uint32_t s_out[CR_TH][CR_TW * 3 / 4];            // finished pixels leave as dwords (byte stores are slow)
+    __shared__ int s_cx[4][CR_TW], s_cy[4][CR_TH];              // per column / row of the tile: s0, s1, c0, c1
     const int tid = threadIdx.x;
-    const int dx = blockIdx.x * CR_TW + (tid & (CR_TW - 1)), dy = blockIdx.y * CR_TH + (tid / CR_TW);
+    const int bx = blockIdx.x * CR_TW, by = blockIdx.y * CR_TH;
     // getRectSubPix: top-left sample position and 16-bit fixed-point bilinear weights
     const float cx = (float) W / 2.0f - (float) (cw - 1) * 0.5f, cy = (float) H / 2.0f - (float) (ch_ - 1) * 0.5f;
     const int ipx = (int) floorf(cx), ipy = (int) floorf(cy);
     const float fa = cx - (float) ipx, fb = cy - (float) ipy;
     const int a11 = cv_round((1.f - fa) * (1.f - fb) * 65536.f), a12 = cv_round(fa * (1.f - fb) * 65536.f);
     const int a21 = cv_round((1.f - fa) * fb * 65536.f), a22 = cv_round(fa * fb * 65536.f);
-    const double sx_scale = (double) cw / W, sy_scale = (double) ch_ / H;
-    // raw rectangle this tile reads: patch columns of the first / last output column (+1 tap, +1 sub-pixel tap)
-    int t0, t1, u0, u1;
-    resize_coeff(blockIdx.x * CR_TW, sx_scale, cw, t0, t1, u0, u1);
-    const int px_lo = t0;
-    resize_coeff(min(blockIdx.x * CR_TW + CR_TW - 1, W - 1), sx_scale, cw, t0, t1, u0, u1);
-    const int px_hi = t1 + 1;
-    resize_coeff(blockIdx.y * CR_TH, sy_scale, ch_, t0, t1, u0, u1);
-    const int py_lo = t0;
-    resize_coeff(min(blockIdx.y * CR_TH + CR_TH - 1, H - 1), sy_scale, ch_, t0, t1, u0, u1);
-    const int py_hi = t1 + 1;
-    const int rx0 = min(max(ipx + px_lo, 0), W - 1), rx1 = min(max(ipx + px_hi, 0), W - 1);
-    const int ry0 = min(max(ipy + py_lo, 0), H - 1), ry1 = min(max(ipy + py_hi, 0), H - 1);
-    const int n_rows = ry1 - ry0 + 1;                                   // <= CR_ROWS
+    if (tid < CR_TW + CR_TH) {
+        const bool col = tid < CR_TW;
+        const int k = col ? tid : tid - CR_TW;
+        int s0, s1, c0, c1;
+        if (col) resize_coeff(min(bx + k, W - 1), (double) cw / W, cw, s0, s1, c0, c1);
+        else resize_coeff(min(by + k, H - 1), (double) ch_ / H, ch_, s0, s1, c0, c1);
+        int* t = col ? &s_cx[0][k] : &s_cy[0][k];
+        const int stride = col ? CR_TW : CR_TH;
+        t[0] = s0; t[stride] = s1; t[2 * stride] = c0; t[3 * stride] = c1;
+    }
+    __syncthreads();
+    // patch rectangle under the tile, and the raw rectangle under that (+1 sub-pixel tap), replicate border as OpenCV does
+    const int px_lo = s_cx[0][0], px_hi = s_cx[1][CR_TW - 1], py_lo = s_cy[0][0], py_hi = s_cy[1][CR_TH - 1];
+    const int n_pc3 = (px_hi - px_lo + 1) * 3, n_pr = py_hi - py_lo + 1;                    // <= CR_PBYTES, <= CR_PROWS
+    const int rx0 = min(max(ipx + px_lo, 0), W - 1), rx1 = min(max(ipx + px_hi + 1, 0), W - 1);
+    const int ry0 = min(max(ipy + py_lo, 0), H - 1), ry1 = min(max(ipy + py_hi + 1, 0), H - 1);
+    const int n_rows = ry1 - ry0 + 1;                                                       // <= CR_RROWS
     const size_t frame_bytes = (size_t) W * H * 3;
-    // every row of the staging rectangle is at most CR_ROW_BYTES / 4 + 1 dwords: one dword per thread and row.
-    // All loads are issued before the first LDS store (a load-store-load-store loop serialised 7 memory
-    // latencies and made this trivial kernel take 16 us).
-    uint32_t stage[CR_ROWS];
+    // (0) stage the raw rows: every load is issued before the first LDS store (a load-store-load-store loop
+    // serialises the memory latencies)
+    uint32_t stage[3];
 #pragma unroll
-    for (int r = 0; r < CR_ROWS; r++) {
-        stage[r] = 0;
+    for (int k = 0; k < 3; k++) {
+        const int item = tid + k * CR_THREADS;
+        const int r = item / CR_RDW, dwi = item - r * CR_RDW;
+        stage[k] = 0;
         if (r < n_rows) {
             const size_t b0 = ((size_t) (ry0 + r) * W + rx0) * 3, b1 = ((size_t) (ry0 + r) * W + rx1) * 3 + 3;
             const size_t a0 = b0 & ~(size_t) 3;
-            const int n_dw = (int) ((b1 - a0 + 3) >> 2);                // <= CR_ROW_BYTES / 4 + 1
-            if (tid < n_dw) {
-                const size_t off = a0 + 4 * (size_t) tid;
-                if (off + 4 <= frame_bytes) stage[r] = *(const uint32_t*) (img + off);
-                else for (int t = 0; t < 4; t++) if (off + t < frame_bytes) stage[r] |= (uint32_t) img[off + t] << (8 * t);
+            if (dwi < (int) ((b1 - a0 + 3) >> 2)) {
+                const size_t off = a0 + 4 * (size_t) dwi;
+                if (off + 4 <= frame_bytes) stage[k] = *(const uint32_t*) (img + off);
+                else for (int t = 0; t < 4; t++) if (off + t < frame_bytes) stage[k] |= (uint32_t) img[off + t] << (8 * t);
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < CR_ROWS; r++)
-        if (r < n_rows && tid <= CR_ROW_BYTES / 4) s_raw[r][tid] = stage[r];
+    for (int k = 0; k < 3; k++) {
+        const int item = tid + k * CR_THREADS;
+        if (item < CR_RROWS * CR_RDW) (&s_raw[0][0])[item] = stage[k];
+    }
     __syncthreads();
-    const bool live = dx < W && dy < H;
-    int sx = 0, sx1 = 0, ax0 = 0, ax1 = 0, sy = 0, sy1 = 0, by0 = 0, by1 = 0;
-    if (live) {
-    resize_coeff(dx, sx_scale, cw, sx, sx1, ax0, ax1);
-    resize_coeff(dy, sy_scale, ch_, sy, sy1, by0, by1);
-    }
-    // the 4 x 4 raw taps of this pixel (2 resize taps x 2 sub-pixel taps per axis), as LDS byte offsets of
-    // channel 0: computed once, replicate border as OpenCV does
-    int xo[4], yo[4];
-    const int px_[4] = { ipx + sx, ipx + sx + 1, ipx + sx1, ipx + sx1 + 1 };
-    const int py_[4] = { ipy + sy, ipy + sy + 1, ipy + sy1, ipy + sy1 + 1 };
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        xo[t] = (min(max(px_[t], 0), W - 1) - rx0) * 3;
-        const int yy = min(max(py_[t], 0), H - 1);
-        // row yy starts at byte ((yy * W + rx0) * 3) & 3 of its staging row
-        yo[t] = (yy - ry0) * (int) sizeof(s_raw[0]) + (int) ((((size_t) yy * W + rx0) * 3) & 3);
-        if (!live) { xo[t] = 0; yo[t] = 0; }                            // threads past the image edge only keep the barriers company
-    }
+    // (1) patch pixels, one byte (pixel channel) per step: 4 raw taps, rounded as cast_8u does
     const uint8_t* raw = (const uint8_t*) s_raw;
-    uint8_t px[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int p[2][2];                                                    // patch pixels (sy|sy1, sx|sx1), rounded as cast_8u does
-#pragma unroll
-        for (int v = 0; v < 2; v++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int t = raw[yo[2 * v] + xo[2 * u] + c] * a11 + raw[yo[2 * v] + xo[2 * u + 1] + c] * a12 +
-                              raw[yo[2 * v + 1] + xo[2 * u] + c] * a21 + raw[yo[2 * v + 1] + xo[2 * u + 1] + c] * a22;
-                p[v][u] = (t + (1 << 15)) >> 16;
-            }
-        const int r0 = p[0][0] * ax0 + p[0][1] * ax1, r1 = p[1][0] * ax0 + p[1][1] * ax1;     // horizontal pass, x2048
-        const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;        // vertical pass
-        px[c] = (uint8_t) min(max(v, 0), 255);
+    uint8_t* patch = (uint8_t*) s_patch;
+    for (int idx = tid; idx < CR_PROWS * CR_PBYTES; idx += CR_THREADS) {
+        const int pr = idx / CR_PBYTES, j = idx - pr * CR_PBYTES;
+        if (pr >= n_pr || j >= n_pc3) continue;
+        const int pc = j / 3, c = j - pc * 3;
+        const int x0 = (min(max(ipx + px_lo + pc, 0), W - 1) - rx0) * 3 + c, x1 = (min(max(ipx + px_lo + pc + 1, 0), W - 1) - rx0) * 3 + c;
+        const int y0 = min(max(ipy + py_lo + pr, 0), H - 1), y1 = min(max(ipy + py_lo + pr + 1, 0), H - 1);
+        // row y starts at byte ((y * W + rx0) * 3) & 3 of its staging row (only the low bits matter: 32-bit is enough)
+        const int o0 = (y0 - ry0) * (int) sizeof(s_raw[0]) + (int) ((((uint32_t) y0 * (uint32_t) W + (uint32_t) rx0) * 3u) & 3u);
+        const int o1 = (y1 - ry0) * (int) sizeof(s_raw[0]) + (int) ((((uint32_t) y1 * (uint32_t) W + (uint32_t) rx0) * 3u) & 3u);
+        const int t = raw[o0 + x0] * a11 + raw[o0 + x1] * a12 + raw[o1 + x0] * a21 + raw[o1 + x1] * a22;
+        patch[pr * (int) sizeof(s_patch[0]) + j] = (uint8_t) ((t + (1 << 15)) >> 16);
     }
-    uint8_t* so = (uint8_t*) s_out[tid / CR_TW] + (tid & (CR_TW - 1)) * 3;
-    so[0] = px[0]; so[1] = px[1]; so[2] = px[2];
     __syncthreads();
-    const int bx = blockIdx.x * CR_TW, byy = blockIdx.y * CR_TH;
+    // (2) resize INTER_LINEAR: 2 x 2 patch pixels per output pixel; two output rows per thread
+    const int col = tid & (CR_TW - 1);
+    const int sx = (s_cx[0][col] - px_lo) * 3, sx1 = (s_cx[1][col] - px_lo) * 3, ax0 = s_cx[2][col], ax1 = s_cx[3][col];
+    uint8_t px[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int row = (tid >> 6) + 4 * m;
+        const int sy = (s_cy[0][row] - py_lo) * (int) sizeof(s_patch[0]), sy1 = (s_cy[1][row] - py_lo) * (int) sizeof(s_patch[0]);
+        const int by0 = s_cy[2][row], by1 = s_cy[3][row];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int r0 = patch[sy + sx + c] * ax0 + patch[sy + sx1 + c] * ax1;            // horizontal pass, x2048
+            const int r1 = patch[sy1 + sx + c] * ax0 + patch[sy1 + sx1 + c] * ax1;
+            const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;  // vertical pass
+            px[m][c] = (uint8_t) min(max(v, 0), 255);
+        }
+        uint8_t* so = (uint8_t*) s_out[row] + col * 3;
+        so[0] = px[m][0]; so[1] = px[m][1]; so[2] = px[m][2];
+    }
+    __syncthreads();
     if ((W & 3) == 0 && bx + CR_TW <= W) {
         constexpr int DW = CR_TW * 3 / 4;
-        for (int i = tid; i < CR_TH * DW; i += CR_TW * CR_TH) {
+        for (int i = tid; i < CR_TH * DW; i += CR_THREADS) {
             const int r = i / DW, k = i - r * DW;
-            if (byy + r < H) ((uint32_t*) (out + ((size_t) (byy + r) * W + bx) * 3))[k] = s_out[r][k];
+            if (by + r < H) ((uint32_t*) (out + ((size_t) (by + r) * W + bx) * 3))[k] = s_out[r][k];
         }
-    } else if (live) {
-        const size_t o = ((size_t) dy * W + dx) * 3;
-        out[o] = px[0]; out[o + 1] = px[1]; out[o + 2] = px[2];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int dx = bx + col, dy = by + (tid >> 6) + 4 * m;
+            if (dx < W && dy < H) {
+                const size_t o = ((size_t) dy * W + dx) * 3;
+                out[o] = px[m][0]; out[o + 1] = px[m][1]; out[o + 2] = px[m][2];
+            }
+        }
     }
 }
 
@@ -584,7 +601,7 @@ int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int c
 {
     KBE_REQUIRE(frame_hwc && out_hwc && W > 0 && H > 0 && crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H,
                 "kbe_crop_resize_u8: bad arguments");
-    hipLaunchKernelGGL(k_crop_resize_u8, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH), dim3(CR_TW * CR_TH), 0,
+    hipLaunchKernelGGL(k_crop_resize_u8, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH), dim3(CR_THREADS), 0,
                        (hipStream_t) stream, frame_hwc, W, H, crop_w, crop_h, out_hwc);
     return launched("kbe_crop_resize_u8");
 }

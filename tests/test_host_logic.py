@@ -137,3 +137,16 @@ def test_product_refuses_to_run_without_gpu_library_or_tensors():
     from ken_burns_effect_amd import _native
     with pytest.raises(_native.KbeError):
         _native._ptr(torch.zeros(4))
+
+
+def test_degrid_fast_path_mean_is_the_correctly_rounded_division(tmp_path):
+    """kbe_device.h degrid_pixel_fast replaces sum / count by a multiply + one Markstein correction; the C
+    program checks it against the division for every float in the band the fast path is used in."""
+    import os
+    import subprocess
+    exe = str(tmp_path / 'markstein_check')
+    src = os.path.join(os.path.dirname(__file__), 'markstein_check.c')
+    subprocess.check_call(['gcc', '-O2', '-mfma', '-ffp-contract=off', src, '-o', exe, '-lm'])
+    out = subprocess.run([exe, '1048576', '8400000'], capture_output=True, text=True)      # 2^20 .. 8 * 1e6 (+ margin)
+    n, bad = (int(v) for v in out.stdout.split())
+    assert out.returncode == 0 and bad == 0 and n > 4 * 12_000_000

@@ -8,7 +8,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from ken_burns_effect_amd import common, synthetic  # noqa: E402
+from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
+
+if os.environ.get('KBE_LIB_PATH'):          # a variant build (tools/gpu_variant_pmc.sh)
+    _native._lib, _native._kernels, _native.LIB_PATH = None, None, os.environ['KBE_LIB_PATH']
 
 size = int(os.environ.get('SIZE', '1024'))
 n = int(os.environ.get('FRAMES', '9'))

@@ -67,6 +67,15 @@ def main():
                 if m.any():
                     print('   count [%d,%d): %d tiles, duration mean %.0f max %.0f; gather %.0f insert %.0f degrid %.0f' % (
                         lo, hi, m.sum(), dur[m].mean(), dur[m].max(), d[m, 5].mean(), d[m, 3].mean(), d[m, 2].mean()), flush=True)
+            w0 = t[:, 11] - t[:, 11].min(); w1 = t[:, 12] - t[:, 11].min()
+            print('   wall clock (10 ns ticks): kernel span %d; WG start percentiles %s; end percentiles %s' % (
+                w1.max(), np.percentile(w0, [0, 10, 25, 50, 75, 90, 100]).astype(int).tolist(),
+                np.percentile(w1, [0, 10, 25, 50, 75, 90, 100]).astype(int).tolist()), flush=True)
+            print('   sorted WG starts (every 32nd):', np.sort(w0).astype(int)[::32].tolist(), flush=True)
+            print('   sorted WG ends   (every 32nd):', np.sort(w1).astype(int)[::32].tolist(), flush=True)
+            print('   XCD0 (start,end) in block order:', [(int(w0[i]), int(w1[i])) for i in range(0, nt, 8)][:40], flush=True)
+            late = np.argsort(-w1)[:12]
+            print('   last to finish: ' + ' '.join('b%d(xcd%d,cnt%d,start%d,end%d)' % (i, i & 7, c[i], w0[i], w1[i]) for i in late), flush=True)
             k0 = xcd == 0
             st = t[k0, 0] - t[k0, 0].min()
             print('   XCD0 starts:', np.sort(st).astype(int)[::8].tolist(), flush=True)
