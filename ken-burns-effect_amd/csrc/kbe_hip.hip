@@ -222,6 +222,7 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
     __shared__ uint32_t s_patch[CR_PROWS][CR_PSTRIDE];
     __shared__ uint32_t s_out[CR_TH][CR_TW * 3 / 4];            // finished pixels leave as dwords (byte stores are slow)
     __shared__ int s_cx[4][CR_TW], s_cy[4][CR_TH];              // per column / row of the tile: s0, s1, c0, c1
+    __shared__ int s_ro[CR_PROWS + 1];
     const int tid = threadIdx.x;
     const int bx = blockIdx.x * CR_TW, by = blockIdx.y * CR_TH;
     // getRectSubPix: top-left sample position and 16-bit fixed-point bilinear weights
@@ -271,21 +272,30 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
         const int item = tid + k * CR_THREADS;
         if (item < CR_RROWS * CR_RDW) (&s_raw[0][0])[item] = stage[k];
     }
+    if (tid <= CR_PROWS) {
+        // byte offset in s_raw of the raw row under patch row `tid` (row CR_PROWS: the last bottom tap); row y starts
+        // at byte ((y * W + rx0) * 3) & 3 of its staging row (only the low bits matter: 32-bit arithmetic is enough)
+        const int y = min(max(ipy + py_lo + tid, 0), H - 1);
+        s_ro[tid] = min(y - ry0, CR_RROWS - 1) * (int) sizeof(s_raw[0]) + (int) ((((uint32_t) y * (uint32_t) W + (uint32_t) rx0) * 3u) & 3u);
+    }
     __syncthreads();
-    // (1) patch pixels, one byte (pixel channel) per step: 4 raw taps, rounded as cast_8u does
+    // (1) patch pixels: a thread owns one byte column (pixel channel) of the patch and walks down its rows; the
+    // bottom taps of one row are the top taps of the next, so a row costs 2 LDS reads, 4 multiply-adds and the
+    // rounding of cast_8u.  (One (row, byte) item per step with its own index arithmetic: 400 instructions.)
     const uint8_t* raw = (const uint8_t*) s_raw;
     uint8_t* patch = (uint8_t*) s_patch;
-    for (int idx = tid; idx < CR_PROWS * CR_PBYTES; idx += CR_THREADS) {
-        const int pr = idx / CR_PBYTES, j = idx - pr * CR_PBYTES;
-        if (pr >= n_pr || j >= n_pc3) continue;
-        const int pc = j / 3, c = j - pc * 3;
+    if (tid < n_pc3) {
+        const int pc = tid / 3, c = tid - pc * 3;
         const int x0 = (min(max(ipx + px_lo + pc, 0), W - 1) - rx0) * 3 + c, x1 = (min(max(ipx + px_lo + pc + 1, 0), W - 1) - rx0) * 3 + c;
-        const int y0 = min(max(ipy + py_lo + pr, 0), H - 1), y1 = min(max(ipy + py_lo + pr + 1, 0), H - 1);
-        // row y starts at byte ((y * W + rx0) * 3) & 3 of its staging row (only the low bits matter: 32-bit is enough)
-        const int o0 = (y0 - ry0) * (int) sizeof(s_raw[0]) + (int) ((((uint32_t) y0 * (uint32_t) W + (uint32_t) rx0) * 3u) & 3u);
-        const int o1 = (y1 - ry0) * (int) sizeof(s_raw[0]) + (int) ((((uint32_t) y1 * (uint32_t) W + (uint32_t) rx0) * 3u) & 3u);
-        const int t = raw[o0 + x0] * a11 + raw[o0 + x1] * a12 + raw[o1 + x0] * a21 + raw[o1 + x1] * a22;
-        patch[pr * (int) sizeof(s_patch[0]) + j] = (uint8_t) ((t + (1 << 15)) >> 16);
+        int o = s_ro[0];
+        int t0 = raw[o + x0], t1 = raw[o + x1];
+        for (int pr = 0; pr < n_pr; pr++) {
+            o = s_ro[pr + 1];
+            const int u0 = raw[o + x0], u1 = raw[o + x1];
+            const int t = t0 * a11 + t1 * a12 + u0 * a21 + u1 * a22;
+            patch[pr * (int) sizeof(s_patch[0]) + tid] = (uint8_t) ((t + (1 << 15)) >> 16);
+            t0 = u0; t1 = u1;
+        }
     }
     __syncthreads();
     // (2) resize INTER_LINEAR: 2 x 2 patch pixels per output pixel; two output rows per thread

@@ -180,7 +180,10 @@ def test_pconv_epilogue(K, oracle):
 
 def test_crop_resize_matches_written_algorithm(K, oracle):
     rng = np.random.default_rng(5)
-    for (H, W, cw, ch) in [(48, 64, 57, 43), (48, 64, 58, 44), (96, 128, 115, 86), (33, 47, 47, 33)]:
+    # even / odd crops (sub-pixel 0.5 and 0), the full frame (replicated border taps), widths that are not a
+    # multiple of 4 or of the 64 x 8 tile, tiny crops (every output pixel blends the same few patch pixels), 1024^2
+    for (H, W, cw, ch) in [(48, 64, 57, 43), (48, 64, 58, 44), (96, 128, 115, 86), (33, 47, 47, 33), (64, 64, 64, 64),
+                           (130, 258, 3, 2), (71, 193, 192, 70), (9, 5, 4, 7), (256, 1024, 900, 225), (1024, 1024, 819, 819)]:
         f = (rng.random((H, W, 3)) * 255).astype(np.uint8)
         out = c(K.crop_resize_u8(torch.from_numpy(f).cuda(), cw, ch))
         assert np.array_equal(out, oracle.crop_resize_u8(f, cw, ch))
