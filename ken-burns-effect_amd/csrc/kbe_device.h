@@ -47,7 +47,10 @@ struct Camera {
 __device__ __forceinline__ void apply_shift(const Camera& cam, float& x, float& y, float& z)
 {
     if (cam.has_shift) {
-        const float r = z / (z + 0.0000001f);
+        // z + 1e-7f == z for every z >= 2 (half an ulp is then > 1e-7): the ratio is exactly 1 and the division
+        // (11 instructions) is skipped when that holds for the whole wave
+        const float zz = z + 0.0000001f;
+        const float r = __all(zz == z) ? 1.0f : z / zz;
         x = x * r + cam.sx;
         y = y * r + cam.sy;
         z = z + cam.sz;

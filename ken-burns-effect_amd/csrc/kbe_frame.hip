@@ -168,33 +168,36 @@ constexpr int PATCH_ROWS = 2 * PTS_PER_THREAD;          // a raster unit is a 32
 __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    // wave-uniform values are made scalar explicitly (the unit -> point index arithmetic below then runs on the
+    // scalar unit, once per wave, in 32 bits; as vector 64-bit arithmetic it was a sixth of this kernel's instructions)
+    const int wave = __builtin_amdgcn_readfirstlane((int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int n_waves = (int) ((gridDim.x * blockDim.x) >> 6);
     const Camera& cam = a.cam;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.hole_count = 0;
     const size_t N = (size_t) a.N;
     // Work units of UNIT points per wave.  Where the cloud is known to start with a row-major raster (the image
     // pixels), a unit is a 32 x PATCH_ROWS patch of it rather than UNIT consecutive pixels of a row: its points
     // then fall into one or two target tiles, and a bucket's records reference neighbouring points.  Pure speed
-    // hint.  (One point per lane: 4 per lane needed 98-118 VGPRs, halved the occupancy of this latency-bound
-    // kernel and doubled its time, 13.8 vs 6.5 us.)
-    const int patches_x = (a.raster_w > 0 && a.raster_w % 32 == 0) ? a.raster_w / 32 : 0;
-    const int patch_rows = patches_x ? (a.raster_n / a.raster_w) / PATCH_ROWS : 0;
-    const long n_patches = (long) patches_x * patch_rows;
-    const long lin0 = n_patches * UNIT;                         // points before lin0 are covered by patches
-    const long n_units = n_patches + ((long) a.N - lin0 + UNIT - 1) / UNIT;
-    for (long unit = wave; unit < n_units; unit += n_waves) {
+    // hint.  (One point per lane: 4 per lane needed 98-118 VGPRs, halved the occupancy of this kernel and doubled
+    // its time; 2 per lane measured 9 % slower.)
+    const unsigned patches_x = (a.raster_w > 0 && a.raster_w % 32 == 0) ? (unsigned) a.raster_w / 32u : 0u;
+    const unsigned patch_rows = patches_x ? ((unsigned) a.raster_n / (unsigned) a.raster_w) / PATCH_ROWS : 0u;
+    const unsigned n_patches = patches_x * patch_rows;                  // <= N / UNIT
+    const unsigned lin0 = n_patches * UNIT;                             // points before lin0 are covered by patches
+    const unsigned n_units = n_patches + ((unsigned) a.N - lin0 + UNIT - 1) / UNIT;
+    for (unsigned unit = (unsigned) wave; unit < n_units; unit += (unsigned) n_waves) {
         float4 rec[PTS_PER_THREAD];
         bool ok[PTS_PER_THREAD], spx[PTS_PER_THREAD], spy[PTS_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < PTS_PER_THREAD; j++) {
-            long i;
+            unsigned i;
             if (unit < n_patches) {
-                const int pyb = (int) (unit / patches_x), pxb = (int) (unit - (long) pyb * patches_x);
-                i = ((long) pyb * PATCH_ROWS + (lane >> 5) + 2 * j) * a.raster_w + pxb * 32 + (lane & 31);
+                const unsigned pyb = unit / patches_x, pxb = unit - pyb * patches_x;
+                i = (pyb * PATCH_ROWS + (unsigned) (lane >> 5) + 2u * j) * (unsigned) a.raster_w + pxb * 32u + (unsigned) (lane & 31);
             } else {
-                i = lin0 + (unit - n_patches) * UNIT + lane + 64 * j;
+                i = lin0 + (unit - n_patches) * UNIT + (unsigned) lane + 64u * j;
             }
-            ok[j] = i < (long) a.N;
+            ok[j] = i < (unsigned) a.N;
             float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f, err = 0.0f;
             if (ok[j]) {
                 x = a.points[i]; y = a.points[N + i]; z = a.points[2 * N + i];
@@ -216,7 +219,9 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
                 const int k = winner_corner(p);                 // common.py:486-506
                 if (k >= 0) {
                     const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+#if !defined(KBE_PROBE_NO_ZSPLAT)
                     if (inside(cx, cy, cam.W, cam.H)) atomicMin(&a.zkeys[(size_t) cy * cam.W + cx], zkey_encode(err));
+#endif
                 }
             }
             rec[j] = make_float4(ox, oy, err, __int_as_float((int) i));
@@ -254,6 +259,9 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
                                  ty0 < a.tiles_y;
 #if defined(KBE_PROBE_NO_SPILLS)
                     if (half + e > 0) want[j][e] = false;
+#endif
+#if defined(KBE_PROBE_NO_BUCKETS)
+                    want[j][e] = false;
 #endif
                     tgt[j][e] = ty0 * a.tiles_x + tx;
                     grp[j][e] = group_by_tile(want[j][e], tgt[j][e]);

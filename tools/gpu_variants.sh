@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU box: for each variant (a quoted set of extra hipcc flags) build the library into /tmp, trace 33 frames
+# and print the per-kernel median durations (dev aid).   gpurun -- 'bash tools/gpu_variants.sh "" "-DX=2"'
+export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for flags in "$@"; do
+  so=/tmp/libkbe_var_$i.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -I$R/include -I$R/ken-burns-effect_amd/csrc $flags \
+      $R/ken-burns-effect_amd/csrc/kbe_hip.hip $R/ken-burns-effect_amd/csrc/kbe_frame.hip -o $so || exit 1
+  rm -rf /tmp/t$i
+  KBE_LIB_PATH=$so FRAMES=${FRAMES:-33} timeout 600 rocprofv3 --kernel-trace -d /tmp/t$i -o t --output-format csv -- python $R/tools/frame_once.py > /tmp/t$i.log 2>&1 || tail -5 /tmp/t$i.log
+  echo "== variant: ${flags:-(default)}"
+  python $R/tools/kernel_times.py /tmp/t$i/t_kernel_trace.csv
+  i=$((i+1))
+done
