@@ -178,15 +178,25 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
  * not filled), then an asynchronous copy of the finished uint8 frame into host_out[i] (pinned host
  * memory, [n_frames,H,W,3]).  focals [n_frames] and shifts [n_frames][3] are HOST arrays (shift as
  * the fp32 values process_shift produces).  Frames are staged on the device in two halves of
- * `batch` frames and leave in one transfer per half; stage: DEVICE buffer of (2*batch + 1)*H*W*3
- * bytes.  If copy_stream differs from stream the transfers run there and overlap the rendering of
- * the other half (the call creates and destroys four HIP events for that; cross-stream waits are
- * per batch because they are expensive); synchronising `stream` afterwards guarantees every
- * frame has landed. */
+ * `batch` frames and leave in one transfer per half.  If copy_stream differs from stream the
+ * transfers run there and overlap the rendering of the other half (cross-stream waits are per
+ * batch because they are expensive); synchronising `stream` afterwards guarantees every frame has
+ * landed.  batch == 0: no staging, every frame's last kernel stores straight into host_out[i],
+ * which may then be DEVICE memory (the frames stay in HBM) or device-visible pinned host memory.
+ * Frames are independent, so consecutive frames are enqueued on `lanes` (1..KBE_MAX_LANES) streams,
+ * lane 0 on `stream`, lane l on lane_streams[l] (may be NULL when lanes == 1); each lane has its
+ * own scratch and raw frame:
+ *   scratch: lanes * kbe_video_scratch_stride(W, H) bytes, each lane's part initialised with
+ *            kbe_frame_scratch_init;
+ *   stage:   DEVICE buffer of (lanes + 2*batch) * H*W*3 bytes.
+ * The call creates and destroys its HIP events. */
+#define KBE_MAX_LANES 4
+KBE_API size_t kbe_video_scratch_stride(int W, int H);
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
-                             int raster_w, int raster_n, kbe_stream_t stream, kbe_stream_t copy_stream);
+                             int raster_w, int raster_n, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
+                             const kbe_stream_t* lane_streams);
 
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
 KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);

@@ -20,11 +20,13 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_video', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_render_video', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
 ABI_VERSION = 1
+MAX_LANES = 4          # KBE_MAX_LANES
+DEFAULT_LANES = 3      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 _lib = None
 
 
@@ -47,6 +49,7 @@ def load():
         getattr(lib, name).restype = ctypes.c_int
     lib.kbe_last_error.restype = ctypes.c_char_p
     lib.kbe_frame_scratch_bytes.restype = ctypes.c_size_t
+    lib.kbe_video_scratch_stride.restype = ctypes.c_size_t
     if lib.kbe_abi_version() != ABI_VERSION:
         raise KbeError('libkbe_hip.so ABI %d != expected %d' % (lib.kbe_abi_version(), ABI_VERSION))
     _lib = lib
@@ -185,10 +188,15 @@ class HipKernels:
                  'raster_w': W if N >= W * H else 0, 'raster_n': W * H if N >= W * H else 0}
         if os.environ.get('KBE_NO_RASTER_HINT'):
             state['raster_w'] = state['raster_n'] = 0
-        nbytes = int(self.lib.kbe_frame_scratch_bytes(_i(W), _i(H)))
-        state['scratch'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self._check(self.lib.kbe_frame_scratch_init(_ptr(state['scratch'], torch.uint8), _i(W), _i(H), _stream()),
-                    'kbe_frame_scratch_init')
+        # one scratch per lane of the frame loop (render_video renders consecutive frames on `lanes` streams);
+        # render_frame uses lane 0's
+        lanes = max(1, min(MAX_LANES, int(os.environ.get('KBE_LANES', DEFAULT_LANES))))
+        stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H)))
+        state['lanes'] = lanes
+        state['scratch'] = torch.empty(lanes * stride, dtype=torch.uint8, device=dev)
+        for l in range(lanes):
+            self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
+                        'kbe_frame_scratch_init')
         return state
 
     def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None, zee_f32=None,
@@ -219,11 +227,14 @@ class HipKernels:
         batch = max(0, int(batch))      # 0 = zero-copy (kernels store straight into the pinned host buffer)
         if host_out.is_cuda:
             batch, overlap = 0, False
+        lanes = state['lanes']
         if state.get('stage_batch') != batch:
-            state['stage'] = torch.empty((2 * batch + 1) * H * W * 3, dtype=torch.uint8, device=dev)
+            state['stage'] = torch.empty((2 * batch + lanes) * H * W * 3, dtype=torch.uint8, device=dev)
             state['stage_batch'] = batch
         if 'copy_stream' not in state:
             state['copy_stream'] = torch.cuda.Stream(device=dev)
+            state['lane_streams'] = [None] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+        lane_streams = (ctypes.c_void_p * MAX_LANES)(*[None if st is None else st.cuda_stream for st in state['lane_streams']])
         focals = (ctypes.c_double * max(n, 1))(*[float(c[0]) for c in cameras])
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
@@ -233,7 +244,7 @@ class HipKernels:
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
-                                              _stream(), copy_stream), 'kbe_render_video')
+                                              _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
         return host_out
 
     def zkeys_clear(self, zkeys):

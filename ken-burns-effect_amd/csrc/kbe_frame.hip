@@ -735,12 +735,18 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
                                                     const int4* __restrict__ bbox)
 {
     // leave the scratch ready for the next frame: empty z-buffer, empty buckets
+#if !defined(KBE_PROBE_NO_RESET)
     {
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int i = gtid; i < W * H; i += gsz) zkeys[i] = KBE_ZKEY_EMPTY;
         for (int i = gtid; i < n_tiles; i += gsz) tile_count[i * CNT_STRIDE] = 0;
     }
+#endif
+#if defined(KBE_PROBE_NO_WALK)
+    const int n = 0;
+#else
     const int n = *hole_count;
+#endif
     // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
     // (common.py:880-885) without walking there.  Exact, and it is what makes a zoomed-out (dolly) frame,
@@ -839,6 +845,11 @@ size_t kbe_frame_scratch_bytes(int W, int H)
     return (W <= 0 || H <= 0) ? 0 : scratch_bytes(W, H);
 }
 
+size_t kbe_video_scratch_stride(int W, int H)
+{
+    return (W <= 0 || H <= 0) ? 0 : ((scratch_bytes(W, H) + 255) & ~(size_t) 255);
+}
+
 int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
 {
     KBE_REQUIRE(scratch && W > 0 && H > 0 && ((uintptr_t) scratch & 15) == 0, "kbe_frame_scratch_init: bad arguments");
@@ -869,7 +880,11 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
         p.raster_w = 0; p.raster_n = 0;
         if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
-        const unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) + 2 : 1;
+#ifndef KBE_PROJECT_MAX_BLOCKS
+#define KBE_PROJECT_MAX_BLOCKS 1000000
+#endif
+        unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) + 2 : 1;
+        if (blocks > KBE_PROJECT_MAX_BLOCKS) blocks = KBE_PROJECT_MAX_BLOCKS;
         hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, p);
         if ((rc = launched("kbe_render_frame/project"))) return rc;
     }
@@ -885,7 +900,10 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     }
     if (stages & KBE_STAGE_FILL) {
         const size_t hw = (size_t) W * H;
-        const unsigned fill_blocks = (unsigned) (hw / 64 < 2048 ? (hw / 64 > 0 ? hw / 64 : 1) : 2048);
+#ifndef KBE_FILL_MAX_BLOCKS
+#define KBE_FILL_MAX_BLOCKS 2048
+#endif
+        const unsigned fill_blocks = (unsigned) (hw / 64 < KBE_FILL_MAX_BLOCKS ? (hw / 64 > 0 ? hw / 64 : 1) : KBE_FILL_MAX_BLOCKS);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
@@ -907,27 +925,41 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
-                     kbe_stream_t copy_stream)
+                     kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams)
 {
     KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 0, "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
+    KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
     const hipStream_t cs = (hipStream_t) stream, ds = (hipStream_t) (copy_stream ? copy_stream : stream);
     const bool overlap = ds != cs;
     const size_t fb = (size_t) W * H * 3;
+    const size_t sb = (scratch_bytes(W, H) + 255) & ~(size_t) 255;      // == kbe_frame_scratch_bytes rounded: lane stride
     const bool crop = crop_w > 0;
-    // stage = [raw frame][ring half 0: batch frames][ring half 1: batch frames].  A half is copied to the host
-    // with ONE transfer while the other half is being rendered; cross-stream events are per batch, not per
-    // frame (a cross-stream wait costs far more host time than a launch on this stack).
-    uint8_t* raw = stage;
-    uint8_t* ring[2] = { stage + fb, stage + fb + (size_t) batch * fb };
-    hipEvent_t rendered[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
-    if (overlap) {
-        for (int b = 0; b < 2; b++) {
-            if (hipEventCreateWithFlags(&rendered[b], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&copied[b], hipEventDisableTiming) != hipSuccess)
-                return fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate");
-        }
+    // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
+    // frame: the fixed cost of a kernel boundary on this chip (launch ramp, tail, and the L2 write-back between
+    // dependent kernels: ~4-5 us per launch, 4 launches per frame) is then paid while another frame's kernels run.
+    // stage = [lanes raw frames][ring half 0: batch frames][ring half 1: batch frames].  A half is copied to
+    // the host with ONE transfer while the other half is being rendered; cross-stream events are per batch, not
+    // per frame (a cross-stream wait costs far more host time than a launch on this stack).
+    hipStream_t ls[KBE_MAX_LANES];
+    for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? cs : (hipStream_t) lane_streams[l];
+    uint8_t* ring[2] = { stage + (size_t) lanes * fb, stage + (size_t) lanes * fb + (size_t) batch * fb };
+    hipEvent_t start = nullptr, rendered[2][KBE_MAX_LANES] = {}, copied[2] = { nullptr, nullptr };
+    auto make = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    bool ok = true;
+    if (lanes > 1) ok = ok && make(&start);
+    for (int h = 0; h < 2; h++) {
+        if (overlap || lanes > 1) ok = ok && make(&copied[h]);
+        for (int l = 0; l < lanes; l++) if (overlap || l > 0) ok = ok && make(&rendered[h][l]);
     }
+    auto destroy = [&]() {
+        if (start) (void) hipEventDestroy(start);
+        for (int h = 0; h < 2; h++) {
+            if (copied[h]) (void) hipEventDestroy(copied[h]);
+            for (int l = 0; l < KBE_MAX_LANES; l++) if (rendered[h][l]) (void) hipEventDestroy(rendered[h][l]);
+        }
+    };
+    if (!ok) { destroy(); return fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate"); }
     int rect[4] = { 0, 0, W - 1, H - 1 };
     if (crop) {
         // the pixels cv2.getRectSubPix reads (common.py:256), padded by one: see kbe_render_frame_stages
@@ -936,49 +968,53 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         rect[2] = x0 + crop_w + 2 < W - 1 ? x0 + crop_w + 2 : W - 1;
         rect[3] = y0 + crop_h + 2 < H - 1 ? y0 + crop_h + 2 : H - 1;
     }
+    // the other lanes start once everything enqueued on `stream` so far (the cloud) is done
+    if (lanes > 1) {
+        (void) hipEventRecord(start, cs);
+        for (int l = 1; l < lanes; l++) (void) hipStreamWaitEvent(ls[l], start, 0);
+    }
+    auto frame = [&](int i, uint8_t* out) {
+        const int l = i % lanes;
+        uint8_t* raw = stage + (size_t) l * fb;
+        int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
+                                         (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
+                                         (kbe_stream_t) ls[l]);
+        if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
+        return rc;
+    };
     int rc = KBE_OK;
     int n_batches = 0;
     if (batch == 0) {
-        // zero-copy: the last kernel of every frame stores straight into the (device-visible) pinned host
-        // buffer; no transfer engine, no second stream, no events
-        for (int i = 0; i < n_frames && rc == KBE_OK; i++) {
-            uint8_t* out = host_out + (size_t) i * fb;
-            rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
-                                         crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
-                                         stream);
-            if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
+        // no staging: the last kernel of every frame stores straight into host_out -- device memory (the frames stay
+        // in HBM) or device-visible pinned host memory (zero-copy); no transfer engine, no copy stream
+        for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = frame(i, host_out + (size_t) i * fb);
+        for (int l = 1; l < lanes; l++) {
+            (void) hipEventRecord(rendered[0][l], ls[l]);
+            (void) hipStreamWaitEvent(cs, rendered[0][l], 0);
         }
-        if (overlap) for (int b = 0; b < 2; b++) { (void) hipEventDestroy(rendered[b]); (void) hipEventDestroy(copied[b]); }
+        destroy();
         return rc;
     }
     for (int i0 = 0; i0 < n_frames && rc == KBE_OK; i0 += batch, n_batches++) {
         const int half = n_batches & 1;
         const int nb = n_frames - i0 < batch ? n_frames - i0 : batch;
-        if (overlap && n_batches >= 2 && hipStreamWaitEvent(cs, copied[half], 0) != hipSuccess) { rc = fail(KBE_E_LAUNCH, "hipStreamWaitEvent"); break; }
-        for (int k = 0; k < nb && rc == KBE_OK; k++) {
-            const int i = i0 + k;
-            uint8_t* out = ring[half] + (size_t) k * fb;
-            rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scratch,
-                                         crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
-                                         stream);
-            if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, stream);
-        }
+        if (copied[half] && n_batches >= 2)
+            for (int l = 0; l < lanes; l++) if (ls[l] != ds) (void) hipStreamWaitEvent(ls[l], copied[half], 0);    // the half is free again
+        for (int k = 0; k < nb && rc == KBE_OK; k++) rc = frame(i0 + k, ring[half] + (size_t) k * fb);
         if (rc != KBE_OK) break;
-        if (overlap) {
-            (void) hipEventRecord(rendered[half], cs);
-            (void) hipStreamWaitEvent(ds, rendered[half], 0);
+        for (int l = 0; l < lanes; l++) {
+            if (ls[l] == ds) continue;                                  // same stream as the transfer: ordered anyway
+            (void) hipEventRecord(rendered[half][l], ls[l]);
+            (void) hipStreamWaitEvent(ds, rendered[half][l], 0);
         }
         const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, ring[half], (size_t) nb * fb, hipMemcpyDeviceToHost, ds);
         if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
-        if (overlap) (void) hipEventRecord(copied[half], ds);
+        if (copied[half]) (void) hipEventRecord(copied[half], ds);
     }
-    if (overlap) {
-        // whoever synchronises `stream` also sees every frame in host memory
-        for (int b = 0; b < 2 && b < n_batches; b++) (void) hipStreamWaitEvent(cs, copied[(n_batches - 1 - b) & 1], 0);
-        for (int b = 0; b < 2; b++) { (void) hipEventDestroy(rendered[b]); (void) hipEventDestroy(copied[b]); }
-    }
+    // whoever synchronises `stream` also sees every frame in host memory (and every lane idle)
+    if (overlap) for (int b = 0; b < 2 && b < n_batches; b++) (void) hipStreamWaitEvent(cs, copied[(n_batches - 1 - b) & 1], 0);
+    destroy();
     return rc;
 }
 
