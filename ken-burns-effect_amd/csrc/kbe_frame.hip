@@ -808,19 +808,31 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
             // left the box of valid pixels for good?
             done = done || (ix < bx0 && ddx <= 0.0f) || (ix > bx1 && ddx >= 0.0f) || (iy < by0 && ddy <= 0.0f) || (iy > by1 && ddy >= 0.0f);
         };
-        while (!done) walk(std::integral_constant<int, 8>());
-        // both ends of my direction
-        const int ox = __shfl_xor(ix, 1), oy = __shfl_xor(iy, 1);
-        const bool ook = (bool) __shfl_xor((int) ok, 1);
-        float dist = INFINITY;
-        if (ok && ook) {
+        // Branch and bound over the 16 directions (exact).  The winner is the direction whose two hits are
+        // STRICTLY closest (:900, first direction on ties).  The two ends of a direction move apart monotonically,
+        // so the distance between their CURRENT positions, computed with the arithmetic of :898, bounds the
+        // distance between their eventual hits from below (fp32 multiply, add and sqrt are monotone).  Once a
+        // direction is complete, every direction whose bound already exceeds it can stop: it could never be
+        // strictly shorter.  A hole in a thin disocclusion strip thus costs the 2-3 steps across the strip, not
+        // the hundreds along it, and a wide hole the walk to its nearest rim, not to its farthest.
+        int ox = 0, oy = 0;
+        bool ook = false;
+        float dist = INFINITY, best = INFINITY;
+        for (;;) {
+            if (!done) walk(std::integral_constant<int, 8>());
+            ox = __shfl_xor(ix, 1); oy = __shfl_xor(iy, 1);     // the other end of my direction
+            ook = (bool) __shfl_xor((int) ok, 1);
+            const bool odone = (bool) __shfl_xor((int) done, 1);
             const float ex = (float) (ix - ox), ey = (float) (iy - oy);
-            const float t = sqrtf(ex * ex + ey * ey);           // :898
-            if (1000000.0f > t) dist = t;                       // :854 + :900 against the initial dblShortest
-        }
-        float best = dist;
+            const float cur = sqrtf(ex * ex + ey * ey);         // :898 on the current positions
+            dist = (ok && ook && 1000000.0f > cur) ? cur : INFINITY;    // :854 + :900 against the initial dblShortest
+            best = dist;
 #pragma unroll
-        for (int off = 2; off < 32; off <<= 1) best = fminf(best, __shfl_xor(best, off));
+            for (int off = 2; off < 32; off <<= 1) best = fminf(best, __shfl_xor(best, off));
+            // stop: the other end is hopeless (:884-885, :895-896), or this direction can no longer win
+            done = done || (odone && !ook) || cur > best;
+            if (__all(done)) break;
+        }
         if (best == INFINITY) continue;                         // unfillable: keeps the rendered value (:913-919)
         const unsigned long long m = __ballot(dist == best);
         const unsigned mine = (unsigned) (m >> (threadIdx.x & 32));     // my 32-lane half

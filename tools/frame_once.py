@@ -15,8 +15,9 @@ if os.environ.get('KBE_LIB_PATH'):          # a variant build (tools/gpu_variant
 
 size = int(os.environ.get('SIZE', '1024'))
 n = int(os.environ.get('FRAMES', '9'))
-ofrom, oto = synthetic.default_windows(size, size, False)
-settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False}
-oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint', settings)
+dolly = os.environ.get('DOLLY', '0') == '1'
+ofrom, oto = synthetic.default_windows(size, size, dolly)
+settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
+oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly, settings)
 frames = common.render_frames(common.frame_cameras(settings, oc), oc, common.crop_size(settings), overlap=False)
 print(frames.shape, oc['tensorInpaPoints'].shape[-1])

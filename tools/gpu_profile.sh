@@ -22,6 +22,6 @@ done
 python $R/tools/pmc_report.py /tmp/pm_FETCH_SIZE/c_counter_collection.csv /tmp/pm_WRITE_SIZE/c_counter_collection.csv > $OUT/hbm_traffic.json
 # 4. a clean trace of 33 frames (no bench differencing, nothing else on the device): per-kernel medians
 rm -rf /tmp/o
-FRAMES=33 timeout 600 rocprofv3 --kernel-trace -d /tmp/o -o t --output-format csv -- python $R/tools/frame_once.py > /dev/null 2>&1
+KBE_LANES=1 FRAMES=33 timeout 600 rocprofv3 --kernel-trace -d /tmp/o -o t --output-format csv -- python $R/tools/frame_once.py > /dev/null 2>&1
 python $R/tools/kernel_times.py /tmp/o/t_kernel_trace.csv > $OUT/frame_loop_kernel_medians.txt
 ls -la $OUT; cat $OUT/bench.json; cat $OUT/frame_loop_kernel_medians.txt; head -12 $OUT/bench_kernel_stats.csv

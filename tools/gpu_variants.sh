@@ -10,8 +10,9 @@ for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -I$R/include -I$R/ken-burns-effect_amd/csrc $flags \
       $R/ken-burns-effect_amd/csrc/kbe_hip.hip $R/ken-burns-effect_amd/csrc/kbe_frame.hip -o $so || exit 1
   rm -rf /tmp/t$i
-  KBE_LIB_PATH=$so FRAMES=${FRAMES:-33} timeout 600 rocprofv3 --kernel-trace -d /tmp/t$i -o t --output-format csv -- python $R/tools/frame_once.py > /tmp/t$i.log 2>&1 || tail -5 /tmp/t$i.log
+  KBE_LANES=1 KBE_LIB_PATH=$so FRAMES=${FRAMES:-33} timeout 600 rocprofv3 --kernel-trace -d /tmp/t$i -o t --output-format csv -- python $R/tools/frame_once.py > /tmp/t$i.log 2>&1 || tail -5 /tmp/t$i.log
   echo "== variant: ${flags:-(default)}"
   python $R/tools/kernel_times.py /tmp/t$i/t_kernel_trace.csv
+  KBE_LIB_PATH=$so python $R/tools/throughput.py 2>/dev/null | tail -1
   i=$((i+1))
 done
