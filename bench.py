@@ -208,11 +208,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the one exchange step of a video: the finished cloud goes from rank 0 to every rank (RCCL broadcast).  It is
+    # scene set-up like build_scene above, not part of a frame step, so it is timed on its own and reported as
+    # `cloud_broadcast_ms` beside the frame rate (a video pays it once, whatever its length)
+    broadcast_ms = None
+    if world_size > 1:
+        sync()
+        t0 = time.perf_counter()
+        sharding.broadcast_cloud(oc, device)
+        sync()
+        broadcast_ms = (time.perf_counter() - t0) * 1e3
+
     def timed(run):
         sync()
         t0 = time.perf_counter()
-        if world_size > 1:
-            sharding.broadcast_cloud(oc, device)      # the one exchange step of a video, inside the timed region
         out = run()
         sync()
         dt = time.perf_counter() - t0
@@ -236,6 +245,8 @@ def main():
         assert frames_h.shape == (args.steps, size, size, 3)
 
     if rank == 0:
+        from ken_burns_effect_amd import _native
+        lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
         kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]))
         HW = size * size
         # Dominant kernel: k_tiles = degrid + z-tested accumulate + normalise (+ uint8) of one frame, i.e. the
@@ -262,12 +273,17 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%dx%d %s camera path, %d points (%s cloud), per frame: shift+zsplat+degrid+accumulate+fill+u8%s, frames left in HBM'
                                    % (size, size, 'dolly' if args.dolly else 'KBE', n_points, args.cloud, '' if crop is None else '+crop/resize'),
-                       'frames_per_rank': args.steps, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast'},
+                       'frames_per_rank': args.steps, 'lanes': lanes, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast (untimed set-up, see cloud_broadcast_ms)'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes': tiles_bytes, 'scatter': scatter,
+                         'note': 'kernel timed alone on one stream (HIP events); the matching rocprofv3 --stats summary is the one taken with '
+                                 'KBE_LANES=1 (profiles/): in the timed region the kernels of %d frames overlap on %d streams and per-kernel '
+                                 'durations stretch' % (lanes, lanes),
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
+        if broadcast_ms is not None:
+            line['cloud_broadcast_ms'] = broadcast_ms
         if elapsed_h is not None:
           line['host_delivery'] = {'value': args.steps * world_size / elapsed_h, 'unit': 'frames/s', 'ms_per_step': elapsed_h / args.steps * 1e3,
                                  'note': 'same K frames copied to pinned host memory (PCIe D2H of %.1f MB per frame, %d frames per transfer, second stream)'

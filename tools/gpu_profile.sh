@@ -14,6 +14,13 @@ rm -rf /tmp/ks
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks -o b --output-format csv -- python $R/bench.py --no-cpu-baseline 2> $OUT/rocprof.err | tail -1 > $OUT/bench_under_rocprof.json
 cp /tmp/ks/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
 python $R/tools/kernel_times.py /tmp/ks/b_kernel_trace.csv > $OUT/bench_kernel_medians.txt
+# 2b. the same with one lane (KBE_LANES=1): kernels never overlap, so the per-kernel averages are those of isolated launches
+rm -rf /tmp/ks1
+KBE_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks1 -o b --output-format csv -- python $R/bench.py --no-cpu-baseline 2>> $OUT/rocprof.err | tail -1 > $OUT/bench_lanes1_under_rocprof.json
+cp /tmp/ks1/b_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv
+python $R/tools/kernel_times.py /tmp/ks1/b_kernel_trace.csv > $OUT/bench_lanes1_kernel_medians.txt
+# 2c. multi-rank code path on this one GPU (gloo; ranks share the device: a functional check, not a measurement)
+KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 32 --warmup 4 2>> $OUT/bench.err | tail -1 > $OUT/bench_2ranks_gloo_one_gpu.json
 # 3. HBM traffic: one PMC pass per counter (no trace domains alongside)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c
@@ -24,4 +31,4 @@ python $R/tools/pmc_report.py /tmp/pm_FETCH_SIZE/c_counter_collection.csv /tmp/p
 rm -rf /tmp/o
 KBE_LANES=1 FRAMES=33 timeout 600 rocprofv3 --kernel-trace -d /tmp/o -o t --output-format csv -- python $R/tools/frame_once.py > /dev/null 2>&1
 python $R/tools/kernel_times.py /tmp/o/t_kernel_trace.csv > $OUT/frame_loop_kernel_medians.txt
-ls -la $OUT; cat $OUT/bench.json; cat $OUT/frame_loop_kernel_medians.txt; head -12 $OUT/bench_kernel_stats.csv
+ls -la $OUT; cat $OUT/bench.json; cat $OUT/frame_loop_kernel_medians.txt; grep -E 'k_tiles|k_project|k_fill_holes|k_crop' $OUT/bench_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv | cut -c1-200; cat $OUT/bench_2ranks_gloo_one_gpu.json | cut -c1-300
