@@ -175,7 +175,7 @@ class HipKernels:
         return out
 
     # -- the frame loop on the resident cloud ---------------------------------------------
-    def prepare_cloud(self, points, image, depth, W, H, focal=None):
+    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None):
         """Makes tensorInpaPoints/Image/Depth resident for the frame loop: contiguous fp32 views (used in
         place, no repacking) plus the per-view scratch (z-buffer, tile buckets, hole list), initialised
         once.  Returns the state render_frame consumes."""
@@ -186,6 +186,8 @@ class HipKernels:
                  'N': N, 'W': W, 'H': H, 'frame': torch.empty(H, W, 3, dtype=torch.uint8, device=dev),
                  # layout hint: process_kenburns' cloud starts with the W x H image raster (common.py:176-179)
                  'raster_w': W if N >= W * H else 0, 'raster_n': W * H if N >= W * H else 0}
+        if raster is not None:          # (width, count): the cloud starts with a row-major raster of another shape
+            state['raster_w'], state['raster_n'] = int(raster[0]), int(raster[1])
         if os.environ.get('KBE_NO_RASTER_HINT'):
             state['raster_w'] = state['raster_n'] = 0
         # one scratch per lane of the frame loop (render_video renders consecutive frames on `lanes` streams);

@@ -280,7 +280,7 @@ def _prepared_cloud(K, objectCommon):
     cached = objectCommon.get('_kbePreparedCloud')
     if cached is None or cached[0] != key:
         state = K.prepare_cloud(tensors[0], tensors[1], tensors[2], objectCommon['intWidth'], objectCommon['intHeight'],
-                                objectCommon['dblFocal'])
+                                objectCommon['dblFocal'], raster=objectCommon.get('_kbeCloudRaster'))
         cached = (key, state, tensors)        # keeps the tensors alive so that data_ptr stays a valid identity
         objectCommon['_kbePreparedCloud'] = cached
     return cached[1]

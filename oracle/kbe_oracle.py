@@ -249,7 +249,7 @@ class OracleKernels:
     def frame_u8(self, render):
         return torch.from_numpy(frame_u8(render[0]))
 
-    def prepare_cloud(self, points, image, depth, W, H, focal=None):
+    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None):
         return {'points': _f32(points).reshape(1, 3, -1), 'image': _f32(image).reshape(1, 3, -1),
                 'depth': _f32(depth).reshape(1, 1, -1), 'W': int(W), 'H': int(H)}
 
