@@ -153,18 +153,20 @@ __device__ __forceinline__ TileGroup group_by_tile(bool want, int tile)
     return g;
 }
 
-#ifndef KBE_PTS_PER_THREAD
-#define KBE_PTS_PER_THREAD 1
-#endif
-constexpr int PTS_PER_THREAD = KBE_PTS_PER_THREAD;      // independent points per lane: their atomics overlap in flight
-constexpr int UNIT = 64 * PTS_PER_THREAD;               // points per wave unit
-constexpr int PATCH_ROWS = 2 * PTS_PER_THREAD;          // a raster unit is a 32 x PATCH_ROWS patch
+constexpr int UNIT = 64;                // points per wave unit: one per lane (4 per lane needed 98-118 VGPRs, halved the
+                                        // occupancy and doubled the time of this kernel; 2 per lane measured 9 % slower)
+constexpr int PATCH_ROWS = 2;           // a raster unit is a 32 x 2 patch
 
-// One wave handles 256 consecutive points; lane l takes l, l+64, l+128, l+192 (coalesced loads).
-// The bucket appends are organised so that ALL counter atomics of a wave are in flight together
-// (a returning global atomic is a ~2 us round trip; issued one after the other they made this
-// launch 60 us long): first every (point, tile) pair is grouped, then the group leaders fire
-// their atomicAdd back to back, then the results are consumed.
+// One wave handles units of 64 points, one per lane.  Per unit: load, shift (common.py:104-109), project
+// (:447-468), then -- as soon as the image position is known -- the bucket bookkeeping: the point goes to the
+// bucket of the tile of its north-west corner (e = 0) and, when that corner sits in a tile's last column (or at
+// -1, just outside), also to the east neighbour (e = 1); the lanes of a wave share very few target tiles, so they
+// are grouped and one leader per tile bumps the counter for all of them.  A returning global atomic is a ~2 us
+// round trip (probe: with the results unused this launch is 3.8 us shorter), so all counter atomics of the round
+// are issued back to back and the rest of the point's work -- weights (:472-484), dblError (:470), winner corner
+// and the z-splat atomic umin (:486-506) -- is done while they are in flight; only then are the results consumed
+// and the 16-byte records stored.  Points whose corner also sits in a tile's last ROW need a second round
+// (south, south-east); ~6 % of the waves of a raster.
 __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -175,116 +177,107 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
     const Camera& cam = a.cam;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.hole_count = 0;
     const size_t N = (size_t) a.N;
-    // Work units of UNIT points per wave.  Where the cloud is known to start with a row-major raster (the image
-    // pixels), a unit is a 32 x PATCH_ROWS patch of it rather than UNIT consecutive pixels of a row: its points
-    // then fall into one or two target tiles, and a bucket's records reference neighbouring points.  Pure speed
-    // hint.  (One point per lane: 4 per lane needed 98-118 VGPRs, halved the occupancy of this kernel and doubled
-    // its time; 2 per lane measured 9 % slower.)
+    // Work units.  Where the cloud is known to start with a row-major raster (the image pixels), a unit is a
+    // 32 x 2 patch of it rather than 64 consecutive pixels of a row: its points then fall into one or two target
+    // tiles, and a bucket's records reference neighbouring points.  Pure speed hint.
     const unsigned patches_x = (a.raster_w > 0 && a.raster_w % 32 == 0) ? (unsigned) a.raster_w / 32u : 0u;
     const unsigned patch_rows = patches_x ? ((unsigned) a.raster_n / (unsigned) a.raster_w) / PATCH_ROWS : 0u;
     const unsigned n_patches = patches_x * patch_rows;                  // <= N / UNIT
     const unsigned lin0 = n_patches * UNIT;                             // points before lin0 are covered by patches
     const unsigned n_units = n_patches + ((unsigned) a.N - lin0 + UNIT - 1) / UNIT;
     for (unsigned unit = (unsigned) wave; unit < n_units; unit += (unsigned) n_waves) {
-        float4 rec[PTS_PER_THREAD];
-        bool ok[PTS_PER_THREAD], spx[PTS_PER_THREAD], spy[PTS_PER_THREAD];
-#pragma unroll
-        for (int j = 0; j < PTS_PER_THREAD; j++) {
-            unsigned i;
-            if (unit < n_patches) {
-                const unsigned pyb = unit / patches_x, pxb = unit - pyb * patches_x;
-                i = (pyb * PATCH_ROWS + (unsigned) (lane >> 5) + 2u * j) * (unsigned) a.raster_w + pxb * 32u + (unsigned) (lane & 31);
-            } else {
-                i = lin0 + (unit - n_patches) * UNIT + (unsigned) lane + 64u * j;
-            }
-            ok[j] = i < (unsigned) a.N;
-            float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f, err = 0.0f;
-            if (ok[j]) {
-                x = a.points[i]; y = a.points[N + i]; z = a.points[2 * N + i];
-                apply_shift(cam, x, y, z);
-                ok[j] = project_xy(cam, x, y, z, ox, oy);
-            }
-            Proj p;
-            p.nwx = p.nwy = 0;
-            if (ok[j]) {
-                project_weights(ox, oy, p);
-                ok[j] = (p.nwx + 1 >= 0) & (p.nwx < cam.W) & (p.nwy + 1 >= 0) & (p.nwy < cam.H);   // touches the image at all
-            }
-            if (ok[j]) {
-#if defined(KBE_PROBE_EXACT_ERR)
-                err = project_err(cam, z);
-#else
-                err = project_err_fast(cam, z);
-#endif
-                const int k = winner_corner(p);                 // common.py:486-506
-                if (k >= 0) {
-                    const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-#if !defined(KBE_PROBE_NO_ZSPLAT)
-                    if (inside(cx, cy, cam.W, cam.H)) atomicMin(&a.zkeys[(size_t) cy * cam.W + cx], zkey_encode(err));
-#endif
-                }
-            }
-            rec[j] = make_float4(ox, oy, err, __int_as_float((int) i));
-            // buckets: the tile of the north-west corner, plus the neighbour the east / south corners
-            // spill into when that corner sits in a tile's last column / row (or at -1, just outside)
-            spx[j] = ok[j] && ((p.nwx + 1) % TW == 0);
-            spy[j] = ok[j] && ((p.nwy + 1) % TH == 0);
+        unsigned i;
+        if (unit < n_patches) {
+            const unsigned pyb = unit / patches_x, pxb = unit - pyb * patches_x;
+            i = (pyb * PATCH_ROWS + (unsigned) (lane >> 5)) * (unsigned) a.raster_w + pxb * 32u + (unsigned) (lane & 31);
+        } else {
+            i = lin0 + (unit - n_patches) * UNIT + (unsigned) lane;
         }
-        // The point goes to the bucket of its north-west corner's tile (c = 0) and, when that corner sits in a
-        // tile's last column / row, to the east / south / south-east neighbour (c = 1, 2, 3).  The lanes of a
-        // wave share very few target tiles, so they are grouped and one leader per tile bumps the counter for
-        // all of them.  Two rounds -- {own, east}, then {south, south-east} only for the few waves that need
-        // it -- keep the live state at 2 groups per point: holding all four at once cost 118 VGPRs, halved the
-        // occupancy of this latency-bound kernel and doubled its time.  Within a round every counter atomic
-        // is issued before any result is consumed.
+        bool ok = i < (unsigned) a.N;
+        float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f;
+        if (ok) {
+            x = a.points[i]; y = a.points[N + i]; z = a.points[2 * N + i];
+            apply_shift(cam, x, y, z);
+            ok = project_xy(cam, x, y, z, ox, oy);
+        }
+        Proj p;
+        p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
+        ok = ok && (p.nwx + 1 >= 0) & (p.nwx < cam.W) & (p.nwy + 1 >= 0) & (p.nwy < cam.H);       // touches the image at all
+        const bool spx = ok && ((p.nwx + 1) % TW == 0), spy = ok && ((p.nwy + 1) % TH == 0);
+        const int tx0 = p.nwx >= 0 ? p.nwx / TW : -1, ty0 = p.nwy >= 0 ? p.nwy / TH : -1;          // nw >= -1 when ok
+
+        // round 0: own tile and east neighbour; the counter atomics go out now
+        TileGroup grp[2];
+        int tgt[2], base[2];
+        bool want[2];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            if (half == 1) {
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < PTS_PER_THREAD; j++) any |= spy[j];
-                if (__ballot(any) == 0) break;                  // wave-uniform
-            }
-            TileGroup grp[PTS_PER_THREAD][2];
-            int tgt[PTS_PER_THREAD][2], base[PTS_PER_THREAD][2];
-            bool want[PTS_PER_THREAD][2];
-#pragma unroll
-            for (int j = 0; j < PTS_PER_THREAD; j++) {
-                const int nwx = (int) floorf(rec[j].x), nwy = (int) floorf(rec[j].y);      // >= -1 when ok
-                const int tx0 = nwx >= 0 ? nwx / TW : -1, ty0 = (nwy >= 0 ? nwy / TH : -1) + half;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int tx = tx0 + e;
-                    want[j][e] = ok[j] && (e == 0 || spx[j]) && (half == 0 || spy[j]) && tx >= 0 && ty0 >= 0 && tx < a.tiles_x &&
-                                 ty0 < a.tiles_y;
+        for (int e = 0; e < 2; e++) {
+            const int tx = tx0 + e;
+            want[e] = ok && (e == 0 || spx) && tx >= 0 && ty0 >= 0 && tx < a.tiles_x && ty0 < a.tiles_y;
 #if defined(KBE_PROBE_NO_SPILLS)
-                    if (half + e > 0) want[j][e] = false;
+            if (e > 0) want[e] = false;
 #endif
 #if defined(KBE_PROBE_NO_BUCKETS)
-                    want[j][e] = false;
+            want[e] = false;
 #endif
-                    tgt[j][e] = ty0 * a.tiles_x + tx;
-                    grp[j][e] = group_by_tile(want[j][e], tgt[j][e]);
-                    base[j][e] = 0;
-                }
+            tgt[e] = ty0 * a.tiles_x + tx;
+            grp[e] = group_by_tile(want[e], tgt[e]);
+            base[e] = 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
+
+        // ... and while they are in flight: weights, dblError, winner corner, z-splat
+        float err = 0.0f;
+        if (ok) {
+            project_weights(ox, oy, p);
+#if defined(KBE_PROBE_EXACT_ERR)
+            err = project_err(cam, z);
+#else
+            err = project_err_fast(cam, z);
+#endif
+            const int k = winner_corner(p);                             // common.py:486-506
+            if (k >= 0) {
+                const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+#if !defined(KBE_PROBE_NO_ZSPLAT)
+                if (inside(cx, cy, cam.W, cam.H)) atomicMin(&a.zkeys[(size_t) cy * cam.W + cx], zkey_encode(err));
+#endif
+            }
+        }
+        const float4 rec = make_float4(ox, oy, err, __int_as_float((int) i));
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int b0 = __shfl(base[e], grp[e].leader);
+            if (want[e]) {
+                const int slot = b0 + __popcll(grp[e].same & ((1ull << lane) - 1ull));
+                if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[e] * BUCKET_STRIDE + slot] = rec;    // beyond: the tile sees count > cap
+            }
+        }
+        // round 1 (rare): south and south-east neighbours
+#if !defined(KBE_PROBE_NO_SPILLS) && !defined(KBE_PROBE_NO_BUCKETS)
+        if (__ballot(spy) != 0ull) {                                    // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int tx = tx0 + e, ty = ty0 + 1;
+                want[e] = spy && (e == 0 || spx) && tx >= 0 && ty >= 0 && tx < a.tiles_x && ty < a.tiles_y;
+                tgt[e] = ty * a.tiles_x + tx;
+                grp[e] = group_by_tile(want[e], tgt[e]);
+                base[e] = 0;
             }
 #pragma unroll
-            for (int j = 0; j < PTS_PER_THREAD; j++)
+            for (int e = 0; e < 2; e++)
+                if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
 #pragma unroll
-                for (int e = 0; e < 2; e++)
-                    if (want[j][e] && lane == grp[j][e].leader)
-                        base[j][e] = atomicAdd(&a.tile_count[tgt[j][e] * CNT_STRIDE], __popcll(grp[j][e].same));
-#pragma unroll
-            for (int j = 0; j < PTS_PER_THREAD; j++)
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int b0 = __shfl(base[j][e], grp[j][e].leader);
-                    if (want[j][e]) {
-                        const int slot = b0 + __popcll(grp[j][e].same & ((1ull << lane) - 1ull));
-                        if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[j][e] * BUCKET_STRIDE + slot] = rec[j];   // beyond: the tile sees count > cap
-                    }
+            for (int e = 0; e < 2; e++) {
+                const int b0 = __shfl(base[e], grp[e].leader);
+                if (want[e]) {
+                    const int slot = b0 + __popcll(grp[e].same & ((1ull << lane) - 1ull));
+                    if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[e] * BUCKET_STRIDE + slot] = rec;
                 }
+            }
         }
+#endif
     }
 }
 
@@ -895,7 +888,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
 #ifndef KBE_PROJECT_MAX_BLOCKS
 #define KBE_PROJECT_MAX_BLOCKS 1000000
 #endif
-        unsigned blocks = N > 0 ? blocks_for((size_t) N, 256 * PTS_PER_THREAD) + 2 : 1;
+        unsigned blocks = N > 0 ? blocks_for((size_t) N, 256) + 2 : 1;
         if (blocks > KBE_PROJECT_MAX_BLOCKS) blocks = KBE_PROJECT_MAX_BLOCKS;
         hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, p);
         if ((rc = launched("kbe_render_frame/project"))) return rc;
