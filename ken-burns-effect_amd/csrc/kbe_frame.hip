@@ -645,6 +645,16 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         {   // validity bits: each 32-lane half of the wave holds 32 consecutive pixels of one row
             const unsigned long long vm = __ballot(valid[m]);
             if ((lane & 31) == 0 && in) a.mask[(size_t) y * ((W + 31) >> 5) + (x >> 5)] = (uint32_t) (vm >> (lane & 32));
+            // bounding box of the valid pixels (depth > 0), which lets the hole fill discard rays that can never hit
+            // one: straight from the ballot, on the scalar unit (as a 6-step butterfly of 4 values it was 24
+            // cross-lane operations per thread).  TW == 32: the low half of the wave is row `wrow`, the high half the next.
+            static_assert(TW == 32, "a wave holds two tile rows");
+            const uint32_t lo = (uint32_t) vm, hi = (uint32_t) (vm >> 32), any = lo | hi;
+            if (any) {                                                  // wave-uniform
+                const int wrow = y0 + ((tid >> 6) << 1) + m * (TILE_THREADS / TW);
+                vx0 = min(vx0, x0 + __builtin_ctz(any)); vx1 = max(vx1, x0 + 31 - __builtin_clz(any));
+                vy0 = min(vy0, lo ? wrow : wrow + 1); vy1 = max(vy1, hi ? wrow + 1 : wrow);
+            }
         }
         if (in) {
             const size_t o = (size_t) y * W + x;
@@ -654,15 +664,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #endif
             if (a.existing) a.existing[o] = acc[m][4];
         }
-        // bounding box of the valid pixels (depth > 0): lets the hole fill discard rays that can never hit one
-        if (valid[m]) { vx0 = min(vx0, x); vy0 = min(vy0, y); vx1 = max(vx1, x); vy1 = max(vy1, y); }
     }
     {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            vx0 = min(vx0, __shfl_xor(vx0, off)); vy0 = min(vy0, __shfl_xor(vy0, off));
-            vx1 = max(vx1, __shfl_xor(vx1, off)); vy1 = max(vy1, __shfl_xor(vy1, off));
-        }
         // per-wave boxes meet in LDS (the bin heads are dead by now), one plain 16-byte store per tile;
         // global atomics here -- even one cache line per tile row, even with a look first -- serialised so
         // badly across XCDs that they added 80-350 us per frame
