@@ -24,7 +24,7 @@ def main():
     variants = sys.argv[1:] or ['']
     for i, flags in enumerate(variants):
         so = '/tmp/libkbe_probe_%d.so' % i
-        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-fvisibility=hidden',
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared', '-fvisibility=hidden',
                '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + flags.split() + \
               [os.path.join(CSRC, 'kbe_hip.hip'), os.path.join(CSRC, 'kbe_frame.hip'), '-o', so]
         subprocess.check_call(cmd)
