@@ -787,22 +787,28 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
             constexpr int kBatch = decltype(batch_tag)::value;
             int bx[kBatch], by[kBatch];
             uint32_t bw[kBatch];
+            bool bin[kBatch];
+            // branch-free: a step outside the image reads word 0 and is flagged; nothing below sits under a branch
+            // (this kernel is instruction-bound on frames with many holes: ~30 instructions per step instead of ~40)
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 fx += ddx; bx[k] = (int) roundf(fx);
                 fy += ddy; by[k] = (int) roundf(fy);
-                const bool in = (bx[k] >= 0) & (bx[k] < W) & (by[k] >= 0) & (by[k] < H);
-                bw[k] = in ? mask[(size_t) by[k] * wpr + (bx[k] >> 5)] : 0u;
+                bin[k] = ((unsigned) bx[k] < (unsigned) W) & ((unsigned) by[k] < (unsigned) H);
+                const unsigned mi = bin[k] ? (unsigned) by[k] * (unsigned) wpr + ((unsigned) bx[k] >> 5) : 0u;
+                bw[k] = mask[mi];
             }
+            bool stop = false;                                          // a step of this batch ended the walk
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
-                if (done) continue;
-                ix = bx[k]; iy = by[k];
-                if ((ix < 0) | (ix >= W) | (iy < 0) | (iy >= H)) { done = true; continue; }
-                if ((bw[k] >> (ix & 31)) & 1u) { ok = true; done = true; }      // depth > 0 (common.py:882 / :893)
+                const bool hit = bin[k] && ((bw[k] >> (bx[k] & 31)) & 1u);      // depth > 0 (common.py:882 / :893)
+                const bool take = !stop;                                // the first ending step fixes position and outcome
+                ix = take ? bx[k] : ix; iy = take ? by[k] : iy;
+                ok = ok || (take && hit);
+                stop = stop || hit || !bin[k];
             }
-            // left the box of valid pixels for good?
-            done = done || (ix < bx0 && ddx <= 0.0f) || (ix > bx1 && ddx >= 0.0f) || (iy < by0 && ddy <= 0.0f) || (iy > by1 && ddy >= 0.0f);
+            // ended, or left the box of valid pixels for good?
+            done = stop || (ix < bx0 && ddx <= 0.0f) || (ix > bx1 && ddx >= 0.0f) || (iy < by0 && ddy <= 0.0f) || (iy > by1 && ddy >= 0.0f);
         };
         // Branch and bound over the 16 directions (exact).  The winner is the direction whose two hits are
         // STRICTLY closest (:900, first direction on ties).  The two ends of a direction move apart monotonically,
