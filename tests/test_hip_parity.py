@@ -442,3 +442,50 @@ def test_invalid_arguments_return_errors_not_crashes(K):
     assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, ctypes.c_void_p(8), None, None) == -1
     assert b'kbe_zsplat' in K.lib.kbe_last_error()
     assert K.lib.kbe_spatial_filter(ctypes.c_void_p(8), 1, 4, 4, 7, ctypes.c_void_p(8), None) == -1
+
+
+@pytest.mark.gpu
+def test_lanes_and_raster_hints_only_change_speed(K, oracle, monkeypatch):
+    """The frame loop spreads consecutive frames over KBE_LANES streams with their own scratch, and k_project
+    walks the cloud in patches of a hinted raster: neither may change a frame (up to the accumulation order)."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene((96, 160), 11)
+    settings = dict(settings, dblSteps=[i / 8.0 for i in range(9)])
+    cams = common.frame_cameras(settings, oc)
+    crop = common.crop_size(settings)
+    frames = {}
+    for lanes in ('1', '2', '4'):
+        monkeypatch.setenv('KBE_LANES', lanes)
+        oc.pop('_kbePreparedCloud', None)
+        frames[lanes] = common.render_frames(cams, oc, crop)
+        assert common._prepared_cloud(K, oc)['lanes'] == int(lanes)
+    for hint in ((32, 32 * 96), (64, 64 * 10), None):             # other raster shapes (every point is still visited once)
+        oc.pop('_kbePreparedCloud', None)
+        oc['_kbeCloudRaster'] = hint
+        frames[str(hint)] = common.render_frames(cams, oc, crop)
+    oc.pop('_kbeCloudRaster', None)
+    ref = frames['1']
+    for key, f in frames.items():
+        d = np.abs(ref.astype(np.int32) - f.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, key
+
+
+@pytest.mark.gpu
+def test_denser_than_raster_cloud_matches_oracle(K, oracle):
+    """BASELINE.json configs[4] in small: a cloud 4x denser than the target raster (several points per pixel,
+    sub-pixel positions), tiled renderer against the oracle."""
+    from ken_burns_effect_amd import common, synthetic
+    H, W, up = 64, 96, 2
+    image, disp = synthetic.make_rgbd(H * up, W * up, 3)
+    depth = (synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)
+    pts = K.depth_to_points(depth.cuda(), synthetic.FOCAL * up).view(1, 3, -1)
+    img, dep = image.cuda().reshape(1, 3, -1), depth.cuda().reshape(1, 1, -1)
+    state = K.prepare_cloud(pts, img, dep, W, H, raster=(W * up, W * up * H * up))
+    shift3 = (3.0, -2.0, 8.0)
+    rf = torch.empty(4, H, W, device='cuda')
+    frame = c(K.render_frame(state, shift3, synthetic.FOCAL, synthetic.BASELINE, render_f32=rf))
+    ok = oracle.OracleKernels('jacobi')
+    ostate = ok.prepare_cloud(pts.cpu(), img.cpu(), dep.cpu(), W, H)
+    oframe = ok.render_frame(ostate, shift3, synthetic.FOCAL, synthetic.BASELINE).numpy()
+    d = np.abs(frame.astype(np.int32) - oframe.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
