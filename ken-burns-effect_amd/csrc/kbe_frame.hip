@@ -314,6 +314,11 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// a pixel's five accumulators; r|g and b|depth as pairs so that they update with packed fp32 instructions
+struct PixAcc { f2 rg, bd; float w; };
+
 struct TileLds {
     float4 rec[REC_CAP];        // ox, oy, dblError, next record (int bits)
     float4 rgbd[REC_CAP];       // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
@@ -355,7 +360,7 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 // `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
 template <bool FAST>
 __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int tid, int x0, int y0,
-                                       float (&acc)[PIX_PER_THREAD][5])
+                                       PixAcc (&acc)[PIX_PER_THREAD])
 {
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
@@ -375,11 +380,10 @@ __device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int 
             const float wx = (k & 1) ? (r.x - (Xf - 1.0f)) : ((Xf + 1.0f) - r.x);          // k & 1 ? ox - fx : ex - ox
             const float wy = (k >> 1) ? (r.y - (Yf - 1.0f)) : ((Yf + 1.0f) - r.y);
             const float w = pass ? wx * wy : 0.0f;
-            acc[m][0] += c.x * w;                                           // :641 product rounded, then added
-            acc[m][1] += c.y * w;
-            acc[m][2] += c.z * w;
-            acc[m][3] += c.w * w;
-            acc[m][4] += w;                                                 // the `ones` channel (:429)
+            const f4 cv = *(const f4*) &c;
+            acc[m].rg += cv.xy * w;                                         // :641 product rounded, then added (v_pk_mul_f32, v_pk_add_f32)
+            acc[m].bd += cv.zw * w;
+            acc[m].w += w;                                                  // the `ones` channel (:429)
         };
         int nx[4];
 #pragma unroll
@@ -521,11 +525,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         }
     }
 
-    float acc[PIX_PER_THREAD][5];
+    PixAcc acc[PIX_PER_THREAD];
 #pragma unroll
-    for (int m = 0; m < PIX_PER_THREAD; m++)
-#pragma unroll
-        for (int ch = 0; ch < 5; ch++) acc[m][ch] = 0.0f;
+    for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
 
     if (bucketed) {
         // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
@@ -615,10 +617,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         const int q = tid + m * TILE_THREADS;
         const int ly = q / TW, lx = q - ly * TW;
         const bool in = x0 + lx < W && y0 + ly < H;
-        const float w = acc[m][4];
+        const float w = acc[m].w;
         const float den = w + 0.0000001f;
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) res[m][ch] = acc[m][ch] / den;
+        res[m][0] = acc[m].rg.x / den; res[m][1] = acc[m].rg.y / den; res[m][2] = acc[m].bd.x / den; res[m][3] = acc[m].bd.y / den;
         dms[m] = res[m][3] * (w > 0.0f ? 1.0f : 0.0f);
         valid[m] = in && dms[m] > 0.0f;
 #if defined(KBE_PROBE_NO_HOLES)
@@ -662,7 +663,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #if !defined(KBE_PROBE_TIMING)
             if (a.render) { a.render[o] = res[m][0]; a.render[HW + o] = res[m][1]; a.render[2 * HW + o] = res[m][2]; a.render[3 * HW + o] = res[m][3]; }
 #endif
-            if (a.existing) a.existing[o] = acc[m][4];
+            if (a.existing) a.existing[o] = acc[m].w;
         }
     }
     {
