@@ -158,7 +158,7 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=256)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--dolly', action='store_true')

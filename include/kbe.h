@@ -198,6 +198,17 @@ KBE_API int kbe_render_video(const float* points, const float* image, const floa
                              int raster_w, int raster_n, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
                              const kbe_stream_t* lane_streams);
 
+/* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where
+ * point i of points[B,3,N] + shift[B,3] (a DEVICE array, the tensorShift of :690) owns the pixel its z-splat
+ * winner corner falls on, else 0.  The reference launch is a race; this computes its serial-order result
+ * deterministically (owner = first point in index order attaining the pixel's minimal dblError; point 0, once an
+ * owner, keeps its 1: `pid > 0`, :759).  Scratch: keys [B*H*W] 64-bit (8-byte aligned), winner [B,N] int32.
+ * Optional outputs in the reference's formats: zee [B,H,W] (:692) and ids [B,H,W] (:694: owner index, or the int
+ * bits of -1.0f where no point landed). */
+KBE_API int kbe_generate_mask(const float* points, const float* shift, int B, int N, int W, int H, double focal,
+                              double baseline, unsigned long long* keys, int32_t* winner, float* masks, float* zee,
+                              int32_t* ids, kbe_stream_t stream);
+
 /* common.py:255: (render[0:3] * 255).clip(0, 255).astype(uint8), CHW fp32 -> HWC u8 */
 KBE_API int kbe_frame_u8(const float* render_chw, int W, int H, uint8_t* frame_hwc, kbe_stream_t stream);
 

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_render_video', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_render_video', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
@@ -248,6 +248,27 @@ class HipKernels:
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
                                               _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
         return host_out
+
+    def generate_mask_raw(self, points, shift, W, H, focal, baseline, want_tables=False):
+        """generate_mask's kernel (common.py:696-817) -> masks [B,1,N] (and zee [B,1,H,W], ids [B,H,W] int32)."""
+        points = _f32c(points)
+        B, _, N = points.shape
+        dev = points.device
+        shift = _f32c(shift).reshape(B, 3).to(dev)
+        keys = torch.empty(B * H * W, dtype=torch.int64, device=dev)
+        winner = torch.empty(B, max(N, 1), dtype=torch.int32, device=dev)
+        masks = torch.empty(B, 1, N, dtype=torch.float32, device=dev)
+        zee = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if want_tables else None
+        ids = torch.empty(B, H, W, dtype=torch.int32, device=dev) if want_tables else None
+        self._check(self.lib.kbe_generate_mask(_ptr(points), _ptr(shift), _i(B), _i(N), _i(int(W)), _i(int(H)), _d(float(focal)),
+                                               _d(float(baseline)), _ptr(keys, torch.int64), _ptr(winner, torch.int32), _ptr(masks),
+                                               _ptr(zee), _ptr(ids, torch.int32), _stream()), 'kbe_generate_mask')
+        return (masks, zee, ids) if want_tables else masks
+
+    def generate_mask(self, points, shift, W, H, focal, baseline):
+        """common.py:689-830: the ownership mask as an image (N == H*W), median-5 filtered (:829)."""
+        masks = self.generate_mask_raw(points, shift, W, H, focal, baseline)
+        return self.spatial_filter(masks.view(-1, 1, int(H), int(W)), 'median-5')
 
     def zkeys_clear(self, zkeys):
         self._check(self.lib.kbe_zkeys_clear(_ptr(zkeys, torch.int32), _z(zkeys.numel()), _stream()), 'kbe_zkeys_clear')

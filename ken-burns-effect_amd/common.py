@@ -73,6 +73,15 @@ def fill_disocclusion(tensorInput, tensorDepth):
 # camera path (reference: common.py:83-112 and the scalar head of both loops, :185-198 / :223-236)
 # ---------------------------------------------------------------------------------------
 
+def generate_mask(tensorInput, tensorShift, intWidth, intHeight, dblFocal, dblBaseline):
+    """Disocclusion mask of view A seen from view B (common.py:689-830): for each point of the image raster
+    ``tensorInput`` [B,3,H*W] moved by ``tensorShift`` [B,3,1], 1 where it still owns the pixel it lands on
+    (nearest point, first in index order on ties), else 0; returned as an image [B,1,H,W] after the median-5 of
+    :829.  The reference's kernel is racy; this is its serial-order result, computed deterministically
+    (include/kbe.h, kbe_generate_mask)."""
+    return _K().generate_mask(tensorInput, tensorShift, intWidth, intHeight, dblFocal, dblBaseline)
+
+
 def _shift_vector(objectSettings, objectCommon, dblFocal):
     """The three python doubles of common.py:88-100, expression for expression."""
     depthrange = objectCommon['objectDepthrange']

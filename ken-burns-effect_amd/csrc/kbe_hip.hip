@@ -74,6 +74,71 @@ __global__ void __launch_bounds__(kBlock) k_zsplat(const float* __restrict__ poi
 }
 
 // ---------------------------------------------------------------------------------------
+// generate_mask (common.py:689-830): which point owns each pixel of the z-splat.
+// The reference's single launch is a race (compare, float atomicMin, atomicExch of the owner,
+// mask updates: four separate steps per point); its serial-order result -- the oracle's -- is
+// "the owner of a pixel is the FIRST point, in index order, that attains the pixel's minimal
+// dblError" (a later point only takes over when strictly nearer, :755), a point's mask is 1 iff it
+// is a final owner, and point 0, once an owner, is never cleared (:759 tests `pid > 0`).
+// That is one native 64-bit atomic umin on (order-preserving key of dblError) << 32 | index,
+// followed by a look-up per point: deterministic, no compare-then-act window.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_mask_splat(const float* __restrict__ points, const float* __restrict__ shift, int N,
+                                                       Camera cam, unsigned long long* __restrict__ keys, int32_t* __restrict__ winner)
+{
+    const int b = blockIdx.y;
+    const float* P = points + (size_t) b * 3 * N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // common.py:690  tensorInput + tensorShift: one fp32 add per component
+    const float x = P[i] + shift[3 * b], y = P[(size_t) N + i] + shift[3 * b + 1], z = P[2 * (size_t) N + i] + shift[3 * b + 2];
+    Proj p;
+    int idx = -1;
+    if (project(cam, x, y, z, p)) {
+        const int c = winner_corner(p);
+        if (c >= 0) {
+            const int cx = p.nwx + (c & 1), cy = p.nwy + (c >> 1);
+            // :755 `zee > dblError` against the initial 1e6: a point at or beyond it never owns anything
+            if (inside(cx, cy, cam.W, cam.H) && 1000000.0f > p.err) {
+                idx = cy * cam.W + cx;
+                atomicMin(&keys[(size_t) b * cam.H * cam.W + idx], ((unsigned long long) zkey_encode(p.err) << 32) | (unsigned) i);
+            }
+        }
+    }
+    winner[(size_t) b * N + i] = idx;
+}
+
+__global__ void __launch_bounds__(kBlock) k_mask_resolve(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ winner,
+                                                         int N, int HW, float* __restrict__ masks)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int idx = winner[(size_t) b * N + i];
+    const bool owner = idx >= 0 && (uint32_t) keys[(size_t) b * HW + idx] == (uint32_t) i;
+    masks[(size_t) b * N + i] = (owner || (i == 0 && idx >= 0)) ? 1.0f : 0.0f;
+}
+
+// optional views of the key table in the reference's own formats: zee (:692) and the owner table (:694, a float
+// tensor of -1 whose bits are used as int memory)
+__global__ void __launch_bounds__(kBlock) k_mask_tables(const unsigned long long* __restrict__ keys, size_t n, float* __restrict__ zee,
+                                                        int32_t* __restrict__ ids)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const bool hit = k != ~0ull;
+    if (zee) zee[i] = hit ? zkey_decode((uint32_t) (k >> 32)) : 1000000.0f;
+    if (ids) ids[i] = hit ? (int32_t) (uint32_t) k : (int32_t) 0xBF800000u;
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill_u64(unsigned long long* p, size_t n, unsigned long long v)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
 // kernel_pointrender_updateDegrid (common.py:525-568), out of place (Jacobi schedule)
 // ---------------------------------------------------------------------------------------
 template <bool FROM_KEYS>
@@ -532,6 +597,24 @@ int kbe_zsplat(const float* points, int B, int N, int W, int H, double focal, do
     const Camera cam = make_camera(W, H, focal, baseline, shift3);
     hipLaunchKernelGGL(k_zsplat, dim3(blocks_for(N), B), dim3(kBlock), 0, (hipStream_t) stream, points, N, cam, zkeys, winner);
     return launched("kbe_zsplat");
+}
+
+int kbe_generate_mask(const float* points, const float* shift, int B, int N, int W, int H, double focal, double baseline,
+                      unsigned long long* keys, int32_t* winner, float* masks, float* zee, int32_t* ids, kbe_stream_t stream)
+{
+    KBE_REQUIRE(B > 0 && N >= 0 && W > 0 && H > 0 && keys && ((uintptr_t) keys & 7) == 0, "kbe_generate_mask: bad arguments");
+    const hipStream_t s = (hipStream_t) stream;
+    const size_t n_pix = (size_t) B * W * H;
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned) ((n_pix + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, n_pix, ~0ull);
+    if (N > 0) {
+        KBE_REQUIRE(points && shift && winner && masks, "kbe_generate_mask: NULL buffer");
+        const Camera cam = make_camera(W, H, focal, baseline, nullptr);
+        hipLaunchKernelGGL(k_mask_splat, dim3(blocks_for(N), B), dim3(kBlock), 0, s, points, shift, N, cam, keys, winner);
+        hipLaunchKernelGGL(k_mask_resolve, dim3(blocks_for(N), B), dim3(kBlock), 0, s, keys, winner, N, W * H, masks);
+    }
+    if (zee || ids)
+        hipLaunchKernelGGL(k_mask_tables, dim3((unsigned) ((n_pix + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, n_pix, zee, ids);
+    return launched("kbe_generate_mask");
 }
 
 int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_stream_t stream)

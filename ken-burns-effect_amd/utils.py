@@ -47,3 +47,55 @@ def load_models(models_list, models_paths, continue_training=False, seed_missing
         else:
             entry['model'].load_state_dict(checkpoint)
     return iter_nb
+
+
+# ---------------------------------------------------------------------------------------
+# training-side users of the splat core (utils/utils.py:219-300 of the reference)
+# ---------------------------------------------------------------------------------------
+
+def get_item_in_dict(dict_in, idx):
+    """Item ``idx`` of every (nested) batched value (utils/utils.py:370-377)."""
+    return {k: get_item_in_dict(v, idx) if isinstance(v, dict) else v[idx] for k, v in dict_in.items()}
+
+
+def get_tensor_shift(objectCommon):
+    """Camera shift of the END pose (dblStep = 1) of ``objectCommon['zoomSettings']`` (utils/utils.py:219-245)."""
+    from . import common
+    zoom = objectCommon['zoomSettings']
+    dblFrom, dblTo = 0.0, 1.0
+    shiftU = (dblFrom * zoom['objectFrom']['dblCenterU'] + dblTo * zoom['objectTo']['dblCenterU']) - objectCommon['intWidth'] / 2.0
+    shiftV = (dblFrom * zoom['objectFrom']['dblCenterV'] + dblTo * zoom['objectTo']['dblCenterV']) - objectCommon['intHeight'] / 2.0
+    cropW = dblFrom * zoom['objectFrom']['intCropWidth'] + dblTo * zoom['objectTo']['intCropWidth']
+    depthFrom = objectCommon['objectDepthrange'][0]
+    depthTo = depthFrom * (cropW / max(zoom['objectFrom']['intCropWidth'], zoom['objectTo']['intCropWidth']))
+    _, tensorShift = common.process_shift({'tensorPoints': objectCommon['tensorRawPoints'], 'dblShiftU': shiftU, 'dblShiftV': shiftV,
+                                           'dblDepthFrom': depthFrom, 'dblDepthTo': depthTo}, objectCommon)
+    return tensorShift
+
+
+def get_masks(tensorImage, tensorDisparity, tensorDepth, zoom_settings, camera, AFromB=True, tensorContext=None):
+    """Disocclusion masks (``AFromB``) or the forward-warped view B with its hole mask, for a batch of RGBD images
+    and per-sample zoom settings (utils/utils.py:248-300).  Returns what the reference returns:
+    ``(tensorMasks, tensorShift, objectList)`` or ``(tensorRender, tensorMasks, tensorPoints, tensorShift, objectList)``."""
+    from . import common, synthetic
+    K = common._K()
+    focal, baseline = camera['focal'], camera['baseline']
+    B, _, H, W = tensorImage.shape
+    tensorValid = K.laplacian_valid(tensorDisparity, tensorDisparity.max(), 0.03)
+    tensorPoints = K.depth_to_points(tensorDepth, focal, valid=tensorValid)
+    shifts, objects = [], []
+    for idx in range(B):
+        oc = {'dblFocal': focal, 'dblBaseline': baseline, 'intWidth': W, 'intHeight': H,
+              'tensorRawImage': tensorImage[idx], 'tensorRawDisparity': tensorDisparity[idx],
+              'dblDispmin': tensorDisparity[idx].min().item(), 'dblDispmax': tensorDisparity[idx].max().item(),
+              'objectDepthrange': synthetic.depthrange_of(tensorDepth[idx:idx + 1]),
+              'tensorRawPoints': tensorPoints[idx].view(1, 3, -1), 'zoomSettings': get_item_in_dict(zoom_settings, idx)}
+        shifts.append(get_tensor_shift(oc))
+        objects.append(oc)
+    tensorShift = torch.cat(shifts)
+    flat = tensorPoints.view(B, 3, -1)
+    if AFromB:
+        return common.generate_mask(flat, tensorShift, W, H, focal, baseline), tensorShift, objects
+    data = [tensorImage, tensorDisparity] + ([tensorContext] if tensorContext is not None else [])
+    tensorRender, tensorMasks = common.render_pointcloud(flat + tensorShift, torch.cat(data, 1).view(B, -1, H * W), W, H, focal, baseline)
+    return tensorRender, (tensorMasks > 0.0).float(), flat, tensorShift, objects

@@ -128,6 +128,42 @@ KBO_API void kbo_zsplat(const float* points, int B, int N, int W, int H, double 
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* generate_mask's kernel (common.py:696-817): the z-splat of :435-507 that also records,   */
+/* per pixel, the point that currently owns it and, per point, whether it is an owner.       */
+/* Serial point order (the reference's launch is racy; this is the schedule the golden       */
+/* vectors were produced with).  points are ALREADY shifted (common.py:690 is a torch add). */
+/* zee [B,H,W] must hold 1e6, ids [B,H,W] the int bits of -1.0f (:692-694), masks [B,N] 0.    */
+/* A displaced owner is only cleared when its index is > 0 (:759 `if (pid > 0)`): point 0    */
+/* keeps its 1.  A point that loses the strict test `zee > err` (:755) gets 0 (:764).        */
+/* ------------------------------------------------------------------------------------ */
+KBO_API void kbo_generate_mask(const float* points, int B, int N, int W, int H, double focal,
+                               double baseline, int use_fma, float* zee, int32_t* ids, float* masks)
+{
+    for (int b = 0; b < B; b++) {
+        const float* P = points + (size_t) b * 3 * N;
+        float* Z = zee + (size_t) b * H * W;
+        int32_t* I = ids + (size_t) b * H * W;
+        float* M = masks + (size_t) b * N;
+        for (int i = 0; i < N; i++) {
+            kbo_proj p;
+            if (!kbo_project(P[i], P[N + i], P[2 * (size_t) N + i], focal, baseline, W, H, use_fma, &p)) continue;
+            const int c = kbo_winner(&p);
+            if (c < 0 || !kbo_inside(p.x[c], p.y[c], W, H)) continue;
+            const int idx = p.y[c] * W + p.x[c];
+            if (Z[idx] > p.err) {                       /* :755 */
+                Z[idx] = p.err;                         /* :756 atomicMin */
+                if (M[i] < 1.0f) M[i] = 1.0f;           /* :757 atomicMax(mask, 1) */
+                const int32_t pid = I[idx];             /* :758 atomicExch */
+                I[idx] = i;
+                if (pid > 0 && M[pid] > 0.0f) M[pid] = 0.0f;    /* :759-761 atomicMin(mask[pid], 0) */
+            } else if (M[i] > 0.0f) {
+                M[i] = 0.0f;                            /* :764 atomicMin(mask, 0) */
+            }
+        }
+    }
+}
+
 /* common.py:430  tensorZee ... .fill_(1000000.0) */
 KBO_API void kbo_fill_zee(float* zee, size_t n)
 {

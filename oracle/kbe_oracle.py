@@ -35,7 +35,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         for name in ('kbo_zsplat', 'kbo_fill_zee', 'kbo_degrid_serial', 'kbo_degrid_jacobi', 'kbo_accumulate',
                      'kbo_normalize', 'kbo_fill_disocclusion', 'kbo_depth_to_points', 'kbo_shift_points',
-                     'kbo_laplacian', 'kbo_median', 'kbo_frame_u8', 'kbo_pconv_epilogue'):
+                     'kbo_laplacian', 'kbo_median', 'kbo_frame_u8', 'kbo_pconv_epilogue', 'kbo_generate_mask'):
             getattr(_lib, name).restype = None
     return _lib
 
@@ -68,6 +68,26 @@ def zsplat(points, W, H, focal, baseline, use_fma=True, want_winner=False):
     lib().kbo_zsplat(_p(points), _i(B), _i(N), _i(W), _i(H), _d(float(focal)), _d(float(baseline)),
                      _i(int(use_fma)), _p(zee), _p(winner))
     return zee, winner
+
+
+def generate_mask_raw(points, shift, W, H, focal, baseline, use_fma=True):
+    """The kernel of generate_mask (common.py:696-817) on points + shift, serial point order.
+    Returns (masks[B,1,N], zee[B,1,H,W], ids[B,H,W] int32 with the bits of -1.0f where no point landed)."""
+    pts = (_f32(points) + _f32(shift).reshape(points.shape[0], 3, 1)).contiguous()      # common.py:690
+    B, _, N = pts.shape
+    zee = torch.empty(B, 1, H, W)
+    lib().kbo_fill_zee(_p(zee), _z(zee.numel()))
+    ids = torch.full((B, H, W), -1.0).view(torch.int32).contiguous()                   # :694: a float tensor used as int memory
+    masks = torch.zeros(B, 1, N)
+    lib().kbo_generate_mask(_p(pts), _i(B), _i(N), _i(W), _i(H), _d(float(focal)), _d(float(baseline)), _i(int(use_fma)),
+                            _p(zee), _p(ids), _p(masks))
+    return masks, zee, ids
+
+
+def generate_mask(points, shift, W, H, focal, baseline, use_fma=True):
+    """common.py:689-830: the ownership mask viewed as an image (N == H*W) and median-5 filtered (:829)."""
+    masks, _, _ = generate_mask_raw(points, shift, W, H, focal, baseline, use_fma)
+    return spatial_filter(masks.view(-1, 1, H, W), 'median-5')
 
 
 def degrid(zee, schedule='jacobi'):
@@ -241,6 +261,9 @@ class OracleKernels:
 
     def spatial_filter(self, x, kind):
         return spatial_filter(x, kind)
+
+    def generate_mask(self, points, shift, W, H, focal, baseline):
+        return generate_mask(points, shift, W, H, focal, baseline, self.use_fma)
 
     def laplacian_valid(self, disparity, scale, threshold):
         lap = spatial_filter(_f32(disparity) / scale, 'laplacian')

@@ -172,7 +172,7 @@ class Harness:
             fn(ctypes.c_int(args[0]), *[ctypes.c_void_p(a) for a in args[1:]])
             if self.tracing:
                 self.trace.append((name, {k: v.detach().clone() for k, v in variables.items()
-                                          if torch.is_tensor(v) and k in ('zee', 'output')}))
+                                          if torch.is_tensor(v) and k in ('zee', 'output', 'masks', 'id_memory')}))
         return call
 
     def traced(self, fn, *args):
@@ -522,10 +522,51 @@ def gen_kenburns():
         save('kenburns_' + tag, **arrays)
 
 
+def gen_generate_mask():
+    """generate_mask (common.py:689-830): per-point ownership mask of the z-splat, serial point order.
+    Inputs are image rasters (N == H*W, the mask is viewed as an image for the median-5), batch 2, with
+    laplacian-invalid points at depth 0 (culled), a shift that moves part of the cloud out of view, and a
+    second case where several points per pixel compete (zoom: shift towards the camera)."""
+    h = HARNESS
+    arrays = {}
+    for tag, (H, W, focal, baseline, shifts) in {
+            'a': (40, 56, 512.0, 120, [(-6.0, 3.0, -20.0), (4.0, -2.0, 35.0)]),
+            'b': (32, 48, 409.6, 40.0, [(1.5, 0.5, 120.0), (-30.0, 12.0, -60.0)]),
+            'c': (12, 16, 512.0, 120, [(0.0, 0.0, 0.0), (0.5, -0.25, 5.0)])}.items():
+        pts_l = []
+        for b in range(2):
+            image, disp = synthetic.make_rgbd(H, W, 20 + b, 'smooth', baseline)
+            depth = (focal * baseline) / (disp + 0.0000001)
+            valid = (h.C.spatial_filter(disp / disp.max(), 'laplacian').abs() < 0.03).float()
+            pts_l.append(h.C.depth_to_points(depth * valid if tag != 'c' else depth, focal).view(1, 3, -1))
+        pts = torch.cat(pts_l, 0).contiguous()
+        shift = torch.tensor(shifts, dtype=torch.float32).view(2, 3, 1)
+        if tag == 'c':
+            # point 0 first owns its pixel and is then displaced by nearer points on the same ray (the reference
+            # only clears a displaced owner when its index is > 0: point 0 keeps mask 1); also a displaced point > 0
+            pts[:, :, 0] = pts[:, :, 27]
+            pts[:, :, 5] = pts[:, :, 27] * 0.5
+            pts[:, :, 9] = pts[:, :, 27] * 0.25
+            pts[0, :, 13] = pts[0, :, 30] * 0.5
+        arrays.update({tag + '_points': npy(pts), tag + '_shift': npy(shift), tag + '_W': np.int32(W), tag + '_H': np.int32(H),
+                       tag + '_focal': np.float64(focal), tag + '_baseline': np.float64(baseline),
+                       tag + '_baseline_is_int': np.bool_(isinstance(baseline, int))})
+        for mode in ('fma', 'nofma'):
+            h.mode = mode
+            out, tr = h.traced(h.C.generate_mask, pts, shift, W, H, focal, baseline)
+            assert [t[0] for t in tr] == ['kernel_pointrender_updateZee']
+            arrays[tag + '_masks_raw_' + mode] = npy(tr[0][1]['masks'])
+            arrays[tag + '_zee_' + mode] = npy(tr[0][1]['zee'])
+            arrays[tag + '_ids_' + mode] = npy(tr[0][1]['id_memory'].view(torch.int32))
+            arrays[tag + '_masks_' + mode] = npy(out)
+    h.mode = 'fma'
+    save('generate_mask', **arrays)
+
+
 if __name__ == '__main__':
     HARNESS = Harness()
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)   # bit-stable conv results
-    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'disparity']
+    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'disparity', 'generate_mask']
     for w in which:
         globals()['gen_' + w]()

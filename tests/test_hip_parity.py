@@ -489,3 +489,38 @@ def test_denser_than_raster_cloud_matches_oracle(K, oracle):
     oframe = ok.render_frame(ostate, shift3, synthetic.FOCAL, synthetic.BASELINE).numpy()
     d = np.abs(frame.astype(np.int32) - oframe.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_generate_mask_against_reference_vectors(K, tag):
+    """kbe_generate_mask against the reference's own generate_mask kernel (serial order): z-buffer bits, owner
+    table, per-point mask, and the median-filtered image (tests/golden/generate_mask.npz)."""
+    z = load_golden('generate_mask')
+    W, H = int(z[tag + '_W']), int(z[tag + '_H'])
+    baseline = int(z[tag + '_baseline']) if bool(z[tag + '_baseline_is_int']) else float(z[tag + '_baseline'])
+    masks, zee, ids = K.generate_mask_raw(g(z[tag + '_points']), g(z[tag + '_shift']), W, H, float(z[tag + '_focal']), baseline,
+                                          want_tables=True)
+    assert_bits_equal(c(zee), z[tag + '_zee_fma'], 'z-buffer')
+    assert np.array_equal(c(ids), z[tag + '_ids_fma']), 'owner table'
+    assert np.array_equal(c(masks), z[tag + '_masks_raw_fma']), 'per-point mask'
+    out = K.generate_mask(g(z[tag + '_points']), g(z[tag + '_shift']), W, H, float(z[tag + '_focal']), baseline)
+    assert np.array_equal(c(out), z[tag + '_masks_fma']), 'median-5 of the mask image'
+
+
+@pytest.mark.gpu
+def test_generate_mask_matches_oracle_at_size(K, oracle):
+    from ken_burns_effect_amd import synthetic
+    H, W, B = 192, 256, 2
+    pts, shifts = [], []
+    for b in range(B):
+        _, disp = synthetic.make_rgbd(H, W, 40 + b)
+        depth = (synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)
+        pts.append(oracle.depth_to_points(depth, synthetic.FOCAL).view(1, 3, -1))
+        shifts.append([4.0 - 9.0 * b, -3.0, 60.0 * b - 20.0])
+    pts, shift = torch.cat(pts, 0), torch.tensor(shifts).view(B, 3, 1)
+    masks, zee, ids = K.generate_mask_raw(pts.cuda(), shift.cuda(), W, H, synthetic.FOCAL, synthetic.BASELINE, want_tables=True)
+    omasks, ozee, oids = oracle.generate_mask_raw(pts, shift, W, H, synthetic.FOCAL, synthetic.BASELINE)
+    assert_bits_equal(c(zee), ozee.numpy(), 'z-buffer')
+    assert np.array_equal(c(ids), oids.numpy()) and np.array_equal(c(masks), omasks.numpy())
+    assert 0.2 < float(masks.mean()) < 1.0        # a real mix of owners and displaced points

@@ -150,3 +150,28 @@ def test_degrid_fast_path_mean_is_the_correctly_rounded_division(tmp_path):
     out = subprocess.run([exe, '1048576', '8400000'], capture_output=True, text=True)      # 2^20 .. 8 * 1e6 (+ margin)
     n, bad = (int(v) for v in out.stdout.split())
     assert out.returncode == 0 and bad == 0 and n > 4 * 12_000_000
+
+
+def test_get_masks_plumbing_with_the_oracle_kernel_set(oracle):
+    """utils.get_masks (utils/utils.py:248-300): both return forms, per-sample zoom settings, on the CPU oracle."""
+    import torch
+    from ken_burns_effect_amd import common, synthetic, utils
+    common._kernel_set = oracle.OracleKernels('jacobi')
+    try:
+        H, W, B = 48, 64, 2
+        imgs, disps = zip(*[synthetic.make_rgbd(H, W, 7 + b) for b in range(B)])
+        image, disp = torch.cat(imgs), torch.cat(disps)
+        depth = (synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)
+        zoom = {'objectFrom': {'dblCenterU': [W / 2.0] * B, 'dblCenterV': [H / 2.0] * B, 'intCropWidth': [W] * B, 'intCropHeight': [H] * B},
+                'objectTo': {'dblCenterU': [W / 2.0 + 3, W / 2.0 - 2], 'dblCenterV': [H / 2.0, H / 2.0 + 1],
+                             'intCropWidth': [int(W * 0.8)] * B, 'intCropHeight': [int(H * 0.8)] * B}}
+        camera = {'focal': synthetic.FOCAL, 'baseline': synthetic.BASELINE}
+        masks, shift, objs = utils.get_masks(image, disp, depth, zoom, camera)
+        assert masks.shape == (B, 1, H, W) and shift.shape == (B, 3, 1) and len(objs) == B
+        assert set(torch.unique(masks).tolist()) <= {0.0, 1.0} and 0.0 < float(masks.mean()) < 1.0
+        assert not torch.equal(shift[0], shift[1])                      # per-sample zoom settings were used
+        render, holes, pts, shift2, _ = utils.get_masks(image, disp, depth, zoom, camera, AFromB=False)
+        assert render.shape == (B, 4, H, W) and holes.shape == (B, 1, H, W) and pts.shape == (B, 3, H * W)
+        assert torch.equal(shift, shift2)
+    finally:
+        common._kernel_set = None

@@ -124,3 +124,20 @@ def test_pconv_epilogue_matches_reference(oracle):
         assert_bits_equal(um.expand(-1, cout, -1, -1).numpy(), z['mask_' + tag], 'update_mask ' + tag)
         # raw comes from this machine's conv2d; the epilogue itself is exact given raw
         assert np.abs(out.numpy() - z['out_' + tag]).max() <= 1e-5 * max(1.0, np.abs(z['out_' + tag]).max())
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('mode', ['fma', 'nofma'])
+def test_generate_mask_matches_reference(oracle, tag, mode):
+    """generate_mask (common.py:689-830): z-buffer, owner table, per-point mask and the median-filtered mask
+    against the reference's own kernel run in serial point order (tests/golden/make_golden.py)."""
+    z = load_golden('generate_mask')
+    pts, shift = torch.from_numpy(z[tag + '_points']), torch.from_numpy(z[tag + '_shift'])
+    W, H = int(z[tag + '_W']), int(z[tag + '_H'])
+    baseline = int(z[tag + '_baseline']) if bool(z[tag + '_baseline_is_int']) else float(z[tag + '_baseline'])
+    masks, zee, ids = oracle.generate_mask_raw(pts, shift, W, H, float(z[tag + '_focal']), baseline, use_fma=(mode == 'fma'))
+    assert_bits_equal(zee.numpy(), z[tag + '_zee_' + mode], 'z-buffer')
+    assert np.array_equal(ids.numpy(), z[tag + '_ids_' + mode]), 'owner table'
+    assert np.array_equal(masks.numpy(), z[tag + '_masks_raw_' + mode]), 'per-point mask'
+    out = oracle.generate_mask(pts, shift, W, H, float(z[tag + '_focal']), baseline, use_fma=(mode == 'fma'))
+    assert np.array_equal(out.numpy(), z[tag + '_masks_' + mode]), 'median-5 of the mask image'
