@@ -167,7 +167,7 @@ def main():
     ap.add_argument('--host-delivery', action='store_true',
                     help='also time the same K frames copied to pinned host memory (PCIe-inclusive; reported beside value)')
     ap.add_argument('--no-overlap', action='store_true', help='copies on the compute stream (dev comparison)')
-    ap.add_argument('--batch', type=int, default=16, help='frames per device->host transfer')
+    ap.add_argument('--batch', type=int, default=None, help='frames per device->host transfer (default: steps / 4 within 8..64)')
     ap.add_argument('--upsample', type=int, default=1, help='cloud of (upsample * size)^2 points (BASELINE configs[4]: 2; implies --cloud raw)')
     ap.add_argument('--cloud', choices=['inpaint', 'raw'], default='inpaint',
                     help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
@@ -252,8 +252,9 @@ def main():
     elapsed_h = None
     if args.host_delivery:
         host_out = torch.empty(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
-        common.render_frames(cams[:nw], oc, crop, host_out=host_out[:nw], batch=args.batch)
-        frames_h, elapsed_h = timed(lambda: common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=args.batch))
+        batch = args.batch if args.batch is not None else max(8, min(64, args.steps // 4))    # render_video's own default for K frames
+        common.render_frames(cams[:nw], oc, crop, host_out=host_out[:nw], batch=batch)        # allocates the staging ring
+        frames_h, elapsed_h = timed(lambda: common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=batch))
         assert frames_h.shape == (args.steps, size, size, 3)
 
     if rank == 0:
@@ -300,7 +301,7 @@ def main():
         if elapsed_h is not None:
           line['host_delivery'] = {'value': args.steps * world_size / elapsed_h, 'unit': 'frames/s', 'ms_per_step': elapsed_h / args.steps * 1e3,
                                  'note': 'same K frames copied to pinned host memory (PCIe D2H of %.1f MB per frame, %d frames per transfer, second stream)'
-                                         % (size * size * 3 / 1e6, args.batch)}
+                                         % (size * size * 3 / 1e6, args.batch if args.batch is not None else max(8, min(64, args.steps // 4)))}
         if world_size == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(oc, cams, crop)
         print(json.dumps(line), flush=True)

@@ -295,7 +295,7 @@ def _prepared_cloud(K, objectCommon):
     return cached[1]
 
 
-def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_out=None, overlap=True, batch=16):
+def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_out=None, overlap=True, batch=None):
     """The frame loop proper (common.py:238-257) for a list of (focal, shift3) cameras.
 
     One fused kernel sequence per frame on the resident packed cloud; frames land in one
