@@ -314,28 +314,32 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
     const int ry0 = min(max(ipy + py_lo, 0), H - 1), ry1 = min(max(ipy + py_hi + 1, 0), H - 1);
     const int n_rows = ry1 - ry0 + 1;                                                       // <= CR_RROWS
     const size_t frame_bytes = (size_t) W * H * 3;
-    // (0) stage the raw rows: every load is issued before the first LDS store (a load-store-load-store loop
-    // serialises the memory latencies)
+    // (0) stage the raw rows: wave w takes rows w, w + 4, w + 8, lane = dword of the row, so everything about a row
+    // is wave-uniform (scalar unit) and a lane only adds its offset; every load is issued before the first LDS
+    // store (a load-store-load-store loop serialises the memory latencies)
+    static_assert(CR_RROWS <= 12 && CR_RDW <= 64 && CR_THREADS == 256, "one lane per dword of a staged row");
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     uint32_t stage[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const int item = tid + k * CR_THREADS;
-        const int r = item / CR_RDW, dwi = item - r * CR_RDW;
+        const int r = wv + 4 * k;                                       // wave-uniform
         stage[k] = 0;
         if (r < n_rows) {
             const size_t b0 = ((size_t) (ry0 + r) * W + rx0) * 3, b1 = ((size_t) (ry0 + r) * W + rx1) * 3 + 3;
             const size_t a0 = b0 & ~(size_t) 3;
-            if (dwi < (int) ((b1 - a0 + 3) >> 2)) {
-                const size_t off = a0 + 4 * (size_t) dwi;
-                if (off + 4 <= frame_bytes) stage[k] = *(const uint32_t*) (img + off);
-                else for (int t = 0; t < 4; t++) if (off + t < frame_bytes) stage[k] |= (uint32_t) img[off + t] << (8 * t);
+            const int n_dw = (int) ((b1 - a0 + 3) >> 2);                // <= CR_RDW
+            const uint8_t* row = img + a0;
+            if (a0 + 4 * (size_t) n_dw <= frame_bytes) {                // wave-uniform: the whole row segment is inside the frame
+                if (ln < n_dw) stage[k] = ((const uint32_t*) row)[ln];
+            } else if (ln < n_dw) {                                     // the very last bytes of the frame
+                for (int t = 0; t < 4; t++) if (a0 + 4 * (size_t) ln + t < frame_bytes) stage[k] |= (uint32_t) row[4 * ln + t] << (8 * t);
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const int item = tid + k * CR_THREADS;
-        if (item < CR_RROWS * CR_RDW) (&s_raw[0][0])[item] = stage[k];
+        const int r = wv + 4 * k;
+        if (r < CR_RROWS && ln < CR_RDW) s_raw[r][ln] = stage[k];
     }
     if (tid <= CR_PROWS) {
         // byte offset in s_raw of the raw row under patch row `tid` (row CR_PROWS: the last bottom tap); row y starts
