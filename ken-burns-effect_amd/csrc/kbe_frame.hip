@@ -145,10 +145,24 @@ __device__ __forceinline__ TileGroup group_by_tile(bool want, int tile)
     unsigned long long pending = __ballot(want);
     while (pending) {                                           // wave-uniform
         const int leader = __ffsll((long long) pending) - 1;
-        const int t = __shfl(tile, leader);
+        const int t = __builtin_amdgcn_readlane(tile, leader);     // leader is wave-uniform: v_readlane, not an LDS round trip (ds_bpermute)
         const unsigned long long same = __ballot(want && tile == t);
         if (want && tile == t) { g.same = same; g.leader = leader; }
         pending &= ~same;
+    }
+    return g;
+}
+
+// The groups of the east spills follow from the groups of the own tiles: lanes that share an own tile share its
+// east neighbour, so a group's spilling lanes are `same & ballot(spills)` and no second grouping loop is needed --
+// except for lanes whose own tile is outside the image (corner at -1) but whose east tile is inside.
+__device__ __forceinline__ TileGroup east_groups(const TileGroup& own, bool want_own, bool want_east, int east_tile)
+{
+    const unsigned long long sp = __ballot(want_east);
+    TileGroup g = group_by_tile(want_east && !want_own, east_tile);            // normally no lane: the loop does not run
+    if (want_east && want_own) {
+        g.same = own.same & sp;
+        g.leader = __ffsll((long long) g.same) - 1;
     }
     return g;
 }
@@ -221,9 +235,10 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
             want[e] = false;
 #endif
             tgt[e] = ty0 * a.tiles_x + tx;
-            grp[e] = group_by_tile(want[e], tgt[e]);
             base[e] = 0;
         }
+        grp[0] = group_by_tile(want[0], tgt[0]);
+        grp[1] = east_groups(grp[0], want[0], want[1], tgt[1]);
 #pragma unroll
         for (int e = 0; e < 2; e++)
             if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
@@ -262,9 +277,10 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
                 const int tx = tx0 + e, ty = ty0 + 1;
                 want[e] = spy && (e == 0 || spx) && tx >= 0 && ty >= 0 && tx < a.tiles_x && ty < a.tiles_y;
                 tgt[e] = ty * a.tiles_x + tx;
-                grp[e] = group_by_tile(want[e], tgt[e]);
                 base[e] = 0;
             }
+            grp[0] = group_by_tile(want[0], tgt[0]);
+            grp[1] = east_groups(grp[0], want[0], want[1], tgt[1]);
 #pragma unroll
             for (int e = 0; e < 2; e++)
                 if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
@@ -674,7 +690,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; }
     }
     if (n_holes > 0) {                              // wave-uniform
-        int base = __shfl(hole_base, 0);
+        int base = __builtin_amdgcn_readfirstlane(hole_base);
 #pragma unroll
         for (int m = 0; m < PIX_PER_THREAD; m++) {
             const int q = tid + m * TILE_THREADS;

@@ -15,7 +15,7 @@ if os.environ.get('KBE_LIB_PATH'):
     _native._lib, _native._kernels, _native.LIB_PATH = None, None, os.environ['KBE_LIB_PATH']
 
 size = int(os.environ.get('SIZE', '1024'))
-n = int(os.environ.get('FRAMES', '256'))
+n = int(os.environ.get("FRAMES", "512"))
 dolly = os.environ.get('DOLLY', '0') == '1'
 ofrom, oto = synthetic.default_windows(size, size, dolly)
 settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
@@ -27,7 +27,7 @@ out = torch.empty(n, size, size, 3, dtype=torch.uint8, device=dev)
 common.render_frames(cams[:8], oc, crop, keep_on_device=True, host_out=out[:8])
 best = 1e9
 enq = 1e9
-for _ in range(int(os.environ.get('REPS', '5'))):
+for _ in range(int(os.environ.get("REPS", "7"))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     common.render_frames(cams, oc, crop, keep_on_device=True, host_out=out)
