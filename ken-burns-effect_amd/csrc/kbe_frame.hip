@@ -695,7 +695,10 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         for (int m = 0; m < PIX_PER_THREAD; m++) {
             const int q = tid + m * TILE_THREADS;
             const int ly = q / TW, lx = q - ly * TW;
-            if (hole[m]) a.holes[base + __popcll(hm[m] & ((1ull << lane) - 1ull))] = (y0 + ly) * W + x0 + lx;
+            const int slot = base + __popcll(hm[m] & ((1ull << lane) - 1ull));
+            // (the list holds W*H entries, enough for any one frame; the bound only matters when this launch is
+            // repeated without the projection launch that zeroes the count, as bench.py does to time it alone)
+            if (hole[m] && slot < W * H) a.holes[slot] = (y0 + ly) * W + x0 + lx;
             base += __popcll(hm[m]);
         }
     }
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
 #if defined(KBE_PROBE_NO_WALK)
     const int n = 0;
 #else
-    const int n = *hole_count;
+    const int n = min(*hole_count, W * H);
 #endif
     // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
