@@ -190,7 +190,7 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
  *            kbe_frame_scratch_init;
  *   stage:   DEVICE buffer of (lanes + 2*batch) * H*W*3 bytes.
  * The call creates and destroys its HIP events. */
-#define KBE_MAX_LANES 4
+#define KBE_MAX_LANES 8
 KBE_API size_t kbe_video_scratch_stride(int W, int H);
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

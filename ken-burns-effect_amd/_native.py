@@ -25,8 +25,8 @@ SYMBOLS = (
 )
 
 ABI_VERSION = 1
-MAX_LANES = 4          # KBE_MAX_LANES
-DEFAULT_LANES = 3      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
+MAX_LANES = 8          # KBE_MAX_LANES
+DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 _lib = None
 
 
