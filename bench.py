@@ -257,7 +257,9 @@ def main():
     if args.host_delivery:
         host_out = torch.empty(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
         batch = args.batch if args.batch is not None else max(8, min(64, args.steps // 4))    # render_video's own default for K frames
-        common.render_frames(cams[:nw], oc, crop, host_out=host_out[:nw], batch=batch)        # allocates the staging ring
+        # untimed full pass: allocates the staging ring and touches every page of the pinned landing buffer (the first
+        # transfer into a page is several times slower than the steady state)
+        common.render_frames(cams, oc, crop, host_out=host_out, batch=batch)
         frames_h, elapsed_h = timed(lambda: common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=batch))
         assert frames_h.shape == (args.steps, size, size, 3)
 
