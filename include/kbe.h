@@ -166,6 +166,10 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_PROJECT 1
 #define KBE_STAGE_TILES 2
 #define KBE_STAGE_FILL 4
+/* with KBE_STAGE_FILL: force one of the two hole-fill schedules (default: chosen by the frame's hole count; the
+ * results are identical -- tests and A/B measurements use these) */
+#define KBE_STAGE_FILL_PER_LANE 8
+#define KBE_STAGE_FILL_PER_HALFWAVE 16
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,

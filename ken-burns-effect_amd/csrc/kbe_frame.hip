@@ -743,12 +743,95 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 // ---------------------------------------------------------------------------------------
 struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are filled
 
+#ifndef KBE_FILL_SERIAL_BATCH
+#define KBE_FILL_SERIAL_BATCH 8
+#endif
+#ifndef KBE_FILL_SERIAL_MIN
+#define KBE_FILL_SERIAL_MIN 49152       // holes per frame from which one lane per hole beats one half-wave per hole
+#endif
+
+// Frames with very many holes (dolly: no inpainting, common.py:217; hundreds of thousands of holes in wide
+// disocclusion bands): ONE LANE PER HOLE, the 16 directions in the reference's order, both ends of a direction
+// advancing together.  In the half-wave-per-hole scheme most lanes are pruned after the first batches and the wave
+// then walks a few long rays at 3 % lane utilisation; here a lane always does useful work, and a later direction
+// stops as soon as the distance between its two current positions reaches the best complete one (it would have to
+// be STRICTLY shorter to win, common.py:900).  Same exact arithmetic (:876-898); neighbouring lanes hold
+// neighbouring holes (the list is written tile by tile), so their walks have similar lengths.
+__device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
+                                                 int wpr, const FillDirs& dirs, int bx0, int by0, int bx1, int by1,
+                                                 uint8_t* __restrict__ frame, float* __restrict__ render)
+{
+    constexpr int SB = KBE_FILL_SERIAL_BATCH;
+    const int y = px / W, x = px - y * W;
+    float best = 1000000.0f;                    // dblShortest (:854)
+    float best_s = INFINITY;                    // ex^2 + ey^2 of the best direction (what `best` is the sqrtf of)
+    int sax = -1, say = -1, sbx = -1, sby = -1;
+    // A hole outside the box of valid pixels: of the two opposite ends of any direction at least one moves away from
+    // the box or parallel to it and can never hit a valid pixel, so every direction is skipped (:884-885, :895-896)
+    if (x < bx0 || x > bx1 || y < by0 || y > by1) return;
+    for (int d = 0; d < 16; d++) {
+        const float ddx = dirs.x[d], ddy = dirs.y[d];
+        float fa_x = (float) x, fa_y = (float) y, fb_x = fa_x, fb_y = fa_y;
+        int ax = x, ay = y, bx = x, by = y;
+        bool hit_a = false, hit_b = false, dead = false;
+        while (!dead && !(hit_a && hit_b)) {
+            // a batch of SB steps per unfinished end: positions first (they do not depend on the data), loads together
+            int pax[SB], pay[SB], pbx[SB], pby[SB];
+            uint32_t wa[SB], wb[SB];
+            bool ina[SB], inb[SB];
+#pragma unroll
+            for (int k = 0; k < SB; k++) {
+                fa_x -= ddx; pax[k] = (int) roundf(fa_x);       // :876-877
+                fa_y -= ddy; pay[k] = (int) roundf(fa_y);
+                fb_x += ddx; pbx[k] = (int) roundf(fb_x);       // :887-888
+                fb_y += ddy; pby[k] = (int) roundf(fb_y);
+                ina[k] = ((unsigned) pax[k] < (unsigned) W) & ((unsigned) pay[k] < (unsigned) H);
+                inb[k] = ((unsigned) pbx[k] < (unsigned) W) & ((unsigned) pby[k] < (unsigned) H);
+                wa[k] = mask[(ina[k] && !hit_a) ? (unsigned) pay[k] * (unsigned) wpr + ((unsigned) pax[k] >> 5) : 0u];
+                wb[k] = mask[(inb[k] && !hit_b) ? (unsigned) pby[k] * (unsigned) wpr + ((unsigned) pbx[k] >> 5) : 0u];
+            }
+#pragma unroll
+            for (int k = 0; k < SB; k++) {
+                if (!hit_a && !dead) {
+                    ax = pax[k]; ay = pay[k];
+                    if (!ina[k]) dead = true;
+                    else if ((wa[k] >> (ax & 31)) & 1u) hit_a = true;
+                }
+                if (!hit_b && !dead) {
+                    bx = pbx[k]; by = pby[k];
+                    if (!inb[k]) dead = true;
+                    else if ((wb[k] >> (bx & 31)) & 1u) hit_b = true;
+                }
+            }
+            if (dead) break;
+            // left the box of valid pixels for good?
+            if (!hit_a && ((ax < bx0 && ddx >= 0.0f) || (ax > bx1 && ddx <= 0.0f) || (ay < by0 && ddy >= 0.0f) || (ay > by1 && ddy <= 0.0f))) { dead = true; break; }
+            if (!hit_b && ((bx < bx0 && ddx <= 0.0f) || (bx > bx1 && ddx >= 0.0f) || (by < by0 && ddy <= 0.0f) || (by > by1 && ddy >= 0.0f))) { dead = true; break; }
+            // bound: the ends only move apart
+            const float ex = (float) (bx - ax), ey = (float) (by - ay);
+            const float s_now = ex * ex + ey * ey;
+            if (s_now >= best_s) { dead = true; break; }       // sqrtf is monotone: this direction cannot become STRICTLY shorter (:900)
+        }
+        if (dead) continue;
+        const float ex = (float) (bx - ax), ey = (float) (by - ay);
+        const float sq = ex * ex + ey * ey;
+        const float dist = sqrtf(sq);                           // :898
+        if (best > dist) { best = dist; best_s = sq; sax = ax; say = ay; sbx = bx; sby = by; }     // :900
+    }
+    if (sax < 0) return;                                        // unfillable: keeps the rendered value (:913-919)
+    int sx = sax, sy = say;
+    if (depth[(size_t) say * W + sax] < depth[(size_t) sby * W + sbx]) { sx = sbx; sy = sby; }     // :904 the farther (background) end
+    const size_t s = (size_t) sy * W + sx, o = (size_t) px, HW = (size_t) W * H;
+    frame[o * 3] = frame[s * 3]; frame[o * 3 + 1] = frame[s * 3 + 1]; frame[o * 3 + 2] = frame[s * 3 + 2];
+    if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + s];
+}
+
 __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
                                                     const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
                                                     FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
-                                                    const int4* __restrict__ bbox)
+                                                    const int4* __restrict__ bbox, int fill_mode)
 {
     // leave the scratch ready for the next frame: empty z-buffer, empty buckets
 #if !defined(KBE_PROBE_NO_RESET)
@@ -783,6 +866,17 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     __syncthreads();
     for (int w = 0; w < 4; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
     const int wpr = (W + 31) >> 5;              // mask words per row
+    // fill_mode: 0 = by hole count, 1 = one lane per hole, 2 = one half-wave per hole (the last two: tests, A/B)
+    if (fill_mode == 1 || (fill_mode == 0 && n >= KBE_FILL_SERIAL_MIN)) {       // uniform over the launch
+        const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        for (int h = gtid; h < n; h += gsz) {
+            const int px = holes[h];
+            const int y = px / W, x = px - y * W;
+            if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1) continue;
+            fill_hole_serial(px, depth, mask, W, H, wpr, dirs, bx0, by0, bx1, by1, frame, render);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 31;
     const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_groups = (gridDim.x * blockDim.x) >> 5;
     const int d = lane >> 1, end = lane & 1;
@@ -941,7 +1035,8 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
-                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox);
+                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
+                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) ? 2 : 0));
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
