@@ -635,7 +635,13 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         const bool in = x0 + lx < W && y0 + ly < H;
         const float w = acc[m].w;
         const float den = w + 0.0000001f;
-        res[m][0] = acc[m].rg.x / den; res[m][1] = acc[m].rg.y / den; res[m][2] = acc[m].bd.x / den; res[m][3] = acc[m].bd.y / den;
+        // four numerators over one denominator: ONE IEEE division for the correctly rounded reciprocal, then
+        // q = a * y, q' = fma(fma(-den, q, a), y, q) per channel -- the correctly rounded a / den (Markstein;
+        // tests/markstein_div_check.c) unless an intermediate underflows, i.e. for |a| below ~2^-100, where the
+        // last bit may differ (no colour or depth of a real cloud gets there)
+        const float y = 1.0f / den;
+        auto quot = [&](float a_) { const float q = a_ * y; return __builtin_fmaf(__builtin_fmaf(-den, q, a_), y, q); };
+        res[m][0] = quot(acc[m].rg.x); res[m][1] = quot(acc[m].rg.y); res[m][2] = quot(acc[m].bd.x); res[m][3] = quot(acc[m].bd.y);
         dms[m] = res[m][3] * (w > 0.0f ? 1.0f : 0.0f);
         valid[m] = in && dms[m] > 0.0f;
 #if defined(KBE_PROBE_NO_HOLES)

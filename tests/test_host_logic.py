@@ -175,3 +175,15 @@ def test_get_masks_plumbing_with_the_oracle_kernel_set(oracle):
         assert torch.equal(shift, shift2)
     finally:
         common._kernel_set = None
+
+
+def test_shared_reciprocal_division_is_the_correctly_rounded_division(tmp_path):
+    """kbe_frame.hip resolve: four numerators over one denominator = one IEEE reciprocal + a Markstein step each."""
+    import os
+    import subprocess
+    exe = str(tmp_path / 'markstein_div_check')
+    src = os.path.join(os.path.dirname(__file__), 'markstein_div_check.c')
+    subprocess.check_call(['gcc', '-O2', '-mfma', '-ffp-contract=off', src, '-o', exe, '-lm'])
+    out = subprocess.run([exe, '60000000'], capture_output=True, text=True)
+    n, bad = (int(v) for v in out.stdout.split()[-2:])
+    assert out.returncode == 0 and bad == 0 and n == 60000000
