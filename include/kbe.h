@@ -176,6 +176,15 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
                                     float* zee_pre_f32, int stages, const int* fill_rect, int raster_w, int raster_n,
                                     kbe_stream_t stream);
 
+/* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
+ * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x32 tile degrid and a
+ * z-tested gather four channels at a time.  data [C,N]; render [C,H,W] normalised (:686), existing [H*W] the
+ * weight sum; shift3 as in kbe_zsplat (NULL: none); scratch as kbe_render_frame (left clean).  Same results
+ * as kbe_render_pointcloud up to the order of the fp32 sums. */
+KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
+                                        double baseline, const float* shift3, void* scratch, float* render,
+                                        float* existing, kbe_stream_t stream);
+
 /* The whole frame loop of process_kenburns (common.py:222-260) for `n_frames` cameras, enqueued
  * from native code (no per-frame host-language work): per frame kbe_render_frame_stages, then the
  * device-side crop + resize of common.py:256-257 when crop_w/crop_h > 0 (holes the crop discards are

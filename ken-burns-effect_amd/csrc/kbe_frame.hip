@@ -374,8 +374,8 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 // -- adding c * 0 leaves the accumulator bits unchanged, so the sums are those of the branching loop.  The
 // trip count is the longest of the four lists, not their sum.  FAST: every z of the tile is in the band where
 // `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
-template <bool FAST>
-__device__ __forceinline__ void gather(const TileArgs& a, const TileLds& L, int tid, int x0, int y0,
+template <bool FAST, class Args>
+__device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid, int x0, int y0,
                                        PixAcc (&acc)[PIX_PER_THREAD])
 {
 #pragma unroll
@@ -743,6 +743,172 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 }
 
 // ---------------------------------------------------------------------------------------
+// render_pointcloud for ANY channel count on the same machinery (the 68-channel forward warp of the inpaint
+// set-up, pointcloud_inpainting.py:201: image, disparity and 64 context features): k_project fills the z-buffer
+// and the buckets exactly as for a frame; this kernel degrids the tile once and then takes the data four
+// channels at a time -- per chunk the records are threaded into the per-pixel lists again with their four values
+// (the lists cost little next to the walk), every pixel walks its bins and the chunk leaves normalised
+// (common.py:686).  No accumulator in HBM, no floating-point atomic; 20x faster than the global-atomic
+// formulation at 68 channels (0.1 vs 2.2 ms at 1024^2).
+// ---------------------------------------------------------------------------------------
+struct TileNcArgs {
+    const float* points;    // [3,N]  (only the brute-force path of an overflowing bucket reads it)
+    const float* data;      // [C,N]
+    int N, C;
+    Camera cam;
+    const uint32_t* zkeys;
+    const int* tile_count;
+    const float4* buckets;
+    int tiles_x, tiles_y;
+    float* render;          // [C,H,W] normalised
+    float* existing;        // [H*W] weight sum
+};
+
+__device__ __forceinline__ float4 fetch_chunk(const TileNcArgs& a, int id, int c0)
+{
+    const size_t N = (size_t) a.N;
+    const float* D = a.data + (size_t) c0 * N + id;
+    float4 v;
+    v.x = D[0];
+    v.y = c0 + 1 < a.C ? D[N] : 0.0f;
+    v.z = c0 + 2 < a.C ? D[2 * N] : 0.0f;
+    v.w = c0 + 3 < a.C ? D[3 * N] : 0.0f;
+    return v;
+}
+
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tiles_nc(TileNcArgs a)
+{
+    __shared__ TileLds L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int W = a.cam.W, H = a.cam.H;
+    const size_t HW = (size_t) W * H;
+    const int count = a.tile_count[tile * CNT_STRIDE];
+    const bool bucketed = count <= BUCKET_CAP;
+    const float4* B = a.buckets + (size_t) tile * BUCKET_STRIDE;
+    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
+
+    // z tile + halo -> LDS, one decision per tile (see k_tiles), degrid
+    bool band = true;
+    for (int i = tid; i < KH * KW; i += TILE_THREADS) {
+        const int py = i / KW, pxl = i - py * KW;
+        const int x = x0 - 1 + pxl, y = y0 - 1 + py;
+        const float z = zkey_decode(inside(x, y, W, H) ? a.zkeys[(size_t) y * W + x] : KBE_ZKEY_EMPTY);     // common.py:430 outside
+        L.zpre[i] = z;
+        band = band && degrid_fast_ok(z);
+    }
+    {
+        const unsigned long long odd = __ballot(!band);
+        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
+    }
+    if (tid == 0) {
+        L.rec[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));      // the gather's dummy record: finite even in an empty tile
+        L.rgbd[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    bool fast = true;
+#pragma unroll
+    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
+    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
+    for (int i = tid; i < TH * TW; i += TILE_THREADS) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        auto at = [&](int xx, int yy) { return L.zpre[(yy - y0 + 1) * KW + (xx - x0 + 1)]; };
+        L.zee[i] = degrid_pixel(x, y, W, H, at);
+    }
+
+    for (int c0 = 0; c0 < a.C; c0 += 4) {
+        PixAcc acc[PIX_PER_THREAD];
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
+        if (bucketed) {
+            for (int r0 = 0; r0 == 0 || r0 < count; r0 += REC_CAP) {
+                const int n = min(REC_CAP, count - r0);
+                float4 rr[PER], cc[PER];
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    rr[u] = B[min(r0 + i, BUCKET_CAP - 1)];                // unconditional (clamped) loads: see k_tiles
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    cc[u] = fetch_chunk(a, i < n ? __float_as_int(rr[u].w) : 0, c0);
+                }
+                __syncthreads();                                        // zee written / the previous gather is done with the lists
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    if (i < n) lds_insert(L, i, rr[u].x, rr[u].y, rr[u].z, cc[u], x0, y0);
+                }
+                __syncthreads();
+                if (fast) gather<true>(a, L, tid, x0, y0, acc);
+                else gather<false>(a, L, tid, x0, y0, acc);
+            }
+        } else {
+            // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's records from the
+            // whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
+            __syncthreads();
+            for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+            if (tid == 0) L.nrec = 0;
+            __syncthreads();
+            const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
+            for (int i0 = 0; i0 < n_round; i0 += TILE_THREADS) {
+                const int i = i0 + tid;
+                bool ok = i < a.N;
+                float ox = 0.0f, oy = 0.0f, z = 0.0f;
+                if (ok) {
+                    float x = a.points[i], y = a.points[(size_t) a.N + i];
+                    z = a.points[2 * (size_t) a.N + i];
+                    apply_shift(a.cam, x, y, z);
+                    ok = project_xy(a.cam, x, y, z, ox, oy);
+                }
+                if (ok) {
+                    const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
+                    ok = (bx >= 0) & (bx < BW) & (by >= 0) & (by < BH);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (m) {
+                    int base = 0;
+                    const int leader = __ffsll((long long) m) - 1;
+                    if (lane == leader) base = atomicAdd(&L.nrec, __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), fetch_chunk(a, i, c0), x0, y0);
+                }
+                __syncthreads();
+                if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
+                    gather<false>(a, L, tid, x0, y0, acc);
+                    __syncthreads();
+                    for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+                    if (tid == 0) L.nrec = 0;
+                    __syncthreads();
+                }
+            }
+        }
+        // the chunk leaves normalised (common.py:686); the weight sum with the first chunk
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) {
+            const int q = tid + m * TILE_THREADS;
+            const int ly = q / TW, lx = q - ly * TW;
+            const int x = x0 + lx, y = y0 + ly;
+            if (x >= W || y >= H) continue;
+            const size_t o = (size_t) y * W + x;
+            const float den = acc[m].w + 0.0000001f;
+            a.render[(size_t) c0 * HW + o] = acc[m].rg.x / den;
+            if (c0 + 1 < a.C) a.render[(size_t) (c0 + 1) * HW + o] = acc[m].rg.y / den;
+            if (c0 + 2 < a.C) a.render[(size_t) (c0 + 2) * HW + o] = acc[m].bd.x / den;
+            if (c0 + 3 < a.C) a.render[(size_t) (c0 + 3) * HW + o] = acc[m].bd.y / den;
+            if (c0 == 0) a.existing[o] = acc[m].w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // hole fill: one 32-lane group per hole; lane = direction * 2 + end (0: against, 1: along)
 // (common.py:838-924; the direction loop and both ray walks run in parallel, then the
 // "strictly shorter, first direction wins" reduction picks the same source pixel)
@@ -1055,6 +1221,32 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
     return kbe_render_frame_stages(points, image, depth, N, W, H, focal, baseline, shift3, scratch, frame_u8, render_f32,
                                    existing_f32, zee_f32, zee_pre_f32, KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL,
                                    nullptr, 0, 0, stream);
+}
+
+int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
+                                double baseline, const float* shift3, void* scratch, float* render, float* existing,
+                                kbe_stream_t stream)
+{
+    KBE_REQUIRE(scratch && render && existing && N >= 0 && C > 0 && W > 0 && H > 0 && (size_t) W * H < (1u << 31) &&
+                ((uintptr_t) scratch & 15) == 0, "kbe_render_pointcloud_tiled: bad arguments");
+    KBE_REQUIRE(N == 0 || (points && data), "kbe_render_pointcloud_tiled: cloud pointers are NULL");
+    const hipStream_t s = (hipStream_t) stream;
+    const Scratch sc = carve(scratch, W, H);
+    const Camera cam = make_camera(W, H, focal, baseline, shift3);
+    const int n_tiles = sc.tiles_x * sc.tiles_y;
+    int rc = kbe_render_frame_stages(points, data, data, N, W, H, focal, baseline, shift3, scratch, (uint8_t*) sc.holes, nullptr, nullptr,
+                                     nullptr, nullptr, KBE_STAGE_PROJECT, nullptr, 0, 0, stream);
+    if (rc != KBE_OK) return rc;
+    TileNcArgs a;
+    a.points = points; a.data = data; a.N = N; a.C = C; a.cam = cam;
+    if (N == 0) a.points = a.data = (const float*) sc.zkeys;            // never dereferenced for a record, but never NULL
+    a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+    a.render = render; a.existing = existing;
+    hipLaunchKernelGGL(k_tiles_nc, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
+    if ((rc = launched("kbe_render_pointcloud_tiled/tiles"))) return rc;
+    // leave the scratch clean (z-buffer, bucket counters)
+    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, s, sc.zkeys, (size_t) W * H, sc.tile_count, n_tiles, sc.hole_count);
+    return launched("kbe_render_pointcloud_tiled/reset");
 }
 
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,

@@ -351,7 +351,7 @@ def test_tiled_frame_equals_generic_stages(K):
     frame = K.render_frame(state, shift3, focal, 120, render_f32=rf, existing_f32=ex)
     pts = K.shift_points(oc['tensorInpaPoints'], shift3)
     data = torch.cat([oc['tensorInpaImage'], oc['tensorInpaDepth']], 1)
-    render, existing = K.render_pointcloud(pts, data, 420, 300, focal, 120)
+    render, existing = K.render_pointcloud(pts, data, 420, 300, focal, 120, tiled=False)
     filled = K.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())
     assert torch.equal(ex.view(300, 420) > 0, existing[0, 0] > 0)
     assert float((rf - filled[0]).abs().max()) < 1e-4 * max(1.0, float(filled.abs().max()))
@@ -411,6 +411,31 @@ def test_pile_up_paths(K, oracle, per_pixel):
     assert psnr(c(rf)[:3], ref_float.numpy()[0, :3], 1.0) > 90.0
     d = np.abs(f.astype(np.int32) - ref.numpy().astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 5e-3
+    # the any-channel-count tile renderer through the same pile-up paths (7 channels: a partial last chunk)
+    data = torch.cat([img, dep, torch.rand(1, 3, N, generator=g0)], 1)
+    spts = oracle.shift_points(pts, torch.tensor(shift3))
+    r_t, e_t = K.render_pointcloud(spts.cuda(), data.cuda(), W, H, focal, 120, tiled=True)
+    r_o, e_o = oracle.render_pointcloud(spts, data, W, H, focal, 120, 'jacobi')
+    assert np.array_equal(c(e_t) > 0, e_o.numpy() > 0)
+    assert np.abs(c(e_t) - e_o.numpy()).max() <= 1e-4 * float(e_o.max())
+    assert (np.abs(c(r_t) - r_o.numpy()) <= 1e-4 * np.maximum(np.abs(r_o.numpy()), 1.0)).all()
+
+
+def test_tiled_render_pointcloud_68_channels_equals_the_atomic_path(K):
+    """The inpaint set-up's forward warp (68 channels) two ways: tile gather vs global float atomics."""
+    settings, oc = _scene((200, 312), 9)
+    from ken_burns_effect_amd import common
+    focal, shift3 = common.frame_cameras(settings, oc)[2]
+    pts = K.shift_points(oc['tensorInpaPoints'], shift3)
+    feat = torch.randn(1, 68, pts.shape[-1], device='cuda', generator=torch.Generator('cuda').manual_seed(2))
+    r_t, e_t = K.render_pointcloud(pts, feat, 312, 200, focal, 120, tiled=True)
+    r_g, e_g = K.render_pointcloud(pts, feat, 312, 200, focal, 120, tiled=False)
+    assert torch.equal(e_t > 0, e_g > 0)
+    assert float((e_t - e_g).abs().max()) <= 1e-5 * max(1.0, float(e_g.max()))
+    assert float((r_t - r_g).abs().max()) <= 1e-4 * max(1.0, float(r_g.abs().max()))
+    # and the scratch is left clean: a second call gives the same result
+    r_2, e_2 = K.render_pointcloud(pts, feat, 312, 200, focal, 120, tiled=True)
+    assert torch.equal(e_2 > 0, e_t > 0) and float((r_2 - r_t).abs().max()) <= 1e-4 * max(1.0, float(r_t.abs().max()))
 
 
 def test_pipeline_on_gpu_config2_shape(K):
