@@ -577,3 +577,22 @@ def test_both_hole_fill_schedules_give_identical_frames(K, size, dolly, kind):
                                               and (a[0] != b[0]).mean() < 1e-3)
         n_filled += int((c(unfilled)[3] == 0).sum())
     assert n_filled > 100
+
+
+@pytest.mark.parametrize('dolly,step', [(False, 1.0), (True, 0.6)])
+def test_full_size_frame_against_the_oracle(K, oracle, dolly, step):
+    """BASELINE.json's 1024x1024 configuration, one frame of the KBE path and one of the dolly path (tens of
+    thousands of holes, both fill schedules in reach), compared with the CPU oracle pixel by pixel."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene((1024, 1024), 0, 'smooth', dolly)
+    settings = dict(settings, dblSteps=[step])
+    cams = common.frame_cameras(settings, oc)
+    frame = common.render_frames(cams, oc, None)[0]
+    ok = oracle.OracleKernels('jacobi')
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), 1024, 1024)
+    focal, shift3 = cams[0]
+    ref = ok.render_frame(state, shift3, focal, oc['dblBaseline']).numpy()
+    d = np.abs(frame.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    src = (oc['tensorRawImage'][0].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
+    assert abs(psnr(frame, src, 255.0) - psnr(ref, src, 255.0)) < 1e-3
