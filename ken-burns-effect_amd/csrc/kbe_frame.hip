@@ -132,6 +132,7 @@ struct ProjectArgs {
     float4* buckets;
     int tiles_x, tiles_y;
     int* hole_count;
+    int dense;              // more than two points per target pixel: pre-reduce the z-splat within the wave
 };
 
 // Groups the lanes of a wave by target tile: for a lane that `want`s, `same` is the mask of the
@@ -245,6 +246,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
 
         // ... and while they are in flight: weights, dblError, winner corner, z-splat
         float err = 0.0f;
+        int zidx = -1;
         if (ok) {
             project_weights(ox, oy, p);
 #if defined(KBE_PROBE_EXACT_ERR)
@@ -255,11 +257,32 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
             const int k = winner_corner(p);                             // common.py:486-506
             if (k >= 0) {
                 const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-#if !defined(KBE_PROBE_NO_ZSPLAT)
-                if (inside(cx, cy, cam.W, cam.H)) atomicMin(&a.zkeys[(size_t) cy * cam.W + cx], zkey_encode(err));
-#endif
+                if (inside(cx, cy, cam.W, cam.H)) zidx = cy * cam.W + cx;
             }
         }
+#if !defined(KBE_PROBE_NO_ZSPLAT)
+        if (a.dense) {
+            // a cloud denser than the target raster (BASELINE configs[4]: 4 points per pixel): the 2 x 2 source
+            // neighbours (lanes ^1, ^32, ^33 of a 32 x 2 patch) mostly splat onto the same pixel and their atomics
+            // would serialise on one address (measured: 8x the time per atomic); the lowest lane of those that agree
+            // issues one atomic with their minimum
+            uint32_t key = zkey_encode(err);
+            bool issue = zidx >= 0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const int mask = m == 0 ? 1 : (m == 1 ? 32 : 33);
+                const int pidx = __shfl_xor(zidx, mask);
+                const uint32_t pkey = (uint32_t) __shfl_xor((int) key, mask);
+                if (zidx >= 0 && pidx == zidx) {
+                    key = min(key, pkey);
+                    if ((lane ^ mask) < lane) issue = false;
+                }
+            }
+            if (issue) atomicMin(&a.zkeys[zidx], key);
+        } else if (zidx >= 0) {
+            atomicMin(&a.zkeys[zidx], zkey_encode(err));
+        }
+#endif
         const float4 rec = make_float4(ox, oy, err, __int_as_float((int) i));
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -1179,6 +1202,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         p.points = points; p.N = N; p.cam = cam; p.zkeys = sc.zkeys; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
         p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
         p.raster_w = 0; p.raster_n = 0;
+        p.dense = (size_t) N > 2 * (size_t) W * H;
         if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
 #ifndef KBE_PROJECT_MAX_BLOCKS
 #define KBE_PROJECT_MAX_BLOCKS 1000000

@@ -18,6 +18,7 @@ n = int(os.environ.get('FRAMES', '9'))
 dolly = os.environ.get('DOLLY', '0') == '1'
 ofrom, oto = synthetic.default_windows(size, size, dolly)
 settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
-oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly, settings)
+oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly and int(os.environ.get('UPSAMPLE', '1')) == 1, settings,
+                       int(os.environ.get('UPSAMPLE', '1')))
 frames = common.render_frames(common.frame_cameras(settings, oc), oc, common.crop_size(settings), overlap=False)
 print(frames.shape, oc['tensorInpaPoints'].shape[-1])

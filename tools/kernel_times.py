@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 total = 0.0
 for key in ('k_project', 'k_tiles', 'k_fill_holes', 'k_crop_resize_u8'):
     for name, v in per.items():
-        if key in name:
+        if key + '(' in name:
             total += statistics.median(v)
             print('%-18s n=%3d median %6.1f us  min %6.1f  max %6.1f' % (key, len(v), statistics.median(v), min(v), max(v)))
 print('sum of medians %.1f us' % total)

@@ -12,7 +12,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         for k in KEYS:
-            if k in r['Kernel_Name']:
+            if k + '(' in r['Kernel_Name']:
                 per[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in KEYS:
     if k in per:

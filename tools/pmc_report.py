@@ -24,7 +24,7 @@ def load(path, counter):
 
 def pick(per, key):
     for name, vals in per.items():
-        if key in name:
+        if key + '(' in name or (key + '<') in name:
             return vals
     return []
 

@@ -20,7 +20,8 @@ dolly = os.environ.get('DOLLY', '0') == '1'
 ofrom, oto = synthetic.default_windows(size, size, dolly)
 settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
 dev = torch.device('cuda:0')
-oc = bench.build_scene(size, dev, os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly, settings)
+oc = bench.build_scene(size, dev, os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly and int(os.environ.get('UPSAMPLE', '1')) == 1, settings,
+                       int(os.environ.get('UPSAMPLE', '1')))
 cams = common.frame_cameras(settings, oc)
 crop = common.crop_size(settings)
 out = torch.empty(n, size, size, 3, dtype=torch.uint8, device=dev)
