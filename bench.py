@@ -292,7 +292,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%dx%d %s camera path, %d points (%s cloud), per frame: shift+zsplat+degrid+accumulate+fill+u8%s, frames left in HBM'
-                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, args.cloud if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2, '' if crop is None else '+crop/resize'),
+                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2, '' if crop is None else '+crop/resize'),
                        'frames_per_rank': args.steps, 'lanes': lanes, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast (untimed set-up, see cloud_broadcast_ms)'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
