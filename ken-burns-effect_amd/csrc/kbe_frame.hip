@@ -42,13 +42,13 @@ namespace {
 #define KBE_TILE_W 32
 #endif
 #ifndef KBE_TILE_H
-#define KBE_TILE_H 32
+#define KBE_TILE_H 16
 #endif
 #ifndef KBE_TILE_THREADS
-#define KBE_TILE_THREADS 512
+#define KBE_TILE_THREADS 256
 #endif
 #ifndef KBE_TILE_CAP
-#define KBE_TILE_CAP 1536
+#define KBE_TILE_CAP 768
 #endif
 #ifndef KBE_BUCKET_FACTOR
 #define KBE_BUCKET_FACTOR 12
