@@ -124,7 +124,7 @@ KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B,
  * -> uint8 HWC (common.py:238-255), as three launches and no floating-point atomics:
  *   1. project: every point is shifted and projected ONCE; its dblError is min-splatted into
  *      the z-buffer (one native global atomic umin on an order-preserving key) and a 16-byte
- *      record {ox, oy, dblError, point index} is appended to the bucket of each 32x32 target
+ *      record {ox, oy, dblError, point index} is appended to the bucket of each 32x16 target
  *      tile whose pixels it can colour (wave-aggregated appends);
  *   2. tiles: one workgroup per target tile loads the tile's z-buffer (+1 px halo), degrids it
  *      in LDS, threads the tile's records into per-pixel lists in LDS and lets every pixel
@@ -177,7 +177,7 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
                                     kbe_stream_t stream);
 
 /* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
- * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x32 tile degrid and a
+ * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
  * z-tested gather four channels at a time.  data [C,N]; render [C,H,W] normalised (:686), existing [H*W] the
  * weight sum; shift3 as in kbe_zsplat (NULL: none); scratch as kbe_render_frame (left clean).  Same results
  * as kbe_render_pointcloud up to the order of the fp32 sums. */

@@ -10,7 +10,7 @@
 //   k_project  one thread per point: shift (common.py:104-109), project (:447-484), ONE native
 //              atomic umin on the order-preserving key of dblError into the z-buffer (:486-506),
 //              and a 16-byte record {ox, oy, dblError, index} appended to the bucket of every
-//              32x32 target tile one of its four corners lies in (appends are aggregated per
+//              32x16 target tile one of its four corners lies in (appends are aggregated per
 //              wave: one counter atomic per distinct tile, records stored coalesced);
 //   k_tiles    one workgroup per tile: z-buffer tile + halo -> LDS, degrid (:525-568) in LDS,
 //              records -> per-pixel linked lists in LDS (bin = north-west corner; one
