@@ -50,7 +50,11 @@ __device__ __forceinline__ void apply_shift(const Camera& cam, float& x, float& 
         // z + 1e-7f == z for every z >= 2 (half an ulp is then > 1e-7): the ratio is exactly 1 and the division
         // (11 instructions) is skipped when that holds for the whole wave
         const float zz = z + 0.0000001f;
-        const float r = __all(zz == z) ? 1.0f : z / zz;
+        float r = 1.0f;
+        if (__ballot(zz != z) != 0ull) {        // wave-uniform
+            asm volatile("" ::: "memory");      // keeps the division inside the branch (it was if-converted into a select)
+            r = z / zz;
+        }
         x = x * r + cam.sx;
         y = y * r + cam.sy;
         z = z + cam.sz;
