@@ -596,3 +596,41 @@ def test_full_size_frame_against_the_oracle(K, oracle, dolly, step):
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
     src = (oc['tensorRawImage'][0].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
     assert abs(psnr(frame, src, 255.0) - psnr(ref, src, 255.0)) < 1e-3
+
+
+def test_random_small_scenes_against_the_oracle(K, oracle):
+    """Fuzz: random image sizes (down to 1 x 1, not multiples of the tile), random clouds (sparser and denser than
+    the raster, points behind the camera and far outside the view) and random cameras; z-buffer bits and frames
+    against the oracle."""
+    rng = np.random.default_rng(2024)
+    ok = oracle.OracleKernels('jacobi')
+    for case in range(120):
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 140))
+        N = int(rng.integers(0, 4 * H * W + 2))
+        focal = float(rng.choice([512.0, 409.6, 153.60000000000002, 64.0]))
+        z = rng.uniform(20.0, 3000.0, N).astype(np.float32)
+        z[rng.random(N) < 0.02] = rng.choice([0.0, -3.0, 0.0005, 0.01], int((rng.random(N) < 0.02).sum() or 1))[0] if N else 0
+        u = rng.uniform(-0.7 * W, 0.7 * W, N).astype(np.float32)
+        v = rng.uniform(-0.7 * H, 0.7 * H, N).astype(np.float32)
+        pts = torch.from_numpy(np.stack([u * z / np.float32(focal), v * z / np.float32(focal), z])[None].astype(np.float32))
+        img = torch.from_numpy(rng.random((1, 3, N), dtype=np.float32))
+        dep = torch.from_numpy(np.maximum(z, 1.0)[None, None].astype(np.float32))
+        shift3 = [float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)), float(rng.uniform(-15, 40))]
+        state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+        zp, zd, ex = (torch.empty(W * H, device='cuda') for _ in range(3))
+        rf = torch.empty(4, H, W, device='cuda')
+        frame = c(K.render_frame(state, shift3, focal, 120, render_f32=rf, existing_f32=ex, zee_f32=zd, zee_pre_f32=zp))
+        ostate = ok.prepare_cloud(pts, img, dep, W, H)
+        ref, ref_float, ref_ex = ok.render_frame(ostate, shift3, focal, 120, want_float=True)
+        z0, _ = oracle.zsplat(oracle.shift_points(pts, torch.tensor(shift3)), W, H, focal, 120)
+        tag = 'case %d: %dx%d, %d points, focal %g' % (case, W, H, N, focal)
+        assert_bits_equal(c(zp).reshape(H, W), z0.numpy()[0, 0], 'z-buffer, ' + tag)
+        assert_bits_equal(c(zd).reshape(H, W), oracle.degrid(z0, 'jacobi').numpy()[0, 0], 'degridded z-buffer, ' + tag)
+        assert np.array_equal(c(ex).reshape(H, W) > 0, ref_ex.numpy()[0, 0] > 0), tag
+        d = np.abs(frame.astype(np.int32) - ref.numpy().astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3, tag
+        # both hole-fill schedules (sparse clouds leave many holes)
+        for mode in (8, 16):
+            f2 = c(K.render_frame(state, shift3, focal, 120, stages=7 | mode))
+            d2 = np.abs(f2.astype(np.int32) - ref.numpy().astype(np.int32))
+            assert d2.max() <= 1 and (d2 > 0).mean() < 5e-3, tag + ', fill schedule %d' % mode
