@@ -634,3 +634,33 @@ def test_random_small_scenes_against_the_oracle(K, oracle):
             f2 = c(K.render_frame(state, shift3, focal, 120, stages=7 | mode))
             d2 = np.abs(f2.astype(np.int32) - ref.numpy().astype(np.int32))
             assert d2.max() <= 1 and (d2 > 0).mean() < 5e-3, tag + ', fill schedule %d' % mode
+
+
+def test_random_render_pointcloud_and_generate_mask_against_the_oracle(K, oracle):
+    """Fuzz of the two other users of the splat core: render_pointcloud for random batch / channel counts through the
+    tile renderer, and generate_mask on random rasters."""
+    rng = np.random.default_rng(7)
+    for case in range(40):
+        H, W, B, C = int(rng.integers(1, 70)), int(rng.integers(1, 100)), int(rng.integers(1, 3)), int(rng.integers(1, 10))
+        N = int(rng.integers(1, 3 * H * W + 2))
+        z = rng.uniform(30.0, 2000.0, (B, N)).astype(np.float32)
+        u = rng.uniform(-0.6 * W, 0.6 * W, (B, N)).astype(np.float32)
+        v = rng.uniform(-0.6 * H, 0.6 * H, (B, N)).astype(np.float32)
+        pts = torch.from_numpy(np.stack([u * z / 512.0, v * z / 512.0, z], 1).astype(np.float32))
+        data = torch.from_numpy(rng.standard_normal((B, C, N)).astype(np.float32))
+        r_t, e_t = K.render_pointcloud(pts.cuda(), data.cuda(), W, H, 512.0, 120, tiled=True)
+        r_o, e_o = oracle.render_pointcloud(pts, data, W, H, 512.0, 120, 'jacobi')
+        tag = 'case %d: %dx%d B%d C%d N%d' % (case, W, H, B, C, N)
+        assert np.array_equal(c(e_t) > 0, e_o.numpy() > 0), tag
+        assert (np.abs(c(r_t) - r_o.numpy()) <= 1e-4 * np.maximum(np.abs(r_o.numpy()), 1.0)).all(), tag
+    for case in range(30):
+        H, W, B = int(rng.integers(3, 60)), int(rng.integers(3, 90)), int(rng.integers(1, 3))     # median-5 reflect-pads by 2
+        disp = torch.from_numpy(rng.uniform(10.0, 120.0, (B, 1, H, W)).astype(np.float32))
+        depth = (512.0 * 120.0) / (disp + 1e-7)
+        pts = oracle.depth_to_points(depth, 512.0).view(B, 3, -1)
+        shift = torch.from_numpy(rng.uniform(-20.0, 20.0, (B, 3, 1)).astype(np.float32))
+        m, zee, ids = K.generate_mask_raw(pts.cuda(), shift.cuda(), W, H, 512.0, 120, want_tables=True)
+        mo, zo, io = oracle.generate_mask_raw(pts, shift, W, H, 512.0, 120)
+        assert_bits_equal(c(zee), zo.numpy(), 'generate_mask z-buffer, case %d' % case)
+        assert np.array_equal(c(ids), io.numpy()) and np.array_equal(c(m), mo.numpy()), case
+        assert np.array_equal(c(K.generate_mask(pts.cuda(), shift.cuda(), W, H, 512.0, 120)), oracle.generate_mask(pts, shift, W, H, 512.0, 120).numpy())
