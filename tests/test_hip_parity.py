@@ -664,3 +664,13 @@ def test_random_render_pointcloud_and_generate_mask_against_the_oracle(K, oracle
         assert_bits_equal(c(zee), zo.numpy(), 'generate_mask z-buffer, case %d' % case)
         assert np.array_equal(c(ids), io.numpy()) and np.array_equal(c(m), mo.numpy()), case
         assert np.array_equal(c(K.generate_mask(pts.cuda(), shift.cuda(), W, H, 512.0, 120)), oracle.generate_mask(pts, shift, W, H, 512.0, 120).numpy())
+
+
+def test_random_crops_against_the_written_algorithm(K, oracle):
+    rng = np.random.default_rng(99)
+    for case in range(80):
+        H, W = int(rng.integers(1, 150)), int(rng.integers(1, 300))
+        cw, ch = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+        f = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        out = c(K.crop_resize_u8(torch.from_numpy(f).cuda(), cw, ch))
+        assert np.array_equal(out, oracle.crop_resize_u8(f, cw, ch)), 'case %d: %dx%d crop %dx%d' % (case, W, H, cw, ch)
