@@ -211,7 +211,10 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs a)
         bool ok = i < (unsigned) a.N;
         float x = 0.0f, y = 0.0f, z = 0.0f, ox = 0.0f, oy = 0.0f;
         if (ok) {
-            x = a.points[i]; y = a.points[N + i]; z = a.points[2 * N + i];
+            const uint32_t off = i << 2;                                // N <= 2^30: a 32-bit byte offset on three uniform bases
+            x = *(const float*) ((const char*) a.points + off);
+            y = *(const float*) ((const char*) (a.points + N) + off);
+            z = *(const float*) ((const char*) (a.points + 2 * N) + off);
             apply_shift(cam, x, y, z);
             ok = project_xy(cam, x, y, z, ox, oy);
         }
@@ -382,9 +385,14 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 #if defined(KBE_PROBE_NO_RGBD)
     return make_float4(0.5f, 0.25f, 0.125f, 700.0f + (float) (id & 1));
 #endif
-    const float* I = a.image + id;
-    const size_t N = (size_t) a.N;
-    return make_float4(I[0], I[N], I[2 * N], a.depth_in[id]);
+    // uniform plane bases + one 32-bit byte offset per record (N <= 2^30): the loads take the scalar-base form and
+    // the lane computes a single shift instead of four 64-bit address additions
+    const uint32_t off = (uint32_t) id << 2;
+    const char* r = (const char*) a.image;
+    const char* g = (const char*) (a.image + (size_t) a.N);
+    const char* b = (const char*) (a.image + 2 * (size_t) a.N);
+    const char* d = (const char*) a.depth_in;
+    return make_float4(*(const float*) (r + off), *(const float*) (g + off), *(const float*) (b + off), *(const float*) (d + off));
 }
 
 // z-tested bilinear accumulation (common.py:586-669) of the records now in LDS, in registers.
@@ -1187,8 +1195,8 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
                             float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect,
                             int raster_w, int raster_n, kbe_stream_t stream)
 {
-    KBE_REQUIRE(scratch && frame_u8 && N >= 0 && W > 0 && H > 0 && (size_t) W * H < (1u << 31) && ((uintptr_t) scratch & 15) == 0,
-                "kbe_render_frame: bad arguments");
+    KBE_REQUIRE(scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H < (1u << 31) &&
+                ((uintptr_t) scratch & 15) == 0, "kbe_render_frame: bad arguments");
     KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame: cloud pointers are NULL");
     static const FillDirs dirs = make_fill_dirs();
     const hipStream_t s = (hipStream_t) stream;
