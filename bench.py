@@ -177,6 +177,7 @@ def main():
                     help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
     args = ap.parse_args()
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # before the first HIP call: RCCL needs dmabuf IPC on this stack
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
