@@ -313,6 +313,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(oc, cams, crop)
         print(json.dumps(line), flush=True)
     if world_size > 1:
+        dist.barrier()                  # rank 0 is still timing single kernels: leave together
         dist.destroy_process_group()
 
 
