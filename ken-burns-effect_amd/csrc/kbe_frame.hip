@@ -17,8 +17,14 @@
 //              ds_wrxchg per record), then every pixel walks the 4 bins that can reach it,
 //              z-tests (:639) and accumulates (:641) in registers, normalises (:686), applies
 //              the hole mask (:253), converts to uint8 (:255) and stores coalesced;
-//   k_fill     one half-wave per hole (:838-924); also resets z-buffer and bucket counters.
+//   k_fill_holes  the hole list (:838-924) with an exact branch-and-bound over the 16 directions, one
+//              half-wave per hole or (frames with very many holes) one lane per hole; also resets z-buffer
+//              and bucket counters;
+//   k_tiles_nc the same tile machinery for render_pointcloud with any channel count (4 channels at a time);
+//   kbe_render_video  the whole loop enqueued from C, consecutive frames on several streams ("lanes").
 // No accumulator or float render ever exists in HBM and no floating-point atomic is executed.
+// What bounds these kernels is instruction issue, not bandwidth: the code below is
+// written branch-free where lanes mostly agree and with wave-uniform work kept on the scalar unit.
 //
 // Numerics are those of oracle/kbe_oracle.c: the z-buffer is bit-exact (min commutes), degrid
 // is the out-of-place schedule, accumulation order is bucket order (not point order).
