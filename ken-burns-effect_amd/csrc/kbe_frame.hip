@@ -188,7 +188,10 @@ constexpr int PATCH_ROWS = 2;           // a raster unit is a 32 x 2 patch
 // and the z-splat atomic umin (:486-506) -- is done while they are in flight; only then are the results consumed
 // and the 16-byte records stored.  Points whose corner also sits in a tile's last ROW need a second round
 // (south, south-east); ~6 % of the waves of a raster.
-__global__ void __launch_bounds__(256) k_project(ProjectArgs a)
+#ifndef KBE_PROJECT_BLOCK
+#define KBE_PROJECT_BLOCK 64        // one wave per workgroup: fits the gaps other lanes' kernels leave (29.7 vs 30.6 us per frame at 256)
+#endif
+__global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
 {
     const int lane = threadIdx.x & 63;
     // wave-uniform values are made scalar explicitly (the unit -> point index arithmetic below then runs on the
@@ -1035,7 +1038,10 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
     if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + s];
 }
 
-__global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
+#ifndef KBE_FILL_BLOCK
+#define KBE_FILL_BLOCK 256
+#endif
+__global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
                                                     const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
                                                     FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
@@ -1059,7 +1065,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
     // (common.py:880-885) without walking there.  Exact, and it is what makes a zoomed-out (dolly) frame,
     // where most of the image is empty border, cheap.
-    __shared__ int s_bb[4][4];
+    __shared__ int s_bb[KBE_FILL_BLOCK / 64][4];
     int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
     if ((int) (blockIdx.x * (blockDim.x >> 5)) >= n) return;    // no hole for this block (whole block: uniform)
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
@@ -1073,7 +1079,7 @@ __global__ void __launch_bounds__(256) k_fill_holes(const int* __restrict__ hole
     }
     if ((threadIdx.x & 63) == 0) { s_bb[threadIdx.x >> 6][0] = bx0; s_bb[threadIdx.x >> 6][1] = by0; s_bb[threadIdx.x >> 6][2] = bx1; s_bb[threadIdx.x >> 6][3] = by1; }
     __syncthreads();
-    for (int w = 0; w < 4; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
+    for (int w = 0; w < KBE_FILL_BLOCK / 64; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
     const int wpr = (W + 31) >> 5;              // mask words per row
     // fill_mode: 0 = by hole count, 1 = one lane per hole, 2 = one half-wave per hole (the last two: tests, A/B)
     if (fill_mode == 1 || (fill_mode == 0 && n >= KBE_FILL_SERIAL_MIN)) {       // uniform over the launch
@@ -1221,9 +1227,9 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
 #ifndef KBE_PROJECT_MAX_BLOCKS
 #define KBE_PROJECT_MAX_BLOCKS 1000000
 #endif
-        unsigned blocks = N > 0 ? blocks_for((size_t) N, 256) + 2 : 1;
+        unsigned blocks = N > 0 ? blocks_for((size_t) N, KBE_PROJECT_BLOCK) + 2 : 1;
         if (blocks > KBE_PROJECT_MAX_BLOCKS) blocks = KBE_PROJECT_MAX_BLOCKS;
-        hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_project, dim3(blocks), dim3(KBE_PROJECT_BLOCK), 0, s, p);
         if ((rc = launched("kbe_render_frame/project"))) return rc;
     }
     if (stages & KBE_STAGE_TILES) {
@@ -1241,10 +1247,11 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
 #ifndef KBE_FILL_MAX_BLOCKS
 #define KBE_FILL_MAX_BLOCKS 2048
 #endif
-        const unsigned fill_blocks = (unsigned) (hw / 64 < KBE_FILL_MAX_BLOCKS ? (hw / 64 > 0 ? hw / 64 : 1) : KBE_FILL_MAX_BLOCKS);
+        const size_t want_fill = hw / 64, max_fill = (size_t) KBE_FILL_MAX_BLOCKS * 256 / KBE_FILL_BLOCK;       // the same number of threads
+        const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(256), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
+        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
                            (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) ? 2 : 0));
         rc = launched("kbe_render_frame/fill");
