@@ -467,7 +467,10 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
 #define KBE_TICK(i) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tiles(TileArgs a)
+#ifndef KBE_TILE_WAVES
+#define KBE_TILE_WAVES 4
+#endif
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES))) k_tiles(TileArgs a)
 {
     __shared__ TileLds L;
 #if defined(KBE_PROBE_TIMING)
