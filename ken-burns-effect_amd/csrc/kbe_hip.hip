@@ -356,14 +356,20 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
     if (tid < n_pc3) {
         const int pc = tid / 3, c = tid - pc * 3;
         const int x0 = (min(max(ipx + px_lo + pc, 0), W - 1) - rx0) * 3 + c, x1 = (min(max(ipx + px_lo + pc + 1, 0), W - 1) - rx0) * 3 + c;
-        int o = s_ro[0];
-        int t0 = raw[o + x0], t1 = raw[o + x1];
-        for (int pr = 0; pr < n_pr; pr++) {
-            o = s_ro[pr + 1];
-            const int u0 = raw[o + x0], u1 = raw[o + x1];
-            const int t = t0 * a11 + t1 * a12 + u0 * a21 + u1 * a22;
-            patch[pr * (int) sizeof(s_patch[0]) + tid] = (uint8_t) ((t + (1 << 15)) >> 16);
-            t0 = u0; t1 = u1;
+        if ((a12 | a21 | a22) == 0) {
+            // an odd crop of an even frame (or the reverse) starts on a whole pixel: a11 = 65536 and the patch IS the
+            // raw rectangle ((t * 65536 + 32768) >> 16 == t): a copy (wave-uniform branch)
+            for (int pr = 0; pr < n_pr; pr++) patch[pr * (int) sizeof(s_patch[0]) + tid] = raw[s_ro[pr] + x0];
+        } else {
+            int o = s_ro[0];
+            int t0 = raw[o + x0], t1 = raw[o + x1];
+            for (int pr = 0; pr < n_pr; pr++) {
+                o = s_ro[pr + 1];
+                const int u0 = raw[o + x0], u1 = raw[o + x1];
+                const int t = t0 * a11 + t1 * a12 + u0 * a21 + u1 * a22;
+                patch[pr * (int) sizeof(s_patch[0]) + tid] = (uint8_t) ((t + (1 << 15)) >> 16);
+                t0 = u0; t1 = u1;
+            }
         }
     }
     __syncthreads();
