@@ -21,7 +21,7 @@
  *   - Re-entrant, no global state: safe with one process per GPU or one stream per thread.
  *   - Inputs must be finite.  A point whose projection overflows int range is dropped (the
  *     reference's behaviour there is platform-defined; see DESIGN.md "Deviations").
- *   - Sizes: W*H < 2^31 pixels; the frame loop (kbe_render_frame*, kbe_render_video, kbe_render_pointcloud_tiled)
+ *   - Sizes: W*H < 2^31 pixels (2^30 for the frame loop); the frame loop (kbe_render_frame*, kbe_render_video, kbe_render_pointcloud_tiled)
  *     takes clouds of up to 2^30 points.
  *
  * Numerical contract: identical to oracle/kbe_oracle.c (which is pinned bit-for-bit to the

@@ -505,12 +505,16 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
     for (int u = 0; u < PER; u++) rr[u] = B[tid + u * TILE_THREADS];
     uint32_t zk[ZPER];
+    bool zin[ZPER];
 #pragma unroll
     for (int u = 0; u < ZPER; u++) {
         const int i = tid + u * TILE_THREADS;
         const int py = i / KW, pxl = i - py * KW;
-        const int x = min(max(x0 - 1 + pxl, 0), W - 1), y = min(max(y0 - 1 + py, 0), H - 1);     // clamped: always a valid address
-        zk[u] = a.zkeys[(size_t) y * W + x];
+        const int xr = x0 - 1 + pxl, yr = y0 - 1 + py;
+        zin[u] = inside(xr, yr, W, H);
+        const int x = min(max(xr, 0), W - 1), y = min(max(yr, 0), H - 1);       // clamped: always a valid address
+        // W * H < 2^31 / 4: a 32-bit byte offset on the uniform base
+        zk[u] = *(const uint32_t*) ((const char*) a.zkeys + (((uint32_t) y * (uint32_t) W + (uint32_t) x) << 2));
     }
     for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
     if (tid == 0) {
@@ -530,9 +534,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
     for (int u = 0; u < ZPER; u++) {
         const int i = tid + u * TILE_THREADS;
-        const int py = i / KW, pxl = i - py * KW;
         if (i < KH * KW) {
-            const float z = zkey_decode(inside(x0 - 1 + pxl, y0 - 1 + py, W, H) ? zk[u] : KBE_ZKEY_EMPTY);     // common.py:430 outside
+            const float z = zkey_decode(zin[u] ? zk[u] : KBE_ZKEY_EMPTY);       // common.py:430 outside
             L.zpre[i] = z;
             band = band && degrid_fast_ok(z);
         }
@@ -1210,7 +1213,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
                             float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect,
                             int raster_w, int raster_n, kbe_stream_t stream)
 {
-    KBE_REQUIRE(scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H < (1u << 31) &&
+    KBE_REQUIRE(scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
                 ((uintptr_t) scratch & 15) == 0, "kbe_render_frame: bad arguments");
     KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame: cloud pointers are NULL");
     static const FillDirs dirs = make_fill_dirs();
@@ -1275,7 +1278,7 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
                                 double baseline, const float* shift3, void* scratch, float* render, float* existing,
                                 kbe_stream_t stream)
 {
-    KBE_REQUIRE(scratch && render && existing && N >= 0 && C > 0 && W > 0 && H > 0 && (size_t) W * H < (1u << 31) &&
+    KBE_REQUIRE(scratch && render && existing && N >= 0 && C > 0 && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
                 ((uintptr_t) scratch & 15) == 0, "kbe_render_pointcloud_tiled: bad arguments");
     KBE_REQUIRE(N == 0 || (points && data), "kbe_render_pointcloud_tiled: cloud pointers are NULL");
     const hipStream_t s = (hipStream_t) stream;
