@@ -162,7 +162,7 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=256)
+    ap.add_argument('--steps', type=int, default=1024, help='timed frames per rank (a 128-frame video repeated is the same work; long enough for the queue ramp to vanish)')
     ap.add_argument('--warmup', type=int, default=128, help='untimed frames first (the clocks need a few ms of load: 8 frames read 6 %% slower than 256)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--dolly', action='store_true')
