@@ -14,6 +14,8 @@ point-cloud side of :meth:`Inpaint.pointcloud_inpainting`: validity mask, unproj
 The network is a 4-row x 4-column GridNet: rows carry 32/64/128/256 features at full, 1/2,
 1/4, 1/8 resolution; columns 0-1 stream downwards, columns 2-3 stream upwards.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -97,6 +99,9 @@ class Inpaint(nn.Module):
         self.spectral_norm = False
         self.tensorMean = None
         self.tensorStd = None
+        # optional reduced-precision GridNet (torch.bfloat16 / torch.float16 under autocast, MIOpen); None = fp32 as the
+        # reference, the only setting the parity tests cover
+        self.compute_dtype = None
 
         self.moduleContext = nn.Sequential(_conv3(4, 64), _act(64), _conv3(64, 64), _act(64))
         # image(3) :: disparity(1) :: context(64) :: mask(1)
@@ -148,8 +153,11 @@ class Inpaint(nn.Module):
                 tensorContext = self.moduleContext(torch.cat([tensorImage, tensorDisparity], 1))
             tensorData = torch.cat([tensorImage, tensorDisparity, tensorContext], 1)
 
-        top = self._grid(self.moduleInput(torch.cat([tensorData, tensorMasks], 1)))
-        tensorImage, tensorDisparity = self.normalize_images_disp(self.moduleImage(top), self.moduleDisparity(top), not_normed=False)
+        fast = self.compute_dtype is not None and tensorMasks.is_cuda and not self.training
+        with (torch.autocast('cuda', dtype=self.compute_dtype) if fast else contextlib.nullcontext()):
+            top = self._grid(self.moduleInput(torch.cat([tensorData, tensorMasks], 1)))
+            outImage, outDisparity = self.moduleImage(top), self.moduleDisparity(top)
+        tensorImage, tensorDisparity = self.normalize_images_disp(outImage.float(), outDisparity.float(), not_normed=False)
         return {
             'tensorExisting': tensorMasks,
             'tensorImage': tensorImage if self.training else tensorImage.clamp(0.0, 1.0),

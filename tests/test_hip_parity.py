@@ -674,3 +674,23 @@ def test_random_crops_against_the_written_algorithm(K, oracle):
         f = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         out = c(K.crop_resize_u8(torch.from_numpy(f).cuda(), cw, ch))
         assert np.array_equal(out, oracle.crop_resize_u8(f, cw, ch)), 'case %d: %dx%d crop %dx%d' % (case, W, H, cw, ch)
+
+
+def test_reduced_precision_inpaint_is_opt_in_and_close(K):
+    """the GridNet may run in fp16 / bf16 under autocast when asked to; fp32 (the reference's arithmetic)
+    is the default and the only setting the parity tests cover."""
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    net = synthetic.seeded_fill_(Inpaint(), 3).cuda().eval()
+    assert net.compute_dtype is None
+    g0 = torch.Generator('cuda').manual_seed(5)
+    data = torch.randn(1, 68, 96, 128, device='cuda', generator=g0)
+    mask = (torch.rand(1, 1, 96, 128, device='cuda', generator=g0) > 0.2).float()
+    with torch.no_grad():
+        net.normalize_images_disp(torch.rand(1, 3, 96, 128, device='cuda'), torch.rand(1, 1, 96, 128, device='cuda') * 50, not_normed=True)
+        base = net.forward(tensorData=data, tensorMasks=mask)
+        net.compute_dtype = torch.float16
+        half = net.forward(tensorData=data, tensorMasks=mask)
+    assert half['tensorImage'].dtype == torch.float32 and half['tensorDisparity'].dtype == torch.float32
+    assert float((half['tensorImage'] - base['tensorImage']).abs().max()) < 0.05
+    assert float((half['tensorDisparity'] - base['tensorDisparity']).abs().max()) < 0.05 * max(1.0, float(base['tensorDisparity'].abs().max()))

@@ -8,6 +8,7 @@ size = int(os.environ.get('SIZE', '1024'))
 if os.environ.get('BENCHMARK') == '1':
     torch.backends.cudnn.benchmark = True
 net = synthetic.seeded_fill_(Inpaint(), 3).to(dev).eval()
+net.compute_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(os.environ.get('DTYPE', ''))
 data = torch.randn(1, 68, size, size, device=dev); mask = torch.ones(1, 1, size, size, device=dev)
 if os.environ.get('CL') == '1':
     net = net.to(memory_format=torch.channels_last); data = data.contiguous(memory_format=torch.channels_last)
@@ -19,4 +20,9 @@ def T(fn, n=5):
 with torch.no_grad():
     net.normalize_images_disp(torch.rand(1, 3, size, size, device=dev), torch.rand(1, 1, size, size, device=dev), not_normed=True)
     first, steady = T(lambda: net.forward(tensorData=data, tensorMasks=mask))
-    print('FIND=%s BENCHMARK=%s CL=%s: first call %.0f ms, steady %.1f ms' % (os.environ.get('MIOPEN_FIND_MODE'), os.environ.get('BENCHMARK'), os.environ.get('CL'), first, steady))
+    ref = os.environ.get('DTYPE')
+    print('FIND=%s BENCHMARK=%s CL=%s DTYPE=%s: first call %.0f ms, steady %.1f ms' % (os.environ.get('MIOPEN_FIND_MODE'), os.environ.get('BENCHMARK'), os.environ.get('CL'), ref, first, steady))
+    out = net.forward(tensorData=data, tensorMasks=mask)
+    net.compute_dtype = None
+    base = net.forward(tensorData=data, tensorMasks=mask)
+    print('   max |image - fp32 image| = %.4g, max |disparity - fp32| = %.4g (relative to max %.4g)' % (float((out['tensorImage'] - base['tensorImage']).abs().max()), float((out['tensorDisparity'] - base['tensorDisparity']).abs().max()), float(base['tensorDisparity'].abs().max())))
