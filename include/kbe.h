@@ -168,10 +168,12 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_PROJECT 1
 #define KBE_STAGE_TILES 2
 #define KBE_STAGE_FILL 4
-/* with KBE_STAGE_FILL: force one of the two hole-fill schedules (default: chosen by the frame's hole count; the
- * results are identical -- tests and A/B measurements use these) */
+/* with KBE_STAGE_FILL: the hole-fill schedule.  Default: one half-wave per hole.  _BY_COUNT: one lane per hole for
+ * frames with more than ~49 k holes (less work, longer dependent chains: what kbe_render_video uses when frames of
+ * several lanes overlap).  _PER_LANE / _PER_HALFWAVE force one.  The results are identical. */
 #define KBE_STAGE_FILL_PER_LANE 8
 #define KBE_STAGE_FILL_PER_HALFWAVE 16
+#define KBE_STAGE_FILL_BY_COUNT 32
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,

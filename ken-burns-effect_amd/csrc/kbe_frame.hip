@@ -1087,7 +1087,9 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
     __syncthreads();
     for (int w = 0; w < KBE_FILL_BLOCK / 64; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
     const int wpr = (W + 31) >> 5;              // mask words per row
-    // fill_mode: 0 = by hole count, 1 = one lane per hole, 2 = one half-wave per hole (the last two: tests, A/B)
+    // fill_mode: 0 = by hole count (the multi-lane frame loop: the per-lane schedule does less work but has long
+    // dependent chains, which only pays when other frames' kernels fill the chip meanwhile), 1 = one lane per hole,
+    // 2 = one half-wave per hole (a frame rendered on its own)
     if (fill_mode == 1 || (fill_mode == 0 && n >= KBE_FILL_SERIAL_MIN)) {       // uniform over the launch
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int h = gtid; h < n; h += gsz) {
@@ -1259,7 +1261,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
-                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) ? 2 : 0));
+                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0));
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -1356,8 +1358,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         uint8_t* raw = stage + (size_t) l * fb;
         int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL, crop ? rect : nullptr, raster_w, raster_n,
-                                         (kbe_stream_t) ls[l]);
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL | (lanes > 1 ? KBE_STAGE_FILL_BY_COUNT : 0),
+                                         crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
         return rc;
     };
