@@ -992,8 +992,9 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
         float fa_x = (float) x, fa_y = (float) y, fb_x = fa_x, fb_y = fa_y;
         int ax = x, ay = y, bx = x, by = y;
         bool hit_a = false, hit_b = false, dead = false;
-        while (!dead && !(hit_a && hit_b)) {
-            // a batch of SB steps per unfinished end: positions first (they do not depend on the data), loads together
+        // phase 1: both ends together, until one of them has hit
+        while (!dead && !hit_a && !hit_b) {
+            // a batch of SB steps per end: positions first (they do not depend on the data), loads together
             int pax[SB], pay[SB], pbx[SB], pby[SB];
             uint32_t wa[SB], wb[SB];
             bool ina[SB], inb[SB];
@@ -1029,6 +1030,40 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
             const float ex = (float) (bx - ax), ey = (float) (by - ay);
             const float s_now = ex * ex + ey * ey;
             if (s_now >= best_s) { dead = true; break; }       // sqrtf is monotone: this direction cannot become STRICTLY shorter (:900)
+        }
+        // phase 2: the end that is still looking walks alone (half the arithmetic per step)
+        if (!dead && hit_a != hit_b) {
+            const bool is_a = !hit_a;
+            const float sdx = is_a ? -ddx : ddx, sdy = is_a ? -ddy : ddy;
+            float fx = is_a ? fa_x : fb_x, fy = is_a ? fa_y : fb_y;
+            int cx = is_a ? ax : bx, cy = is_a ? ay : by;
+            const int ox = is_a ? bx : ax, oy = is_a ? by : ay;            // the end that has hit stays put
+            bool hit = false;
+            while (!dead && !hit) {
+                int px_[SB], py_[SB];
+                uint32_t wv[SB];
+                bool in_[SB];
+#pragma unroll
+                for (int k = 0; k < SB; k++) {
+                    fx += sdx; px_[k] = (int) roundf(fx);
+                    fy += sdy; py_[k] = (int) roundf(fy);
+                    in_[k] = ((unsigned) px_[k] < (unsigned) W) & ((unsigned) py_[k] < (unsigned) H);
+                    wv[k] = mask[in_[k] ? (unsigned) py_[k] * (unsigned) wpr + ((unsigned) px_[k] >> 5) : 0u];
+                }
+#pragma unroll
+                for (int k = 0; k < SB; k++) {
+                    if (!hit && !dead) {
+                        cx = px_[k]; cy = py_[k];
+                        if (!in_[k]) dead = true;
+                        else if ((wv[k] >> (cx & 31)) & 1u) hit = true;
+                    }
+                }
+                if (dead || hit) break;
+                if ((cx < bx0 && sdx <= 0.0f) || (cx > bx1 && sdx >= 0.0f) || (cy < by0 && sdy <= 0.0f) || (cy > by1 && sdy >= 0.0f)) { dead = true; break; }
+                const float ex = (float) (cx - ox), ey = (float) (cy - oy);
+                if (ex * ex + ey * ey >= best_s) { dead = true; break; }
+            }
+            if (is_a) { ax = cx; ay = cy; } else { bx = cx; by = cy; }
         }
         if (dead) continue;
         const float ex = (float) (bx - ax), ey = (float) (by - ay);
