@@ -202,7 +202,10 @@ __device__ __forceinline__ float degrid_pixel_fast(float c, const float (&a)[4],
         s += t ? a[k] : 0.0f;                                   // s + 0.0f == s: same sum, same order as :559-560
         s += t ? d[k] : 0.0f;
     }
-    const float y = n == 3 ? 0.16666667f : (n == 1 ? 0.5f : (n == 2 ? 0.25f : 0.125f));
+    // y = RN(1 / (2n)): 2^-1, 2^-2, 2^-3 for n = 1, 2, 4 by exponent arithmetic, the rounded sixth for n = 3 (the
+    // select chain n == 3 ? .. : n == 1 ? .. compiled into divergent branches)
+    const int e = n - (n >> 2);
+    const float y = n == 3 ? 0.16666667f : __int_as_float(0x3F800000 - (e << 23));
     const float q = s * y;
     const float mean = __builtin_fmaf(__builtin_fmaf(-(float) (2 * n), q, s), y, q);
     return n > 0 ? fminf(c, mean) : c;
