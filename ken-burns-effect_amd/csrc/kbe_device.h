@@ -216,9 +216,9 @@ __device__ __forceinline__ bool degrid_fast_ok(float z) { return (z >= 524288.0f
 // common.py:255: (x * 255.0).clip(0.0, 255.0).astype(np.uint8)
 __device__ __forceinline__ uint8_t to_u8(float v)
 {
-    v = v * 255.0f;
-    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-    return (uint8_t) (int) v;
+    // clip as one median-of-three (finite inputs: identical to the two comparisons; a NaN would become 0 either way
+    // after the conversion)
+    return (uint8_t) (int) __builtin_amdgcn_fmed3f(v * 255.0f, 0.0f, 255.0f);
 }
 
 // fire-and-forget fp32 add: the native global_atomic_add_f32 (the buffers are ordinary

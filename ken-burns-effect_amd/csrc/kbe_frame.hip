@@ -698,11 +698,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         hm[m] = __ballot(hole[m]);
         n_holes += __popcll(hm[m]);
     }
-    // ONE returning atomic per wave reserves its slots in the hole list; it is issued here and its result is
-    // only consumed after the stores and the bounding-box reduction below (a ~2 us round trip otherwise
-    // spent waiting)
-    int hole_base = 0;
-    if (n_holes > 0 && lane == 0) hole_base = atomicAdd(a.hole_count, n_holes);
     int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
@@ -741,19 +736,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         int* sb = L.head;
         if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; }
     }
-    if (n_holes > 0) {                              // wave-uniform
-        int base = __builtin_amdgcn_readfirstlane(hole_base);
-#pragma unroll
-        for (int m = 0; m < PIX_PER_THREAD; m++) {
-            const int q = tid + m * TILE_THREADS;
-            const int ly = q / TW, lx = q - ly * TW;
-            const int slot = base + __popcll(hm[m] & ((1ull << lane) - 1ull));
-            // (the list holds W*H entries, enough for any one frame; the bound only matters when this launch is
-            // repeated without the projection launch that zeroes the count, as bench.py does to time it alone)
-            if (hole[m] && slot < W * H) a.holes[slot] = (y0 + ly) * W + x0 + lx;
-            base += __popcll(hm[m]);
-        }
-    }
     KBE_TICK(8);
     __syncthreads();
     if (tid == 0) {
@@ -780,6 +762,23 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             const int q = i / 3, ch = i - q * 3;
             const int ly = q / TW, lx = q - ly * TW;
             if (x0 + lx < W && y0 + ly < H) a.frame[((size_t) (y0 + ly) * W + x0 + lx) * 3 + ch] = s_u8[i];
+        }
+    }
+    // The hole list last: ONE returning atomic per wave reserves its slots (a ~2 us round trip).  Anywhere earlier the
+    // wave would sit in it in front of a barrier and hold up its whole workgroup; here it only delays its own exit.
+    if (n_holes > 0) {                              // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.hole_count, n_holes);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) {
+            const int q = tid + m * TILE_THREADS;
+            const int ly = q / TW, lx = q - ly * TW;
+            const int slot = base + __popcll(hm[m] & ((1ull << lane) - 1ull));
+            // (the list holds W*H entries, enough for any one frame; the bound only matters when this launch is
+            // repeated without the projection launch that zeroes the count, as bench.py does to time it alone)
+            if (hole[m] && slot < W * H) a.holes[slot] = (y0 + ly) * W + x0 + lx;
+            base += __popcll(hm[m]);
         }
     }
     KBE_TICK(10);
