@@ -612,10 +612,25 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             }
             KBE_TICK(3);
 #if !defined(KBE_PROBE_SKIP_INSERT)
+            {
+                // all of this thread's list exchanges first, then the records with the links they returned (one after
+                // the other each exchange was an LDS round trip in front of the next)
+                int nxt[PER];
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int i = tid + u * TILE_THREADS;
-                if (i < n) lds_insert(L, i, rr[u].x, rr[u].y, rr[u].z, cc[u], x0, y0);
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    nxt[u] = -1;
+                    if (i < n) {
+                        const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
+                        L.rgbd[i] = cc[u];
+                        nxt[u] = atomicExch(&L.head[by * BW + bx], i);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    if (i < n) L.rec[i] = make_float4(rr[u].x, rr[u].y, rr[u].z, __int_as_float(nxt[u]));
+                }
             }
 #endif
             KBE_TICK(4);
