@@ -140,7 +140,7 @@ __device__ __forceinline__ int winner_corner(const Proj& p)
 
 __device__ __forceinline__ bool inside(int x, int y, int W, int H)
 {
-    return (x >= 0) & (x < W) & (y >= 0) & (y < H);
+    return ((unsigned) x < (unsigned) W) & ((unsigned) y < (unsigned) H);      // two compares instead of four
 }
 
 // `a + 1.0` evaluated in double (common.py:556-557, :639) equals the fp32 sum exactly when a lies in

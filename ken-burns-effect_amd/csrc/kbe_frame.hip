@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
         }
         Proj p;
         p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
-        ok = ok && (p.nwx + 1 >= 0) & (p.nwx < cam.W) & (p.nwy + 1 >= 0) & (p.nwy < cam.H);       // touches the image at all
+        ok = ok && ((unsigned) (p.nwx + 1) <= (unsigned) cam.W) & ((unsigned) (p.nwy + 1) <= (unsigned) cam.H);      // touches the image at all: -1 <= nw < size
         const bool spx = ok && ((p.nwx + 1) % TW == 0), spy = ok && ((p.nwy + 1) % TH == 0);
         const int tx0 = p.nwx >= 0 ? p.nwx / TW : -1, ty0 = p.nwy >= 0 ? p.nwy / TH : -1;          // nw >= -1 when ok
 
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const int tx = tx0 + e;
-            want[e] = ok && (e == 0 || spx) && tx >= 0 && ty0 >= 0 && tx < a.tiles_x && ty0 < a.tiles_y;
+            want[e] = ok && (e == 0 || spx) && ((unsigned) tx < (unsigned) a.tiles_x) & ((unsigned) ty0 < (unsigned) a.tiles_y);
 #if defined(KBE_PROBE_NO_SPILLS)
             if (e > 0) want[e] = false;
 #endif
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const int tx = tx0 + e, ty = ty0 + 1;
-                want[e] = spy && (e == 0 || spx) && tx >= 0 && ty >= 0 && tx < a.tiles_x && ty < a.tiles_y;
+                want[e] = spy && (e == 0 || spx) && ((unsigned) tx < (unsigned) a.tiles_x) & ((unsigned) ty < (unsigned) a.tiles_y);
                 tgt[e] = ty * a.tiles_x + tx;
                 base[e] = 0;
             }
