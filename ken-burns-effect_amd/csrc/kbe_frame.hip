@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
         p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
         ok = ok && ((unsigned) (p.nwx + 1) <= (unsigned) cam.W) & ((unsigned) (p.nwy + 1) <= (unsigned) cam.H);      // touches the image at all: -1 <= nw < size
         const bool spx = ok && ((p.nwx + 1) % TW == 0), spy = ok && ((p.nwy + 1) % TH == 0);
-        const int tx0 = p.nwx >= 0 ? p.nwx / TW : -1, ty0 = p.nwy >= 0 ? p.nwy / TH : -1;          // nw >= -1 when ok
+        static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "tile sizes are powers of two");
+        const int tx0 = p.nwx >> __builtin_ctz(TW), ty0 = p.nwy >> __builtin_ctz(TH);              // floor division: -1 for nw == -1
 
         // round 0: own tile and east neighbour; the counter atomics go out now
         TileGroup grp[2];
