@@ -694,3 +694,16 @@ def test_reduced_precision_inpaint_is_opt_in_and_close(K):
     assert half['tensorImage'].dtype == torch.float32 and half['tensorDisparity'].dtype == torch.float32
     assert float((half['tensorImage'] - base['tensorImage']).abs().max()) < 0.05
     assert float((half['tensorDisparity'] - base['tensorDisparity']).abs().max()) < 0.05 * max(1.0, float(base['tensorDisparity'].abs().max()))
+
+
+def test_sharded_video_on_the_hip_path_two_ranks():
+    """sharding.process_kenburns_sharded with two processes on this GPU (gloo rendezvous on 127.0.0.1): cloud
+    broadcast, round-robin frames, gather -- the union equals a single-process render."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29533', os.path.join(root, 'tools', 'sharded_check.py')],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
