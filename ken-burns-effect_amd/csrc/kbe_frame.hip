@@ -81,6 +81,7 @@ struct Scratch {                            // carve-out of the caller's scratch
     int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
     int* hole_count;        // [1]
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
+    uint32_t* coarse;       // [n_tiles]: bit (cy * (TW/8) + cx) = the 8x8 block (cx, cy) of the tile holds a valid pixel
     int* holes;             // [H*W]
     float* depth;           // [H*W]  render[3] * (existing > 0): the fill compares the two ends of a ray with it
     uint32_t* mask;         // [H][ceil(W/32)]  bit = depth > 0: what the fill walks on (32x smaller than the plane)
@@ -102,6 +103,7 @@ Scratch carve(void* base, int W, int H)
     s.tile_count = (int*) p;      p += align16(4 * n_tiles * CNT_STRIDE);
     s.hole_count = (int*) p;      p += 16;
     s.bbox = (int4*) p;           p += align16(16 * n_tiles);
+    s.coarse = (uint32_t*) p;     p += align16(4 * n_tiles);
     s.holes = (int*) p;           p += align16(4 * hw);
     s.depth = (float*) p;         p += align16(4 * hw);
     s.mask = (uint32_t*) p;       p += align16(4 * (size_t) H * ((W + 31) / 32));
@@ -113,7 +115,7 @@ size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
+    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
            align16(4 * (size_t) H * ((W + 31) / 32)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
@@ -352,6 +354,7 @@ struct TileArgs {
     int* holes;
     int* hole_count;
     int4* bbox;
+    uint32_t* coarse;
     float* render;          // optional [4,H,W] (unfilled; the fill kernel patches the holes)
     float* existing;        // optional [H*W]
     float* zee;             // optional [H*W] degridded z-buffer
@@ -715,6 +718,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         n_holes += __popcll(hm[m]);
     }
     int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
+    uint32_t cbits = 0;
+    static_assert((TW / 8) * (TH / 8) <= 32 && TH % 8 == 0, "the coarse block bits of a tile fit a word");
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
         const int q = tid + m * TILE_THREADS;
@@ -734,6 +739,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                 const int wrow = y0 + ((tid >> 6) << 1) + m * (TILE_THREADS / TW);
                 vx0 = min(vx0, x0 + __builtin_ctz(any)); vx1 = max(vx1, x0 + 31 - __builtin_clz(any));
                 vy0 = min(vy0, lo ? wrow : wrow + 1); vy1 = max(vy1, hi ? wrow + 1 : wrow);
+                // which 8 x 8 blocks of the tile hold a valid pixel (the hole fill skips through blocks that do not)
+                const uint32_t cols = (any & 0xFFu ? 1u : 0u) | (any & 0xFF00u ? 2u : 0u) | (any & 0xFF0000u ? 4u : 0u) | (any & 0xFF000000u ? 8u : 0u);
+                cbits |= cols << ((TW / 8) * ((wrow - y0) >> 3));
             }
         }
         if (in) {
@@ -750,7 +758,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         // global atomics here -- even one cache line per tile row, even with a look first -- serialised so
         // badly across XCDs that they added 80-350 us per frame
         int* sb = L.head;
-        if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; }
+        if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; sb[64 + (tid >> 6)] = (int) cbits; }
     }
     KBE_TICK(8);
     __syncthreads();
@@ -761,6 +769,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             bb.x = min(bb.x, sb[4 * w]); bb.y = min(bb.y, sb[4 * w + 1]); bb.z = max(bb.z, sb[4 * w + 2]); bb.w = max(bb.w, sb[4 * w + 3]);
         }
         a.bbox[tile] = bb;
+        uint32_t cb = 0;
+        for (int w = 0; w < TILE_THREADS / 64; w++) cb |= (uint32_t) sb[64 + w];
+        a.coarse[tile] = cb;
     }
     KBE_TICK(9);
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
@@ -979,6 +990,7 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 #ifndef KBE_FILL_SERIAL_BATCH
 #define KBE_FILL_SERIAL_BATCH 8
 #endif
+constexpr int COARSE_WORDS = 2048;     // 8 x 8 blocks of images up to 2048 x 2048 (larger: the walks do not skip)
 #ifndef KBE_FILL_SERIAL_MIN
 #define KBE_FILL_SERIAL_MIN 49152       // holes per frame from which one lane per hole beats one half-wave per hole
 #endif
@@ -992,9 +1004,13 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 // neighbouring holes (the list is written tile by tile), so their walks have similar lengths.
 __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
                                                  int wpr, const FillDirs& dirs, int bx0, int by0, int bx1, int by1,
-                                                 uint8_t* __restrict__ frame, float* __restrict__ render)
+                                                 uint8_t* __restrict__ frame, float* __restrict__ render,
+                                                 const uint32_t* near, int c_wpr)
 {
     constexpr int SB = KBE_FILL_SERIAL_BATCH;
+    static_assert(SB <= 8, "a skipped batch must stay within one 8 x 8 block of where it ends");
+    // true when no valid pixel lies within one block of the block of in-image position (px_, py_)
+    auto far_from_valid = [&](int px_, int py_) { return !((near[(py_ >> 3) * c_wpr + (px_ >> 8)] >> ((px_ >> 3) & 31)) & 1u); };
     const int y = px / W, x = px - y * W;
     float best = 1000000.0f;                    // dblShortest (:854)
     float best_s = INFINITY;                    // ex^2 + ey^2 of the best direction (what `best` is the sqrtf of)
@@ -1009,6 +1025,23 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
         bool hit_a = false, hit_b = false, dead = false;
         // phase 1: both ends together, until one of them has hit
         while (!dead && !hit_a && !hit_b) {
+            if (near) {
+                // both ends deep inside a hole?  then the next SB steps of both cannot hit anything: take them at once
+                float ta_x = fa_x, ta_y = fa_y, tb_x = fb_x, tb_y = fb_y;
+#pragma unroll
+                for (int k = 0; k < SB; k++) { ta_x -= ddx; ta_y -= ddy; tb_x += ddx; tb_y += ddy; }       // the same fp32 sums
+                const int eax = (int) roundf(ta_x), eay = (int) roundf(ta_y), ebx = (int) roundf(tb_x), eby = (int) roundf(tb_y);
+                const bool in_both = ((unsigned) eax < (unsigned) W) & ((unsigned) eay < (unsigned) H) & ((unsigned) ebx < (unsigned) W) & ((unsigned) eby < (unsigned) H);
+                if (in_both && far_from_valid(eax, eay) && far_from_valid(ebx, eby)) {
+                    fa_x = ta_x; fa_y = ta_y; fb_x = tb_x; fb_y = tb_y;
+                    ax = eax; ay = eay; bx = ebx; by = eby;
+                    if ((ax < bx0 && ddx >= 0.0f) || (ax > bx1 && ddx <= 0.0f) || (ay < by0 && ddy >= 0.0f) || (ay > by1 && ddy <= 0.0f)) { dead = true; break; }
+                    if ((bx < bx0 && ddx <= 0.0f) || (bx > bx1 && ddx >= 0.0f) || (by < by0 && ddy <= 0.0f) || (by > by1 && ddy >= 0.0f)) { dead = true; break; }
+                    const float sx_ = (float) (bx - ax), sy_ = (float) (by - ay);
+                    if (sx_ * sx_ + sy_ * sy_ >= best_s) { dead = true; break; }
+                    continue;
+                }
+            }
             // a batch of SB steps per end: positions first (they do not depend on the data), loads together
             int pax[SB], pay[SB], pbx[SB], pby[SB];
             uint32_t wa[SB], wb[SB];
@@ -1055,6 +1088,19 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
             const int ox = is_a ? bx : ax, oy = is_a ? by : ay;            // the end that has hit stays put
             bool hit = false;
             while (!dead && !hit) {
+                if (near) {
+                    float tx = fx, ty = fy;
+#pragma unroll
+                    for (int k = 0; k < SB; k++) { tx += sdx; ty += sdy; }
+                    const int ex_ = (int) roundf(tx), ey_ = (int) roundf(ty);
+                    if (((unsigned) ex_ < (unsigned) W) & ((unsigned) ey_ < (unsigned) H) && far_from_valid(ex_, ey_)) {
+                        fx = tx; fy = ty; cx = ex_; cy = ey_;
+                        if ((cx < bx0 && sdx <= 0.0f) || (cx > bx1 && sdx >= 0.0f) || (cy < by0 && sdy <= 0.0f) || (cy > by1 && sdy >= 0.0f)) { dead = true; break; }
+                        const float sx_ = (float) (cx - ox), sy_ = (float) (cy - oy);
+                        if (sx_ * sx_ + sy_ * sy_ >= best_s) { dead = true; break; }
+                        continue;
+                    }
+                }
                 int px_[SB], py_[SB];
                 uint32_t wv[SB];
                 bool in_[SB];
@@ -1102,7 +1148,8 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                                     FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
-                                                    const int4* __restrict__ bbox, int fill_mode)
+                                                    const int4* __restrict__ bbox, int fill_mode, const uint32_t* __restrict__ coarse,
+                                                    int tiles_x, int tiles_y)
 {
     // leave the scratch ready for the next frame: empty z-buffer, empty buckets
 #if !defined(KBE_PROBE_NO_RESET)
@@ -1141,12 +1188,47 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
     // dependent chains, which only pays when other frames' kernels fill the chip meanwhile), 1 = one lane per hole,
     // 2 = one half-wave per hole (a frame rendered on its own)
     if (fill_mode == 1 || (fill_mode == 0 && n >= KBE_FILL_SERIAL_MIN)) {       // uniform over the launch
+        // Coarse map for the walks (LDS): bit (cy, cx) = some 8 x 8 block within one block of (cx, cy) holds a valid
+        // pixel.  Eight steps of a ray stay within 7 pixels of where they end, i.e. inside the 3 x 3 blocks around the end
+        // position's block; if that neighbourhood has no valid pixel the eight steps cannot hit one and are taken at
+        // once (16 additions, the same fp32 sums, no rounding of the positions in between, no mask look-ups).
+        if ((int) (blockIdx.x * blockDim.x) >= n) return;       // no hole for this block in this schedule either
+        __shared__ uint32_t s_blk[COARSE_WORDS], s_near[COARSE_WORDS];
+        constexpr int CX = TW / 8, CY = TH / 8;                 // coarse blocks per tile
+        const int c_rows = tiles_y * CY, c_wpr = (tiles_x * CX + 31) >> 5;
+        const bool skip_ok = c_rows * c_wpr <= COARSE_WORDS;
+        if (skip_ok) {
+            for (int idx = threadIdx.x; idx < c_rows * c_wpr; idx += blockDim.x) {
+                const int r = idx / c_wpr, wi = idx - r * c_wpr;
+                const int ty = r / CY, sub = r - ty * CY;
+                uint32_t word = 0;
+                for (int t = 0; t < 32 / CX; t++) {
+                    const int tx = wi * (32 / CX) + t;
+                    if (tx < tiles_x) word |= ((coarse[ty * tiles_x + tx] >> (CX * sub)) & ((1u << CX) - 1u)) << (CX * t);
+                }
+                s_blk[idx] = word;
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < c_rows * c_wpr; idx += blockDim.x) {
+                const int r = idx / c_wpr, wi = idx - r * c_wpr;
+                uint32_t near = 0;
+                for (int dr = -1; dr <= 1; dr++) {
+                    const int rr = r + dr;
+                    if (rr < 0 || rr >= c_rows) continue;
+                    const uint32_t w0 = s_blk[rr * c_wpr + wi];
+                    const uint32_t wl = wi > 0 ? s_blk[rr * c_wpr + wi - 1] : 0u, wr = wi + 1 < c_wpr ? s_blk[rr * c_wpr + wi + 1] : 0u;
+                    near |= w0 | (w0 << 1) | (w0 >> 1) | (wl >> 31) | (wr << 31);
+                }
+                s_near[idx] = near;
+            }
+            __syncthreads();
+        }
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int h = gtid; h < n; h += gsz) {
             const int px = holes[h];
             const int y = px / W, x = px - y * W;
             if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1) continue;
-            fill_hole_serial(px, depth, mask, W, H, wpr, dirs, bx0, by0, bx1, by1, frame, render);
+            fill_hole_serial(px, depth, mask, W, H, wpr, dirs, bx0, by0, bx1, by1, frame, render, skip_ok ? s_near : nullptr, c_wpr);
         }
         return;
     }
@@ -1295,7 +1377,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
         if (N == 0) a.points = a.image = a.depth_in = (const float*) sc.zkeys;     // never dereferenced for a record, but never NULL
         a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
-        a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox;
+        a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox; a.coarse = sc.coarse;
         a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
         hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
         if ((rc = launched("kbe_render_frame/tiles"))) return rc;
@@ -1311,7 +1393,8 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
-                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0));
+                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
+                           sc.coarse, sc.tiles_x, sc.tiles_y);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
