@@ -719,6 +719,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
     }
     int vx0 = W, vy0 = H, vx1 = -1, vy1 = -1;
     uint32_t cbits = 0;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     static_assert((TW / 8) * (TH / 8) <= 32 && TH % 8 == 0, "the coarse block bits of a tile fit a word");
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) {
@@ -736,12 +737,14 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             static_assert(TW == 32, "a wave holds two tile rows");
             const uint32_t lo = (uint32_t) vm, hi = (uint32_t) (vm >> 32), any = lo | hi;
             if (any) {                                                  // wave-uniform
-                const int wrow = y0 + ((tid >> 6) << 1) + m * (TILE_THREADS / TW);
+                const int wrow = y0 + (wave_s << 1) + m * (TILE_THREADS / TW);       // scalar: bounding box and block bits stay on the scalar unit
                 vx0 = min(vx0, x0 + __builtin_ctz(any)); vx1 = max(vx1, x0 + 31 - __builtin_clz(any));
                 vy0 = min(vy0, lo ? wrow : wrow + 1); vy1 = max(vy1, hi ? wrow + 1 : wrow);
                 // which 8 x 8 blocks of the tile hold a valid pixel (the hole fill skips through blocks that do not)
+#if !defined(KBE_PROBE_NO_COARSE)
                 const uint32_t cols = (any & 0xFFu ? 1u : 0u) | (any & 0xFF00u ? 2u : 0u) | (any & 0xFF0000u ? 4u : 0u) | (any & 0xFF000000u ? 8u : 0u);
                 cbits |= cols << ((TW / 8) * ((wrow - y0) >> 3));
+#endif
             }
         }
         if (in) {
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         // global atomics here -- even one cache line per tile row, even with a look first -- serialised so
         // badly across XCDs that they added 80-350 us per frame
         int* sb = L.head;
-        if (lane == 0) { sb[4 * (tid >> 6) + 0] = vx0; sb[4 * (tid >> 6) + 1] = vy0; sb[4 * (tid >> 6) + 2] = vx1; sb[4 * (tid >> 6) + 3] = vy1; sb[64 + (tid >> 6)] = (int) cbits; }
+        if (lane == 0) { sb[4 * wave_s + 0] = vx0; sb[4 * wave_s + 1] = vy0; sb[4 * wave_s + 2] = vx1; sb[4 * wave_s + 3] = vy1; sb[64 + wave_s] = (int) cbits; }
     }
     KBE_TICK(8);
     __syncthreads();
