@@ -707,3 +707,24 @@ def test_sharded_video_on_the_hip_path_two_ranks():
                           '--master-port', '29533', os.path.join(root, 'tools', 'sharded_check.py')],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_partial_conv_inpainting_pipeline_on_gpu(K):
+    """BASELINE.json configs[3] in miniature: the partial-convolution Inpaint (fused HIP mask-update epilogue) driving
+    the set-up of a KBE video, and a dolly video (no inpainting, common.py:217), both through Pipeline."""
+    from ken_burns_effect_amd import kbe, synthetic
+    from ken_burns_effect_amd.pipeline import Pipeline
+    import warnings
+    image, _ = synthetic.make_rgbd(192, 256, 12)
+    zoom = kbe.windows_for(256, 192, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipe = Pipeline(model_paths=None, partial_inpainting=True, device='cuda:0', steps=4)
+        frames = pipe(image, zoom)
+        assert len(frames) == 4 and frames[0].shape == (192, 256, 3) and frames[0].dtype == np.uint8
+        assert pipe.objectCommon['tensorInpaPoints'].shape[2] > 192 * 256          # the partial-conv net appended points
+        dolly = Pipeline(model_paths=None, partial_inpainting=True, dolly=True, device='cuda:0', steps=4)
+        zoom_d = kbe.windows_for(256, 192, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), True)
+        frames_d = dolly(image, zoom_d)
+    assert len(frames_d) == 4 and dolly.objectCommon['tensorInpaPoints'].shape[2] == 192 * 256
+    assert np.stack(frames).std() > 1.0 and np.stack(frames_d).std() > 1.0
