@@ -993,6 +993,9 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 #ifndef KBE_FILL_SERIAL_BATCH
 #define KBE_FILL_SERIAL_BATCH 8
 #endif
+#ifndef KBE_FILL_BY_COUNT_MIN_LANES
+#define KBE_FILL_BY_COUNT_MIN_LANES 2
+#endif
 constexpr int COARSE_WORDS = 2048;     // 8 x 8 blocks of images up to 2048 x 2048 (larger: the walks do not skip)
 #ifndef KBE_FILL_SERIAL_MIN
 #define KBE_FILL_SERIAL_MIN 49152       // holes per frame from which one lane per hole beats one half-wave per hole
@@ -1494,7 +1497,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         uint8_t* raw = stage + (size_t) l * fb;
         int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL | (lanes > 1 ? KBE_STAGE_FILL_BY_COUNT : 0),
+                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL | (lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0),
                                          crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
         return rc;
