@@ -375,21 +375,29 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 struct PixAcc { f2 rg, bd; float w; };
 
 struct TileLds {
-    float4 rec[REC_CAP];        // ox, oy, dblError, next record (int bits)
-    float4 rgbd[REC_CAP];       // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
-    int head[BH * BW];          // first record of each bin, -1 = empty
+    float4 rec[REC_CAP + 1];    // ox, oy, dblError, link to the next record of the bin; slot REC_DUMMY: see gather
+    float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
+    int head[BH * BW];          // link to the first record of each bin.  A link is the record's BYTE offset, -1 = none
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo
     float zee[TH * TW];         // degridded z-buffer
     int nrec;
     int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code)
 };
 
+constexpr int REC_DUMMY = REC_CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, no successor
+
+__device__ __forceinline__ void lds_dummy_record(TileLds& L)
+{
+    L.rec[REC_DUMMY] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(-1));
+    L.rgbd[REC_DUMMY] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
 __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float oy, float err, const float4& rgbd, int x0, int y0)
 {
     const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
     L.rgbd[idx] = rgbd;
-    const int next = atomicExch(&L.head[by * BW + bx], idx);
+    const int next = atomicExch(&L.head[by * BW + bx], idx << 4);
     L.rec[idx] = make_float4(ox, oy, err, __int_as_float(next));
 }
 
@@ -414,8 +422,10 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 // The launch is bound by instruction issue and LDS latency (PMC: the SIMDs issue ~85 % of the time, a wave
 // waits ~46 % of its life), so the walk is branch-free and as parallel as the data allows: the heads of the four
 // bins that can reach a pixel are read together, then one record of EACH bin together, and a record that
-// fails the z test (or a bin that has run out: index -1 reads record 0 as a dummy) contributes with weight 0
-// -- adding c * 0 leaves the accumulator bits unchanged, so the sums are those of the branching loop.  The
+// fails the z test contributes with weight 0 -- adding c * 0 leaves the accumulator bits unchanged, so the sums
+// are those of the branching loop.  A bin that has run out (link -1) reads the dummy record, which fails the z
+// test by itself and links to nothing: no "is this a record" test per (pixel, record), and a link is the byte
+// offset the LDS read takes (one unsigned min per read, no shift).  The
 // trip count is the longest of the four lists, not their sum.  FAST: every z of the tile is in the band where
 // `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
 template <bool FAST, class Args>
@@ -435,8 +445,8 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
         // corner k of a point is this pixel  <=>  its north-west corner is (X - (k & 1), Y - (k >> 1)).  That pins
         // floor(ox), floor(oy), so the bilinear weight of common.py:481-484 needs two subtractions and one
         // product: (ex - ox | ox - fx) * (ey - oy | oy - fy) with fx = (float) nwx, ex = (float) (nwx + 1).
-        auto add = [&](int k, bool on, const float4& r, const float4& c) {
-            const bool pass = on && (exact ? (r.z <= zlimf) : ((double) r.z <= zlim));    // :639
+        auto add = [&](int k, const float4& r, const float4& c) {
+            const bool pass = exact ? (r.z <= zlimf) : ((double) r.z <= zlim);             // :639
             const float wx = (k & 1) ? (r.x - (Xf - 1.0f)) : ((Xf + 1.0f) - r.x);          // k & 1 ? ox - fx : ex - ox
             const float wy = (k >> 1) ? (r.y - (Yf - 1.0f)) : ((Yf + 1.0f) - r.y);
             const float w = pass ? wx * wy : 0.0f;
@@ -452,14 +462,14 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
             float4 r[4], c[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int j = max(nx[k], 0);
-                r[k] = L.rec[j];
-                c[k] = L.rgbd[j];
+                const uint32_t j = min((uint32_t) nx[k], (uint32_t) (REC_DUMMY * 16));
+                r[k] = *(const float4*) ((const char*) L.rec + j);
+                c[k] = *(const float4*) ((const char*) L.rgbd + j);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                add(k, nx[k] >= 0, r[k], c[k]);
-                nx[k] = nx[k] >= 0 ? __float_as_int(r[k].w) : -1;
+                add(k, r[k], c[k]);
+                nx[k] = __float_as_int(r[k].w);
             }
         } while ((nx[0] & nx[1] & nx[2] & nx[3]) >= 0);                     // some list goes on
     }
@@ -523,9 +533,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
     for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
     if (tid == 0) {
         L.nrec = 0;
-        // record 0 doubles as the dummy an exhausted list reads in the gather: finite even if the tile stays empty
-        L.rec[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-        L.rgbd[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        lds_dummy_record(L);
     }
     // colours of the records (slots past the count: point 0, discarded later; the host never passes a NULL cloud)
     const int n0 = bucketed ? min(REC_CAP, count) : 0;
@@ -627,7 +635,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                     if (i < n) {
                         const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
                         L.rgbd[i] = cc[u];
-                        nxt[u] = atomicExch(&L.head[by * BW + bx], i);
+                        nxt[u] = atomicExch(&L.head[by * BW + bx], i << 4);
                     }
                 }
 #pragma unroll
@@ -878,10 +886,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         const unsigned long long odd = __ballot(!band);
         if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
     }
-    if (tid == 0) {
-        L.rec[0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));      // the gather's dummy record: finite even in an empty tile
-        L.rgbd[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    if (tid == 0) lds_dummy_record(L);
     __syncthreads();
     bool fast = true;
 #pragma unroll
