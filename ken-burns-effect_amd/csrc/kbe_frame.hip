@@ -377,18 +377,19 @@ struct PixAcc { f2 rg, bd; float w; };
 struct TileLds {
     float4 rec[REC_CAP + 1];    // ox, oy, dblError, link to the next record of the bin; slot REC_DUMMY: see gather
     float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
-    int head[BH * BW];          // link to the first record of each bin.  A link is the record's BYTE offset, -1 = none
+    int head[BH * BW];          // link to the first record of each bin.  A link is the record's BYTE offset, REC_NULL = none
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo
     float zee[TH * TW];         // degridded z-buffer
     int nrec;
     int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code)
 };
 
-constexpr int REC_DUMMY = REC_CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, no successor
+constexpr int REC_DUMMY = REC_CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, its own successor
+constexpr int REC_NULL = REC_DUMMY * 16;    // "no record" as a link: the dummy's byte offset, so that every link can be read as it is
 
 __device__ __forceinline__ void lds_dummy_record(TileLds& L)
 {
-    L.rec[REC_DUMMY] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(-1));
+    L.rec[REC_DUMMY] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(REC_NULL));
     L.rgbd[REC_DUMMY] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -423,9 +424,9 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 // waits ~46 % of its life), so the walk is branch-free and as parallel as the data allows: the heads of the four
 // bins that can reach a pixel are read together, then one record of EACH bin together, and a record that
 // fails the z test contributes with weight 0 -- adding c * 0 leaves the accumulator bits unchanged, so the sums
-// are those of the branching loop.  A bin that has run out (link -1) reads the dummy record, which fails the z
-// test by itself and links to nothing: no "is this a record" test per (pixel, record), and a link is the byte
-// offset the LDS read takes (one unsigned min per read, no shift).  The
+// are those of the branching loop.  A bin that has run out reads the dummy record, which fails the z test by
+// itself and links to itself: no "is this a record" test per (pixel, record), and a link is the byte offset
+// the LDS read takes as it is.  The
 // trip count is the longest of the four lists, not their sum.  FAST: every z of the tile is in the band where
 // `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
 template <bool FAST, class Args>
@@ -462,16 +463,15 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
             float4 r[4], c[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t j = min((uint32_t) nx[k], (uint32_t) (REC_DUMMY * 16));
-                r[k] = *(const float4*) ((const char*) L.rec + j);
-                c[k] = *(const float4*) ((const char*) L.rgbd + j);
+                r[k] = *(const float4*) ((const char*) L.rec + nx[k]);
+                c[k] = *(const float4*) ((const char*) L.rgbd + nx[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 add(k, r[k], c[k]);
                 nx[k] = __float_as_int(r[k].w);
             }
-        } while ((nx[0] & nx[1] & nx[2] & nx[3]) >= 0);                     // some list goes on
+        } while (min(min(nx[0], nx[1]), min(nx[2], nx[3])) < REC_NULL);      // some list goes on
     }
 }
 
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         // W * H < 2^31 / 4: a 32-bit byte offset on the uniform base
         zk[u] = *(const uint32_t*) ((const char*) a.zkeys + (((uint32_t) y * (uint32_t) W + (uint32_t) x) << 2));
     }
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
     if (tid == 0) {
         L.nrec = 0;
         lds_dummy_record(L);
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             const int n = min(REC_CAP, count - r0);
             if (r0 > 0) {
                 __syncthreads();                                // the previous round's gather is done with the lists
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const int i = tid + u * TILE_THREADS;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const int i = tid + u * TILE_THREADS;
-                    nxt[u] = -1;
+                    nxt[u] = REC_NULL;
                     if (i < n) {
                         const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
                         L.rgbd[i] = cc[u];
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
                 gather<false>(a, L, tid, x0, y0, acc);
                 __syncthreads();
-                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
                 if (tid == 0) L.nrec = 0;
                 __syncthreads();
             }
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                     cc[u] = fetch_chunk(a, i < n ? __float_as_int(rr[u].w) : 0, c0);
                 }
                 __syncthreads();                                        // zee written / the previous gather is done with the lists
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = -1;
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
                 __syncthreads();
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's records from the
             // whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
             __syncthreads();
-            for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+            for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
             if (tid == 0) L.nrec = 0;
             __syncthreads();
             const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
@@ -964,7 +964,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                 if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
                     gather<false>(a, L, tid, x0, y0, acc);
                     __syncthreads();
-                    for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = -1;
+                    for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
                     if (tid == 0) L.nrec = 0;
                     __syncthreads();
                 }
