@@ -398,7 +398,7 @@ __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float 
 {
     const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
     L.rgbd[idx] = rgbd;
-    const int next = atomicExch(&L.head[by * BW + bx], idx << 4);
+    const int next = atomicExch(&L.head[__mul24(by, BW) + bx], idx << 4);
     L.rec[idx] = make_float4(ox, oy, err, __int_as_float(next));
 }
 
@@ -528,7 +528,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         zin[u] = inside(xr, yr, W, H);
         const int x = min(max(xr, 0), W - 1), y = min(max(yr, 0), H - 1);       // clamped: always a valid address
         // W * H < 2^31 / 4: a 32-bit byte offset on the uniform base
-        zk[u] = *(const uint32_t*) ((const char*) a.zkeys + (((uint32_t) y * (uint32_t) W + (uint32_t) x) << 2));
+        // (24-bit multiply: full rate, the 32-bit one is quarter rate; y, W < 2^24)
+        zk[u] = *(const uint32_t*) ((const char*) a.zkeys + ((__umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x) << 2));
     }
     for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
     if (tid == 0) {
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                     if (i < n) {
                         const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
                         L.rgbd[i] = cc[u];
-                        nxt[u] = atomicExch(&L.head[by * BW + bx], i << 4);
+                        nxt[u] = atomicExch(&L.head[__mul24(by, BW) + bx], i << 4);
                     }
                 }
 #pragma unroll
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         s_u8[q * 3] = to_u8(res[m][0]); s_u8[q * 3 + 1] = to_u8(res[m][1]); s_u8[q * 3 + 2] = to_u8(res[m][2]);
         {   // validity bits: each 32-lane half of the wave holds 32 consecutive pixels of one row
             const unsigned long long vm = __ballot(valid[m]);
-            if ((lane & 31) == 0 && in) a.mask[(size_t) y * ((W + 31) >> 5) + (x >> 5)] = (uint32_t) (vm >> (lane & 32));
+            if ((lane & 31) == 0 && in) a.mask[__umul24((uint32_t) y, (uint32_t) ((W + 31) >> 5)) + (uint32_t) (x >> 5)] = (uint32_t) (vm >> (lane & 32));
             // bounding box of the valid pixels (depth > 0), which lets the hole fill discard rays that can never hit
             // one: straight from the ballot, on the scalar unit (as a 6-step butterfly of 4 values it was 24
             // cross-lane operations per thread).  TW == 32: the low half of the wave is row `wrow`, the high half the next.
@@ -756,10 +757,11 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             }
         }
         if (in) {
-            const size_t o = (size_t) y * W + x;
+            // W * H <= 2^30: a 32-bit element index (24-bit multiply) and scalar plane bases instead of 64-bit vector arithmetic
+            const uint32_t o = __umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x;
             a.depth[o] = dms[m];
 #if !defined(KBE_PROBE_TIMING)
-            if (a.render) { a.render[o] = res[m][0]; a.render[HW + o] = res[m][1]; a.render[2 * HW + o] = res[m][2]; a.render[3 * HW + o] = res[m][3]; }
+            if (a.render) { a.render[o] = res[m][0]; (a.render + HW)[o] = res[m][1]; (a.render + 2 * HW)[o] = res[m][2]; (a.render + 3 * HW)[o] = res[m][3]; }
 #endif
             if (a.existing) a.existing[o] = acc[m].w;
         }
@@ -792,8 +794,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
         for (int i = tid; i < TH * DW_PER_ROW; i += TILE_THREADS) {
             const int ly = i / DW_PER_ROW, k = i - ly * DW_PER_ROW;
             if (y0 + ly >= H) continue;
-            uint32_t* dst = (uint32_t*) (a.frame + ((size_t) (y0 + ly) * W + x0) * 3);
-            dst[k] = ((const uint32_t*) s_u8)[ly * DW_PER_ROW + k];
+            // byte offset < 3 * 2^30: 32 bits
+            *(uint32_t*) (a.frame + ((__umul24((uint32_t) (y0 + ly), (uint32_t) W) + (uint32_t) x0) * 3u + 4u * (uint32_t) k)) = ((const uint32_t*) s_u8)[ly * DW_PER_ROW + k];
         }
     } else {
         for (int i = tid; i < TH * TW * 3; i += TILE_THREADS) {
@@ -815,7 +817,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             const int slot = base + __popcll(hm[m] & ((1ull << lane) - 1ull));
             // (the list holds W*H entries, enough for any one frame; the bound only matters when this launch is
             // repeated without the projection launch that zeroes the count, as bench.py does to time it alone)
-            if (hole[m] && slot < W * H) a.holes[slot] = (y0 + ly) * W + x0 + lx;
+            if (hole[m] && slot < W * H) a.holes[(uint32_t) slot] = (int) __umul24((uint32_t) (y0 + ly), (uint32_t) W) + x0 + lx;
             base += __popcll(hm[m]);
         }
     }
