@@ -38,6 +38,8 @@ struct Camera {
     double fb;          // dblFocal * dblBaseline       common.py:470
     double half_w;      // 0.5 * W                      common.py:467
     double half_h;      // 0.5 * H                      common.py:468
+    float cx_f, cy_f;   // (float) (0.5 * W - 0.5), (float) (0.5 * H - 0.5): the same position in one fp32 addition
+    int fp32_centre;    // W, H >= 2: that addition is bit-identical to the fp64 form (tests/centre_offset_check.c)
     int W, H;
     int has_shift;      // apply process_shift (common.py:104-109) on the fly
     float sx, sy, sz;
@@ -73,13 +75,21 @@ struct Proj {
 // common.py:453-468.  Returns false when the point touches no pixel at all.
 __device__ __forceinline__ bool project_xy(const Camera& cam, float px, float py, float pz, float& ox, float& oy)
 {
-    if (!((double) pz >= 0.001)) return false;                 // :453 (also covers :461)
+    // :453 (also covers :461).  `(double) pz >= 0.001` in fp32: 0.001f is the smallest float that is >= the double 0.001
+    if (!(pz >= 0.001f)) return false;
     const float lvx = 0.0f - px, lvy = 0.0f - py, lvz = 0.0f - pz;
     const float dist = (cam.focal_f - pz) / lvz;               // :457-459
     const float ix = __builtin_fmaf(dist, lvx, px);            // :465 as NVRTC (--fmad=true) emits it
     const float iy = __builtin_fmaf(dist, lvy, py);
-    ox = (float) (((double) ix + cam.half_w) - 0.5);           // :467
-    oy = (float) (((double) iy + cam.half_h) - 0.5);           // :468
+    if (cam.fp32_centre) {                                     // wave-uniform; the normal case
+        // both fp64 operations of :467-468 are exact whenever ix matters to the result, so the two roundings
+        // collapse into the one of an fp32 addition (swept over every fp32 ix: tests/centre_offset_check.c)
+        ox = ix + cam.cx_f;
+        oy = iy + cam.cy_f;
+    } else {
+        ox = (float) (((double) ix + cam.half_w) - 0.5);       // :467
+        oy = (float) (((double) iy + cam.half_h) - 0.5);       // :468
+    }
     return (fabsf(ox) < 1.0e9f) && (fabsf(oy) < 1.0e9f);       // see kbe.h "Inputs must be finite"
 }
 

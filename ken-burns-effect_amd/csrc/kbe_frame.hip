@@ -119,6 +119,10 @@ size_t scratch_bytes(int W, int H)
            align16(4 * (size_t) H * ((W + 31) / 32)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
+#if defined(KBE_PROBE_NOP_CROP)
+__global__ void k_probe_nop() { }
+#endif
+
 __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
 {
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,6 +145,7 @@ struct ProjectArgs {
     int tiles_x, tiles_y;
     int* hole_count;
     int dense;              // more than two points per target pixel: pre-reduce the z-splat within the wave
+    int buckets_32bit;      // every bucket ends below byte 2^32 of `buckets`
 };
 
 // Groups the lanes of a wave by target tile: for a lane that `want`s, `same` is the mask of the
@@ -214,8 +219,10 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
     for (unsigned unit = (unsigned) wave; unit < n_units; unit += (unsigned) n_waves) {
         unsigned i;
         if (unit < n_patches) {
+            // the patch's first point on the scalar unit; a lane adds its row (0 or raster_w) and column
             const unsigned pyb = unit / patches_x, pxb = unit - pyb * patches_x;
-            i = (pyb * PATCH_ROWS + (unsigned) (lane >> 5)) * (unsigned) a.raster_w + pxb * 32u + (unsigned) (lane & 31);
+            static_assert(PATCH_ROWS == 2, "a lane's patch row is lane >> 5");
+            i = (pyb * PATCH_ROWS * (unsigned) a.raster_w + pxb * 32u) + ((lane >> 5) ? (unsigned) a.raster_w : 0u) + (unsigned) (lane & 31);
         } else {
             i = lin0 + (unit - n_patches) * UNIT + (unsigned) lane;
         }
@@ -250,14 +257,14 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
 #if defined(KBE_PROBE_NO_BUCKETS)
             want[e] = false;
 #endif
-            tgt[e] = ty0 * a.tiles_x + tx;
+            tgt[e] = __mul24(ty0, a.tiles_x) + tx;                      // 24-bit multiply: full rate (the 32-bit one is quarter rate)
             base[e] = 0;
         }
         grp[0] = group_by_tile(want[0], tgt[0]);
         grp[1] = east_groups(grp[0], want[0], want[1], tgt[1]);
 #pragma unroll
         for (int e = 0; e < 2; e++)
-            if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
+            if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[(uint32_t) tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
 
         // ... and while they are in flight: weights, dblError, winner corner, z-splat
         float err = 0.0f;
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
             const int k = winner_corner(p);                             // common.py:486-506
             if (k >= 0) {
                 const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-                if (inside(cx, cy, cam.W, cam.H)) zidx = cy * cam.W + cx;
+                if (inside(cx, cy, cam.W, cam.H)) zidx = __mul24(cy, cam.W) + cx;
             }
         }
 #if !defined(KBE_PROBE_NO_ZSPLAT)
@@ -293,18 +300,25 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
                     if ((lane ^ mask) < lane) issue = false;
                 }
             }
-            if (issue) atomicMin(&a.zkeys[zidx], key);
+            if (issue) atomicMin(&a.zkeys[(uint32_t) zidx], key);
         } else if (zidx >= 0) {
-            atomicMin(&a.zkeys[zidx], zkey_encode(err));
+            atomicMin(&a.zkeys[(uint32_t) zidx], zkey_encode(err));
         }
 #endif
         const float4 rec = make_float4(ox, oy, err, __int_as_float((int) i));
+        // all buckets within 4 GB (frames up to 4096 x 4096): a 32-bit byte offset from a 24-bit multiply on the
+        // uniform base; otherwise 64-bit arithmetic (a quarter-rate multiply-add)
+        auto store_record = [&](int tile, int slot) {
+            static_assert(BUCKET_STRIDE * 16 < (1 << 24), "the bucket stride in bytes is a 24-bit factor");
+            if (a.buckets_32bit) *(float4*) ((char*) a.buckets + (__umul24((uint32_t) tile, (uint32_t) BUCKET_STRIDE * 16u) + ((uint32_t) slot << 4))) = rec;
+            else a.buckets[(size_t) tile * BUCKET_STRIDE + slot] = rec;
+        };
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const int b0 = __shfl(base[e], grp[e].leader);
             if (want[e]) {
                 const int slot = b0 + __popcll(grp[e].same & ((1ull << lane) - 1ull));
-                if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[e] * BUCKET_STRIDE + slot] = rec;    // beyond: the tile sees count > cap
+                if (slot < BUCKET_CAP) store_record(tgt[e], slot);      // beyond: the tile sees count > cap
             }
         }
         // round 1 (rare): south and south-east neighbours
@@ -314,20 +328,20 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
             for (int e = 0; e < 2; e++) {
                 const int tx = tx0 + e, ty = ty0 + 1;
                 want[e] = spy && (e == 0 || spx) && ((unsigned) tx < (unsigned) a.tiles_x) & ((unsigned) ty < (unsigned) a.tiles_y);
-                tgt[e] = ty * a.tiles_x + tx;
+                tgt[e] = __mul24(ty, a.tiles_x) + tx;
                 base[e] = 0;
             }
             grp[0] = group_by_tile(want[0], tgt[0]);
             grp[1] = east_groups(grp[0], want[0], want[1], tgt[1]);
 #pragma unroll
             for (int e = 0; e < 2; e++)
-                if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
+                if (want[e] && lane == grp[e].leader) base[e] = atomicAdd(&a.tile_count[(uint32_t) tgt[e] * CNT_STRIDE], __popcll(grp[e].same));
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const int b0 = __shfl(base[e], grp[e].leader);
                 if (want[e]) {
                     const int slot = b0 + __popcll(grp[e].same & ((1ull << lane) - 1ull));
-                    if (slot < BUCKET_CAP) a.buckets[(size_t) tgt[e] * BUCKET_STRIDE + slot] = rec;
+                    if (slot < BUCKET_CAP) store_record(tgt[e], slot);
                 }
             }
         }
@@ -1376,6 +1390,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
         p.raster_w = 0; p.raster_n = 0;
         p.dense = (size_t) N > 2 * (size_t) W * H;
+        p.buckets_32bit = (size_t) n_tiles * BUCKET_STRIDE * sizeof(float4) <= ((size_t) 1 << 32);
         if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
 #ifndef KBE_PROJECT_MAX_BLOCKS
 #define KBE_PROJECT_MAX_BLOCKS 1000000
@@ -1448,6 +1463,9 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
     return launched("kbe_render_pointcloud_tiled/reset");
 }
 
+#ifndef KBE_VIDEO_STAGES            // probe builds time a subset of the frame's launches in the multi-lane loop (tools/gpu_cases.sh)
+#define KBE_VIDEO_STAGES (KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL)
+#endif
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
@@ -1504,9 +1522,13 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         uint8_t* raw = stage + (size_t) l * fb;
         int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL | (lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0),
+                                         KBE_VIDEO_STAGES | (lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0),
                                          crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
+#if defined(KBE_PROBE_NOP_CROP)
+        hipLaunchKernelGGL(k_probe_nop, dim3(KBE_PROBE_NOP_CROP), dim3(64), 0, ls[l]);     // what does a launch cost by itself?
+#elif !defined(KBE_PROBE_NO_CROP)
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
+#endif
         return rc;
     };
     int rc = KBE_OK;

@@ -30,6 +30,9 @@ inline Camera make_camera(int W, int H, double focal, double baseline, const flo
     c.fb_f = (float) c.fb;
     c.half_w = 0.5 * (double) W;
     c.half_h = 0.5 * (double) H;
+    c.cx_f = (float) (c.half_w - 0.5);
+    c.cy_f = (float) (c.half_h - 0.5);
+    c.fp32_centre = W >= 2 && H >= 2 && (double) c.cx_f == c.half_w - 0.5 && (double) c.cy_f == c.half_h - 0.5;
     c.W = W;
     c.H = H;
     c.has_shift = shift3 != nullptr;

@@ -462,6 +462,28 @@ def test_empty_and_single_point_clouds(K):
     assert float(e.sum()) == pytest.approx(1.0, abs=1e-6)
 
 
+@pytest.mark.parametrize('W,H', [(1, 1), (1, 9), (7, 1), (2, 2)])
+def test_one_pixel_wide_rasters_take_the_fp64_image_position(K, oracle, W, H):
+    """W or H == 1 is the one case where the fp32 form of common.py:467-468 is NOT the fp64 one (kbe_device.h
+    project_xy falls back); z-buffer and winners bit-exact through both splat paths."""
+    rng = np.random.default_rng(W * 16 + H)
+    N = 200
+    z = rng.uniform(30.0, 2000.0, (1, N)).astype(np.float32)
+    # image-plane offsets down to 1e-12: tiny positions are where the two forms differ
+    u = (rng.uniform(-1.5, 1.5, (1, N)) * 10.0 ** rng.uniform(-12, 0, (1, N))).astype(np.float32) * W
+    v = (rng.uniform(-1.5, 1.5, (1, N)) * 10.0 ** rng.uniform(-12, 0, (1, N))).astype(np.float32) * H
+    pts = torch.from_numpy(np.stack([u * z / 512.0, v * z / 512.0, z], 1).astype(np.float32))
+    zk, win = K.zsplat(pts.cuda(), W, H, 512.0, 120, want_winner=True)
+    zo, wo = oracle.zsplat(pts, W, H, 512.0, 120, want_winner=True)
+    assert_bits_equal(c(K.zkeys_decode(zk)), zo.numpy(), 'z-buffer %dx%d' % (W, H))
+    assert np.array_equal(c(win), wo.numpy())
+    data = torch.from_numpy(rng.standard_normal((1, 3, N)).astype(np.float32))
+    r_t, e_t = K.render_pointcloud(pts.cuda(), data.cuda(), W, H, 512.0, 120, tiled=True)
+    r_o, e_o = oracle.render_pointcloud(pts, data, W, H, 512.0, 120, 'jacobi')
+    assert np.array_equal(c(e_t) > 0, e_o.numpy() > 0)
+    assert (np.abs(c(r_t) - r_o.numpy()) <= 1e-4 * np.maximum(np.abs(r_o.numpy()), 1.0)).all()
+
+
 def test_invalid_arguments_return_errors_not_crashes(K):
     import ctypes
     assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, ctypes.c_void_p(8), None, None) == -1

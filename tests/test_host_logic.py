@@ -187,3 +187,17 @@ def test_shared_reciprocal_division_is_the_correctly_rounded_division(tmp_path):
     out = subprocess.run([exe, '60000000'], capture_output=True, text=True)
     n, bad = (int(v) for v in out.stdout.split()[-2:])
     assert out.returncode == 0 and bad == 0 and n == 60000000
+
+
+def test_fp32_image_position_and_cull_equal_the_fp64_forms(tmp_path):
+    """kbe_device.h project_xy: `(float) (((double) ix + W/2) - 0.5)` as ONE fp32 addition and `(double) z >= 0.001`
+    as an fp32 comparison.  The C program compares bit patterns; here every 1021st fp32 value for 17 sizes (the
+    full sweep, stride 1: 7.7e10 comparisons, no mismatch, 2 min 15 s on one core)."""
+    import os
+    import subprocess
+    exe = str(tmp_path / 'centre_offset_check')
+    src = os.path.join(os.path.dirname(__file__), 'centre_offset_check.c')
+    subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', src, '-o', exe, '-lm'])
+    out = subprocess.run([exe, '1021'], capture_output=True, text=True)
+    n, bad = (int(v) for v in out.stdout.split()[-2:])
+    assert out.returncode == 0 and bad == 0 and n > 70_000_000
