@@ -205,9 +205,13 @@ __device__ __forceinline__ float degrid_pixel_fast(float c, const float (&a)[4],
 {
     int n = 0;
     float s = 0.0f;
+    // in the band both a + 1 and c - 1 are exact, so (c >= a + 1) & (c >= d + 1) is c - 1 >= max(a, d): one
+    // subtraction for the pixel, one max and one comparison per pair -- on the bit patterns, which order positive
+    // floats as integers (a float max would first canonicalise its operands)
+    const int cm1 = __float_as_int(c - 1.0f);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const bool t = (c >= a[k] + 1.0f) & (c >= d[k] + 1.0f);
+        const bool t = cm1 >= max(__float_as_int(a[k]), __float_as_int(d[k]));
         n += t ? 1 : 0;
         s += t ? a[k] : 0.0f;                                   // s + 0.0f == s: same sum, same order as :559-560
         s += t ? d[k] : 0.0f;
