@@ -498,7 +498,12 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
 #ifndef KBE_TILE_WAVES
 #define KBE_TILE_WAVES 4
 #endif
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES))) k_tiles(TileArgs a)
+#if defined(KBE_TILE_NUM_VGPR)      // probe: a register cap (gfx90a+ counts the unified file, so the value is HALF the cap)
+#define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES), amdgpu_num_vgpr(KBE_TILE_NUM_VGPR)
+#else
+#define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES)
+#endif
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileArgs a)
 {
     __shared__ TileLds L;
 #if defined(KBE_PROBE_TIMING)
