@@ -200,7 +200,7 @@ __device__ __forceinline__ float degrid_pixel(int x, int y, int W, int H, At at)
 // and can then never pass `c >= 1e6 + 1`, which is how the reference's bounds test (:548-553) drops its pair,
 // and the mean needs no division: with y = RN(1 / (2n)), q = s y, q' = fma(fma(-2n, q, s), y, q) IS the
 // correctly rounded s / (2n) (Markstein; checked for every float s in [1, 1.7e7] and n = 1..4 by
-// tests/markstein_check.c).  Branch-free; bit-identical to degrid_pixel.
+// tests/markstein_check.c).  Bit-identical to degrid_pixel.
 __device__ __forceinline__ float degrid_pixel_fast(float c, const float (&a)[4], const float (&d)[4])
 {
     int n = 0;
@@ -209,9 +209,15 @@ __device__ __forceinline__ float degrid_pixel_fast(float c, const float (&a)[4],
     // subtraction for the pixel, one max and one comparison per pair -- on the bit patterns, which order positive
     // floats as integers (a float max would first canonicalise its operands)
     const int cm1 = __float_as_int(c - 1.0f);
+    int m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = max(__float_as_int(a[k]), __float_as_int(d[k]));
+    // most waves hold no pixel that any pair pulls down (a smooth surface without 1-pixel gaps): one test for the
+    // whole wave, then the pixel keeps its value (wave-uniform branch)
+    if (__ballot(cm1 >= min(min(m[0], m[1]), min(m[2], m[3]))) == 0ull) return c;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const bool t = cm1 >= max(__float_as_int(a[k]), __float_as_int(d[k]));
+        const bool t = cm1 >= m[k];
         n += t ? 1 : 0;
         s += t ? a[k] : 0.0f;                                   // s + 0.0f == s: same sum, same order as :559-560
         s += t ? d[k] : 0.0f;
