@@ -159,7 +159,9 @@ class HipKernels:
         B, C, N = data.shape
         dev = points.device
         if tiled is None:
-            tiled = os.environ.get('KBE_RENDER_TILED', '1') != '0'
+            # the tile renderer's size limits (include/kbe.h); beyond them the stage-by-stage HIP kernels take over
+            tiled = (os.environ.get('KBE_RENDER_TILED', '1') != '0' and N <= (1 << 30) and int(W) * int(H) <= (1 << 30)
+                     and int(W) < (1 << 24) and int(H) < (1 << 24))
         if tiled:
             W, H = int(W), int(H)
             key = (dev, W, H)

@@ -1380,7 +1380,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
                             int raster_w, int raster_n, kbe_stream_t stream)
 {
     KBE_REQUIRE(scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
-                ((uintptr_t) scratch & 15) == 0, "kbe_render_frame: bad arguments");
+                W < (1 << 24) && H < (1 << 24) && ((uintptr_t) scratch & 15) == 0, "kbe_render_frame: bad arguments");
     KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame: cloud pointers are NULL");
     static const FillDirs dirs = make_fill_dirs();
     const hipStream_t s = (hipStream_t) stream;
@@ -1446,8 +1446,8 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
                                 double baseline, const float* shift3, void* scratch, float* render, float* existing,
                                 kbe_stream_t stream)
 {
-    KBE_REQUIRE(scratch && render && existing && N >= 0 && C > 0 && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
-                ((uintptr_t) scratch & 15) == 0, "kbe_render_pointcloud_tiled: bad arguments");
+    KBE_REQUIRE(scratch && render && existing && N >= 0 && N <= (1 << 30) && C > 0 && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
+                W < (1 << 24) && H < (1 << 24) && ((uintptr_t) scratch & 15) == 0, "kbe_render_pointcloud_tiled: bad arguments");
     KBE_REQUIRE(N == 0 || (points && data), "kbe_render_pointcloud_tiled: cloud pointers are NULL");
     const hipStream_t s = (hipStream_t) stream;
     const Scratch sc = carve(scratch, W, H);

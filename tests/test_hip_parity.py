@@ -489,6 +489,11 @@ def test_invalid_arguments_return_errors_not_crashes(K):
     assert K.lib.kbe_zsplat(None, 1, 4, 8, 8, ctypes.c_double(512.0), ctypes.c_double(120.0), None, ctypes.c_void_p(8), None, None) == -1
     assert b'kbe_zsplat' in K.lib.kbe_last_error()
     assert K.lib.kbe_spatial_filter(ctypes.c_void_p(8), 1, 4, 4, 7, ctypes.c_void_p(8), None) == -1
+    # the frame loop's size limits (include/kbe.h): rasters with a side of 2^24 or more are refused, not mis-indexed
+    z16 = ctypes.c_void_p(16)
+    rc = K.lib.kbe_render_frame_stages(z16, z16, z16, 1, 1 << 24, 1, ctypes.c_double(512.0), ctypes.c_double(120.0), None, z16, z16,
+                                       None, None, None, None, 7, None, 0, 0, None)
+    assert rc == -1 and b'kbe_render_frame' in K.lib.kbe_last_error()
 
 
 @pytest.mark.gpu
