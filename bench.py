@@ -139,7 +139,8 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
 
 
 def cpu_baseline(oc, cams, crop, budget_s=20.0):
-    """The CPU oracle (oracle/kbe_oracle.c, single thread) rendering the same frames on this host."""
+    """The CPU oracle (oracle/kbe_oracle.c) rendering the same frames on this host: single thread, then one frame per
+    host thread (`all_cores`)."""
     from oracle import kbe_oracle
     ok = kbe_oracle.OracleKernels(schedule='jacobi')
     W, H = oc['intWidth'], oc['intHeight']
