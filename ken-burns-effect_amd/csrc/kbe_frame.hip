@@ -74,7 +74,6 @@ constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between t
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
 static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS && TW % 32 == 0, "tile geometry");
-static_assert(REC_CAP * 16 >= TW * TH * 3, "the uint8 staging area re-uses the record data array");
 
 struct Scratch {                            // carve-out of the caller's scratch allocation
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
@@ -390,9 +389,9 @@ struct PixAcc { f2 rg, bd; float w; };
 
 struct TileLds {
     float4 rec[REC_CAP + 1];    // ox, oy, dblError, link to the next record of the bin; slot REC_DUMMY: see gather
-    float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time; later the uint8 staging area
+    float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time
     int head[BH * BW];          // link to the first record of each bin.  A link is the record's BYTE offset, REC_NULL = none
-    float zpre[KH * KW];        // z-buffer before degrid, tile + halo
+    float zpre[KH * KW];        // z-buffer before degrid, tile + halo; after the degrid: uint8 staging area + per-wave partials
     float zee[TH * TW];         // degridded z-buffer
     int nrec;
     int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code)
@@ -674,7 +673,8 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 #endif
             KBE_TICK(6);
         }
-        __syncthreads();
+        // no barrier here: what follows stages its bytes and per-wave partial results in the z-buffer area, dead since
+        // the barrier in front of the gather, so a wave that is done resolves its pixels while others still walk
         KBE_TICK(7);
     } else {
         // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
@@ -716,7 +716,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 
     // resolve: normalise (common.py:686), hole mask (:253), uint8 (:255)
     const size_t HW = (size_t) W * H;
-    uint8_t* s_u8 = (uint8_t*) L.rgbd;            // the records are dead now
+    static_assert(sizeof(L.zpre) >= TW * TH * 3 + (64 + TILE_THREADS / 64) * sizeof(int), "uint8 staging + per-wave partials fit the z-buffer area");
+    uint8_t* s_u8 = (uint8_t*) L.zpre;            // the pre-degrid z-buffer is dead since the barrier in front of the gather
+    int* const s_part = (int*) L.zpre + TW * TH * 3 / 4;
     float res[PIX_PER_THREAD][4], dms[PIX_PER_THREAD];
     bool hole[PIX_PER_THREAD], valid[PIX_PER_THREAD];
     unsigned long long hm[PIX_PER_THREAD];
@@ -786,16 +788,16 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         }
     }
     {
-        // per-wave boxes meet in LDS (the bin heads are dead by now), one plain 16-byte store per tile;
+        // per-wave boxes meet in LDS, one plain 16-byte store per tile;
         // global atomics here -- even one cache line per tile row, even with a look first -- serialised so
         // badly across XCDs that they added 80-350 us per frame
-        int* sb = L.head;
+        int* sb = s_part;
         if (lane == 0) { sb[4 * wave_s + 0] = vx0; sb[4 * wave_s + 1] = vy0; sb[4 * wave_s + 2] = vx1; sb[4 * wave_s + 3] = vy1; sb[64 + wave_s] = (int) cbits; }
     }
     KBE_TICK(8);
     __syncthreads();
     if (tid == 0) {
-        const int* sb = L.head;
+        const int* sb = s_part;
         int4 bb = make_int4(W, H, -1, -1);
         for (int w = 0; w < TILE_THREADS / 64; w++) {
             bb.x = min(bb.x, sb[4 * w]); bb.y = min(bb.y, sb[4 * w + 1]); bb.z = max(bb.z, sb[4 * w + 2]); bb.w = max(bb.w, sb[4 * w + 3]);
