@@ -7,15 +7,20 @@
 A "step" is one output frame of the reference's process_kenburns loop body
 (/root/reference/utils/common.py:222-260): camera shift -> forward-warp of the resident point
 cloud (z-splat, degrid, z-tested bilinear accumulate) -> disocclusion fill -> uint8 ->
-centred crop + resize -> the finished frame landing in (pinned) host memory.  The point cloud
-is resident in HBM when the timed region starts; frames are sharded over ranks (rank r renders
-steps r, r+N, ... of an N*K-step path; the one RCCL broadcast of the cloud is inside the timed
-region).  Synthetic seeded RGBD input (no datasets / checkpoints are reachable offline).
+centred crop + resize -> the finished frame landing in pinned host memory (the `.cpu()` of
+common.py:255; SURVEY.md 8d counts it in the step).  The point cloud is resident in HBM when the
+timed region starts; frames are sharded over ranks (rank r renders steps r, r+N, ... of an N*K-step
+path).  Synthetic seeded RGBD input (no datasets / checkpoints are reachable offline).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel:
-algorithmic bytes / HIP-event time, measured live) and `cpu_baseline` (the CPU oracle timed
-on this host, rank 0 at N=1 only -- the oracle is used here as the baseline, never as the
-product path).
+Timing: W untimed warm-up frames, then passes of EXACTLY K frames, each bracketed by barrier +
+synchronize on both sides (max over ranks), repeated until >= 0.5 s of timed wall; `value` is K * N /
+the MEDIAN pass.  `device_only` is the same loop with the frames left in HBM (no PCIe), reported beside
+it.  The cloud broadcast (multi-GPU) is scene set-up, timed separately as `cloud_broadcast_ms`.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the scatter =
+render_pointcloud: SURVEY.md 8d's 28 N + 20 HW bytes over the HIP-event time of its launches, measured
+live) and `cpu_baseline` (the CPU oracle timed on this host, rank 0 at N=1 only -- the oracle is
+used here as the baseline, never as the product path).
 """
 import argparse
 import json
@@ -72,19 +77,19 @@ def build_scene(size, device, inpaint, settings=None, upsample=1):
 
 
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel (k_tiles) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    """Per-launch HBM bytes of the frame kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, calibrated and corrected by tools/pmc_report.py as MI355X_MICROARCH.md
-    prescribes).  PMC counters cannot be collected from inside this process, so the figure is read from
-    profiles/; None when the file is missing."""
+    prescribes).  PMC counters cannot be collected from inside this process, so the figures are read from the newest
+    profiles/r*_hbm_traffic.json; ({}, None) when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
     if not files:
-        return None, None
+        return {}, None
     try:
         k = json.load(open(files[-1]))['kernels']
-        return k['k_tiles']['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+        return {name: v['hbm_bytes'] for name, v in k.items()}, os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None, None
+        return {}, None
 
 
 def time_kernels(oc, cams, reps=40, fill_rect=None):
@@ -160,7 +165,7 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
                      % (n, W, H, os.cpu_count())}
     # frames are independent, so the same port also runs one frame per host thread (the C calls release the GIL);
     # reported beside the single-thread figure, bounded the same way
-    threads = max(1, min(os.cpu_count() or 1, int(os.environ.get('KBE_CPU_BASELINE_THREADS', '64'))))
+    threads = max(1, int(os.environ.get('KBE_CPU_BASELINE_THREADS', os.cpu_count() or 1)))      # all host cores
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         deadline = time.perf_counter() + 0.5 * budget_s
@@ -179,7 +184,8 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
             done = sum(pool.map(work, range(threads)))
         dt = time.perf_counter() - t0
         out['all_cores'] = {'value': done / dt, 'unit': 'frames/s', 'cores': threads,
-                            'sample': '%d frames in %.1f s, %d threads each rendering whole frames' % (done, dt, threads)}
+                            'sample': '%d frames in %.1f s, %d threads (os.cpu_count() = %d) each rendering whole frames'
+                                      % (done, dt, threads, os.cpu_count() or 0)}
     return out
 
 
@@ -192,10 +198,12 @@ def main():
     ap.add_argument('--dolly', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-crop', action='store_true')
-    ap.add_argument('--host-delivery', action='store_true',
-                    help='also time the same K frames copied to pinned host memory (PCIe-inclusive; reported beside value)')
-    ap.add_argument('--no-overlap', action='store_true', help='copies on the compute stream (dev comparison)')
-    ap.add_argument('--batch', type=int, default=None, help='frames per device->host transfer (default: steps / 4 within 8..64)')
+    ap.add_argument('--device-only', action='store_true',
+                    help='leave the finished frames in HBM: `value` is then NOT the SURVEY 8d step (dev comparison; config.delivery says so)')
+    ap.add_argument('--no-overlap', action='store_true', help='with --batch: transfers on the compute stream (dev comparison)')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='hand-off (include/kbe.h): default groups of 8 frames per hipMemcpyAsync, the lanes taking turns; 0: per-frame copy kernel; '
+                         '> 0: staged ring, one hipMemcpyAsync per BATCH frames on a copy stream')
     ap.add_argument('--upsample', type=int, default=1, help='cloud of (upsample * size)^2 points (BASELINE configs[4]: 2; implies --cloud raw)')
     ap.add_argument('--cloud', choices=['inpaint', 'raw'], default='inpaint',
                     help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
@@ -238,10 +246,22 @@ def main():
     _, my_steps = sharding.shard_steps(settings['dblSteps'], rank, world_size)
     cams = common.frame_cameras(dict(settings, dblSteps=my_steps), oc)
 
-    # warm-up (untimed); the landing buffers of the timed runs are allocated here, not in the loop
-    dev_out = torch.zeros(args.steps, size, size, 3, dtype=torch.uint8, device=device)    # zeros: every page touched before the timed region
+    # landing buffers of the timed runs are allocated (and every page touched) here, not in the loop
+    delivery = 'hbm' if args.device_only else 'pinned_host'
+    host_out = None if args.device_only else torch.zeros(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
+    dev_out = torch.zeros(args.steps, size, size, 3, dtype=torch.uint8, device=device)
+
+    def run_host():
+        return common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=args.batch)
+
+    def run_device():
+        return common.render_frames(cams, oc, crop, keep_on_device=True, host_out=dev_out)
+
+    # warm-up (untimed): W frames on both routes (clocks, staging buffers, streams, first-touch of the pinned pages)
     nw = max(args.warmup, 1)
     common.render_frames(cams[:nw], oc, crop, keep_on_device=True, host_out=dev_out[:nw])
+    if host_out is not None:
+        common.render_frames(cams[:nw], oc, crop, host_out=host_out[:nw], overlap=not args.no_overlap, batch=args.batch)
 
     def sync():
         torch.cuda.synchronize()
@@ -260,79 +280,84 @@ def main():
         sync()
         broadcast_ms = (time.perf_counter() - t0) * 1e3
 
-    def timed(run):
+    def timed_pass(run):
+        """EXACTLY K frames between barrier + synchronize on both sides; max over ranks."""
         sync()
         t0 = time.perf_counter()
-        out = run()
+        run()
         sync()
         dt = time.perf_counter() - t0
         if world_size > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return out, dt
+        return dt
 
-    # THE timed region: K frames, cloud resident in HBM, finished uint8 frames left in HBM
-    frames, elapsed = timed(lambda: common.render_frames(cams, oc, crop, keep_on_device=True, host_out=dev_out))
-    # --host-delivery: the same K frames delivered to pinned host memory as process_kenburns returns them
-    # (PCIe-inclusive; reported beside `value`, never as `value`): one transfer per `batch` frames on a second
-    # stream.  Off by default so that the rocprofv3 --stats averages of the default command are those of
-    # undisturbed kernels (the transfers run as blit kernels that stretch whatever overlaps them).
-    elapsed_h = None
-    if args.host_delivery:
-        host_out = torch.empty(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
-        batch = args.batch if args.batch is not None else max(8, min(64, args.steps // 4))    # render_video's own default for K frames
-        # untimed full pass: allocates the staging ring and touches every page of the pinned landing buffer (the first
-        # transfer into a page is several times slower than the steady state)
-        common.render_frames(cams, oc, crop, host_out=host_out, batch=batch)
-        frames_h, elapsed_h = timed(lambda: common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=batch))
-        assert frames_h.shape == (args.steps, size, size, 3)
+    def timed(run, min_wall=0.5, min_passes=3, max_passes=200):
+        """Passes of K frames until >= min_wall seconds of timed wall (a single short pass mostly measures the ramp of
+        the lanes' queues); every rank takes the same number of passes (the max-reduced times are identical on all)."""
+        times = []
+        while len(times) < min_passes or (sum(times) < min_wall and len(times) < max_passes):
+            times.append(timed_pass(run))
+        return times
+
+    # THE timed region: passes of K frames, cloud resident in HBM, finished uint8 frames delivered to pinned host memory
+    # (--device-only: left in HBM); the HBM-resident rate is measured the same way and reported beside it
+    times = timed(run_device if args.device_only else run_host)
+    elapsed = float(np.median(times))
+    times_dev = times if args.device_only else timed(run_device)
+    elapsed_dev = float(np.median(times_dev))
 
     if rank == 0:
         from ken_burns_effect_amd import _native
         lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
+        host_lanes = min(lanes, max(1, int(os.environ.get('KBE_HOST_LANES', _native.DEFAULT_HOST_LANES))))
         kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]))
         HW = size * size
-        # Dominant kernel: k_tiles = degrid + z-tested accumulate + normalise (+ uint8) of one frame, i.e. the
-        # reference's updateDegrid + updateOutput + the normalisation of render_pointcloud.  Its algorithmic
-        # bytes per launch (two-pass variant: compulsory traffic of that part, each input once,
-        # each output once, no scratch): xyz + rgb + depth of every point 28 N, z-buffer in 4 HW, normalised
-        # 4-channel render + weight out 20 HW.  Its time is isolated by differencing two GPU-bound launch
-        # sequences and agrees with rocprofv3's per-kernel duration (profiles/).
-        tiles_bytes = 28 * n_points + 24 * HW
-        dom = 'tiles'
-        achieved = tiles_bytes / kt['tiles'] / 1e9
-        # The whole scatter = render_pointcloud = z-buffer/accumulator clear + z-splat + degrid + accumulate +
-        # normalise = launches k_project + k_tiles + the scratch reset riding in k_fill_holes; SURVEY.md 8d's
-        # single-pass figure 28 N + 20 HW over the time of that GPU-bound three-launch sequence.
+        # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
+        # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch)
+        # over the HIP-event time of the launches that implement it, back to back alone on a stream:
+        # k_project + k_tiles + the z-buffer / bucket reset that rides in k_fill_holes (empty fill rectangle).
         scatter_bytes = 28 * n_points + 20 * HW
-        scatter = {'achieved': scatter_bytes / kt['project+tiles+reset'] / 1e9, 'unit': 'GB/s', 'algorithmic_bytes': scatter_bytes,
-                   'us': round(kt['project+tiles+reset'] * 1e6, 2), 'launches': 'k_project + k_tiles + scratch reset (in k_fill_holes)'}
-        scatter['frac'] = scatter['achieved'] / HBM_PEAK_GBS
+        t_scatter = kt['project+tiles+reset']
+        achieved = scatter_bytes / t_scatter / 1e9
+        launches = ['k_project', 'k_tiles', 'k_fill_holes']
         # the committed PMC passes are of the default workload only
-        traffic, traffic_src = measured_traffic() if (size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1) else (None, None)
+        per_kernel, traffic_src = measured_traffic() if (size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1) else ({}, None)
+        traffic = sum(per_kernel[k] for k in launches) if all(k in per_kernel for k in launches) else None
+        # its dominant launch alone (k_tiles: degrid + accumulate + normalise; its share of the two-pass figure is the
+        # whole 28 N + 20 HW: it re-reads xyz as the bucket records)
+        dominant = {'kernel': 'k_tiles', 'us': round(kt['tiles'] * 1e6, 2), 'achieved': scatter_bytes / kt['tiles'] / 1e9,
+                    'frac': scatter_bytes / kt['tiles'] / 1e9 / HBM_PEAK_GBS, 'traffic': per_kernel.get('k_tiles')}
+        cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
             'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%dx%d %s camera path, %d points (%s cloud), per frame: shift+zsplat+degrid+accumulate+fill+u8%s, frames left in HBM'
-                                   % (size, size, 'dolly' if args.dolly else 'KBE', n_points, ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2, '' if crop is None else '+crop/resize'),
-                       'frames_per_rank': args.steps, 'lanes': lanes, 'sharding': 'frames round-robin over ranks, 1 cloud broadcast (untimed set-up, see cloud_broadcast_ms)'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'algorithmic_bytes': tiles_bytes, 'scatter': scatter,
-                         'note': 'kernel timed alone on one stream (HIP events); the matching rocprofv3 --stats summary is the one taken with '
-                                 'KBE_LANES=1 (profiles/): in the timed region the kernels of %d frames overlap on %d streams and per-kernel '
-                                 'durations stretch' % (lanes, lanes),
+            'config': {'workload': '%dx%d %s path, %d pts (%s cloud), frame=shift+scatter+fill+u8%s' % (
+                           size, size, 'dolly' if args.dolly else 'KBE', n_points, cloud, '' if crop is None else '+crop/resize'),
+                       'delivery': delivery, 'frames_per_rank': args.steps, 'lanes': lanes if args.device_only else host_lanes,
+                       'device_only_lanes': lanes, 'passes': len(times),
+                       'pass_ms': {'median': round(elapsed * 1e3, 3), 'min': round(min(times) * 1e3, 3), 'max': round(max(times) * 1e3, 3)},
+                       'sharding': 'frames round-robin over ranks; one cloud broadcast (set-up, cloud_broadcast_ms)'},
+            'device_only': {'value': args.steps * world_size / elapsed_dev, 'unit': 'frames/s', 'ms_per_step': elapsed_dev / args.steps * 1e3,
+                            'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
+            'roofline': {'bound': 'hbm', 'kernel': ' + '.join(launches) + ' (the scatter = render_pointcloud; fill only resets the z-buffer here)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': scatter_bytes,
+                         'formula': '28 N + 20 HW (SURVEY.md 8d)', 'us': round(t_scatter * 1e6, 2), 'dominant': dominant,
+                         'note': 'launch sequence timed alone on one stream (HIP events, 40 repetitions); the matching rocprofv3 --stats summary '
+                                 'is the one taken with KBE_LANES=1 (profiles/): in the timed region the kernels of %d frames overlap on %d '
+                                 'streams and per-kernel durations stretch' % (lanes, lanes),
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
+        if not args.device_only:
+            line['pcie'] = {'achieved': args.steps * size * size * 3 / elapsed / 1e9, 'unit': 'GB/s per GPU', 'peak': 63.0,
+                            'note': 'uint8 frames of %.2f MB over PCIe Gen5 x16 (63 GB/s spec, ~57 measured with hipMemcpyAsync on an idle chip)'
+                                    % (size * size * 3 / 1e6)}
         if broadcast_ms is not None:
             line['cloud_broadcast_ms'] = broadcast_ms
-        if elapsed_h is not None:
-          line['host_delivery'] = {'value': args.steps * world_size / elapsed_h, 'unit': 'frames/s', 'ms_per_step': elapsed_h / args.steps * 1e3,
-                                 'note': 'same K frames copied to pinned host memory (PCIe D2H of %.1f MB per frame, %d frames per transfer, second stream)'
-                                         % (size * size * 3 / 1e6, args.batch if args.batch is not None else max(8, min(64, args.steps // 4)))}
         if world_size == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(oc, cams, crop)
         print(json.dumps(line), flush=True)

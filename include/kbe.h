@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 1
+#define KBE_ABI_VERSION 2
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -95,6 +95,14 @@ KBE_API int kbe_zkeys_decode(const uint32_t* zkeys, size_t n, float* zee, kbe_st
    degridded fp32 z-buffer.  `zee_in_f32`, if non-NULL, is used instead of the keys. */
 KBE_API int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out,
                kbe_stream_t stream);
+
+/* The same kernel under the SERIAL schedule (pixels one after the other in index order, in place: what the
+   reference kernel text does when executed by a host shim, and what tests/golden's `*_serial` vectors hold).  The
+   reference's in-place update (common.py:556-566) is a race on a GPU; kbe_degrid above is the normative,
+   deterministic out-of-place schedule.  This entry exists to tie the HIP path to reference-run vectors bit for bit
+   (tests); one workgroup per image, W + 2 H barrier steps: not a production path.  zee_out may alias zee_in_f32. */
+KBE_API int kbe_degrid_serial(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out,
+                              kbe_stream_t stream);
 
 /* kernel_pointrender_updateOutput (common.py:586-669): z-tested bilinear accumulation of
    C data channels plus the weight channel into acc [B,C+1,H,W] (zeroed by the caller,
@@ -192,23 +200,31 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
 /* The whole frame loop of process_kenburns (common.py:222-260) for `n_frames` cameras, enqueued
  * from native code (no per-frame host-language work): per frame kbe_render_frame_stages, then the
  * device-side crop + resize of common.py:256-257 when crop_w/crop_h > 0 (holes the crop discards are
- * not filled), then an asynchronous copy of the finished uint8 frame into host_out[i] (pinned host
- * memory, [n_frames,H,W,3]).  focals [n_frames] and shifts [n_frames][3] are HOST arrays (shift as
- * the fp32 values process_shift produces).  Frames are staged on the device in two halves of
- * `batch` frames and leave in one transfer per half.  If copy_stream differs from stream the
- * transfers run there and overlap the rendering of the other half (cross-stream waits are per
- * batch because they are expensive); synchronising `stream` afterwards guarantees every frame has
- * landed.  batch == 0: no staging, every frame's last kernel stores straight into host_out[i],
- * which may then be DEVICE memory (the frames stay in HBM) or device-visible pinned host memory.
+ * not filled), then the hand-off of the finished uint8 frame to host_out[i] ([n_frames,H,W,3]; the
+ * `.cpu()` of common.py:255).  focals [n_frames] and shifts [n_frames][3] are HOST arrays (shift as
+ * the fp32 values process_shift produces).
  * Frames are independent, so consecutive frames are enqueued on `lanes` (1..KBE_MAX_LANES) streams,
  * lane 0 on `stream`, lane l on lane_streams[l] (may be NULL when lanes == 1); each lane has its
- * own scratch and raw frame:
+ * own scratch, raw frame and finished frame.  Synchronising `stream` afterwards guarantees every
+ * frame has landed and every lane is idle.
+ * Hand-off to pinned (device-visible) host memory happens in the lanes' own streams (no copy stream, no event), the
+ * lanes taking turns on the PCIe link (a bounded, advisory device-side wait), by `batch`:
+ *   batch < 0: groups of G = -batch consecutive frames are rendered by one lane into its own G buffers and leave
+ *       with ONE hipMemcpyAsync per group (the runtime's transfer engine).  The default of the Python host side:
+ *       G = 8 on 2 lanes keeps the link busy back to back (59 us per 1024^2 frame, 53 GB/s of PCIe Gen5 x16).
+ *   batch == 0: per frame, by a small copy kernel (k_deliver: 16 workgroups, 16-byte stores, throttled).
+ *   batch <= 0 with host_out = DEVICE memory: every frame's last kernel stores straight into host_out[i]
+ *       (the frames stay in HBM).
+ *   batch > 0: round 1's scheme, kept for comparison and for host memory the device cannot address: frames are
+ *       staged on the device in two halves of `batch` frames and leave with one hipMemcpyAsync per half on
+ *       copy_stream (NULL: on `stream`), cross-stream events per half.
  *   scratch: lanes * kbe_video_scratch_stride(W, H) bytes, each lane's part initialised with
  *            kbe_frame_scratch_init;
- *   stage:   DEVICE buffer of (lanes + 2*batch) * H*W*3 bytes.
+ *   stage:   DEVICE buffer, 256-byte aligned, of kbe_video_stage_bytes(W, H, lanes, batch) bytes.
  * The call creates and destroys its HIP events. */
 #define KBE_MAX_LANES 8
 KBE_API size_t kbe_video_scratch_stride(int W, int H);
+KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,

@@ -19,14 +19,15 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 # every symbol include/kbe.h declares (tests check the library exports exactly these)
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
-    'kbe_degrid', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
+DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory (env KBE_HOST_LANES)
 _lib = None
 
 
@@ -50,6 +51,7 @@ def load():
     lib.kbe_last_error.restype = ctypes.c_char_p
     lib.kbe_frame_scratch_bytes.restype = ctypes.c_size_t
     lib.kbe_video_scratch_stride.restype = ctypes.c_size_t
+    lib.kbe_video_stage_bytes.restype = ctypes.c_size_t
     if lib.kbe_abi_version() != ABI_VERSION:
         raise KbeError('libkbe_hip.so ABI %d != expected %d' % (lib.kbe_abi_version(), ABI_VERSION))
     _lib = lib
@@ -65,6 +67,9 @@ def _ptr(t, dtype=torch.float32):
     if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise KbeError('kernel arguments must be contiguous %s tensors on the GPU (got %s %s on %s)'
                        % (dtype, 'contiguous' if t.is_contiguous() else 'strided', t.dtype, t.device))
+    if t.device.index != torch.cuda.current_device():
+        raise KbeError('tensor on %s but the current device is cuda:%d: wrap the call in torch.cuda.device(%d) '
+                       '(launches go to the current device\'s stream)' % (t.device, torch.cuda.current_device(), t.device.index))
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -84,6 +89,9 @@ def _shift(shift3):
 
 
 def _stream():
+    """The HIP stream launches go to: torch's current stream of the CURRENT device.  Every wrapper below checks that its
+    tensors live on that device (`_ptr`), so a caller working on cuda:1 without torch.cuda.set_device(1) gets a KbeError
+    instead of device-1 pointers launched on device 0's stream."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -131,6 +139,16 @@ class HipKernels:
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=src.device)
         self._check(self.lib.kbe_degrid(_ptr(zkeys, torch.int32), _ptr(None if zee is None else _f32c(zee)), _i(B), _i(W),
                                         _i(H), _ptr(out), _stream()), 'kbe_degrid')
+        return out
+
+    def degrid_serial(self, zkeys=None, zee=None):
+        """The serial (index-order, in-place) schedule of the same kernel: what the reference-run golden vectors hold.
+        Proof-of-fidelity entry for the tests; the product path uses :meth:`degrid`'s out-of-place schedule."""
+        src = zkeys if zkeys is not None else zee
+        B, _, H, W = src.shape
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=src.device)
+        self._check(self.lib.kbe_degrid_serial(_ptr(zkeys, torch.int32), _ptr(None if zee is None else _f32c(zee)), _i(B), _i(W),
+                                               _i(H), _ptr(out), _stream()), 'kbe_degrid_serial')
         return out
 
     def accumulate(self, points, data, zee, focal, baseline, shift3=None):
@@ -244,33 +262,38 @@ class HipKernels:
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
         also be a DEVICE tensor: the frames then stay in HBM (the last kernel of every frame stores straight into
-        it, no transfer)."""
+        it, no transfer).  ``batch`` selects the hand-off to host memory (None: groups of up to 8 frames per
+        transfer on KBE_HOST_LANES lanes; see include/kbe.h); ``overlap`` only matters for ``batch`` > 0."""
         n, W, H = len(cameras), state['W'], state['H']
         dev = state['points'].device
         if host_out is None:
             host_out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
         assert host_out.dtype == torch.uint8 and host_out.is_contiguous() and host_out.numel() >= n * H * W * 3
-        if batch is None:
-            # frames per device->host transfer: large transfers use the link best (14.1 k frames/s at 64 frames =
-            # 200 MB against 11.0 k at 16, 1024^2), but a video should still be cut into a few batches so that
-            # rendering and transfer overlap
-            batch = max(8, min(64, n // 4))
-        batch = max(0, int(batch))      # 0 = zero-copy (kernels store straight into the pinned host buffer)
+        lanes = state['lanes']
         if host_out.is_cuda:
             batch, overlap = 0, False
-        lanes = state['lanes']
-        if state.get('stage_batch', -1) < batch or 'stage' not in state:
-            state['stage'] = torch.empty((2 * batch + lanes) * H * W * 3, dtype=torch.uint8, device=dev)
-            state['stage_batch'] = batch
+        else:
+            if not host_out.is_pinned():
+                raise KbeError('render_video: host_out must be pinned host memory (or a device tensor)')
+            # The hand-off (include/kbe.h): < 0 = groups of -batch frames per lane, one hipMemcpyAsync each, the lanes
+            # taking turns on the link (default); 0 = per frame by a copy kernel; > 0 = round 1's staged ring.
+            # Two lanes ping-pong best (one renders its next group while the other's leaves: 59 us per 1024^2 frame;
+            # 3-4 lanes 60-61): the link, not the rendering, bounds this mode.
+            lanes = min(lanes, max(1, int(os.environ.get('KBE_HOST_LANES', DEFAULT_HOST_LANES))))
+            if batch is None:
+                batch = int(os.environ.get('KBE_DELIVERY_BATCH', '0')) or -max(1, min(8, n // (4 * lanes)))
+        batch = max(-64, int(batch))
+        need = int(self.lib.kbe_video_stage_bytes(_i(W), _i(H), _i(lanes), _i(batch)))
+        if 'stage' not in state or state['stage'].numel() < need:
+            state['stage'] = torch.empty(need, dtype=torch.uint8, device=dev)
         if 'copy_stream' not in state:
             state['copy_stream'] = torch.cuda.Stream(device=dev)
-            state['lane_streams'] = [None] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+            state['lane_streams'] = [None] + [torch.cuda.Stream(device=dev) for _ in range(state['lanes'] - 1)]
         lane_streams = (ctypes.c_void_p * MAX_LANES)(*[None if st is None else st.cuda_stream for st in state['lane_streams']])
         focals = (ctypes.c_double * max(n, 1))(*[float(c[0]) for c in cameras])
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
-        state['copy_stream'].wait_stream(torch.cuda.current_stream())
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),

@@ -195,6 +195,26 @@ __device__ __forceinline__ float degrid_pixel(int x, int y, int W, int H, At at)
     return count > 0 ? fminf(c, sum / (float) count) : c;
 }
 
+// The same, written exactly as the reference (fp64 comparisons throughout, no cross-lane test): for callers whose lanes
+// diverge (the serial-schedule kernel, where only the lanes on the current wavefront take part).
+template <class At>
+__device__ __forceinline__ float degrid_pixel_one(int x, int y, int W, int H, At at)
+{
+    const float c = at(x, y);
+    const int ox[4] = { 1, 0, 1, 1 };
+    const int oy[4] = { 0, 1, 1, -1 };
+    int count = 0;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
+        if (!(inside(x1, y1, W, H) && inside(x2, y2, W, H))) continue;                        // :548-553
+        const float a = at(x1, y1), d = at(x2, y2);
+        if (((double) c >= (double) a + 1.0) && ((double) c >= (double) d + 1.0)) { count += 2; sum += a; sum += d; }   // :556-561
+    }
+    return count > 0 ? fminf(c, sum / (float) count) : c;                                     // :564-566
+}
+
 // The same pixel when all nine values lie in [2^19, 1e6] (tested once per tile by the caller): the `+ 1.0`
 // comparisons are exact in fp32 (plus_one_is_exact), a neighbour outside the image reads as the empty value 1e6
 // and can then never pass `c >= 1e6 + 1`, which is how the reference's bounds test (:548-553) drops its pair,

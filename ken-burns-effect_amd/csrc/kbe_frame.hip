@@ -30,6 +30,7 @@
 // is the out-of-place schedule, accumulation order is bucket order (not point order).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -1353,6 +1354,86 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// frame hand-off (common.py:255 `.cpu()`): finished uint8 frames go from the lane's device buffers into pinned host
+// memory IN THE LANE'S OWN STREAM -- no copy stream, no event (cross-stream events cost ~25 us per frame on this
+// stack: a dedicated copy stream measured 89-107 us per frame) -- either by the runtime's transfer engine, one
+// hipMemcpyAsync per group of frames (default), or by k_deliver below, one frame at a time.
+// Left alone, the lanes' copies share the PCIe link, finish together, and the lanes then render together: a convoy
+// that leaves the link idle a quarter of the time (measured: 80 us per 1024^2 frame, 39 GB/s).  So the copies take
+// TURNS: copy i waits (one lane polling, s_sleep in between) until copy i - 1 has finished and then has the link
+// to itself; the lanes fall into a staggered pipeline -- with two lanes, one renders its next group while the other's
+// group leaves -- and the link is busy back to back (59 us per frame = 53 GB/s of the ~57 the link gives a single
+// large transfer; tools/d2h_probe*.hip, gpurun_out sweeps in DESIGN.md).  The turn is ADVISORY -- a performance
+// ordering only: the wait is bounded (~4 ms) and a copy that gives up simply copies, so no mapping of streams onto
+// hardware queues can deadlock it.
+// k_deliver: a copy kernel with plain 16-byte stores into device-visible host memory.  64 unthrottled workgroups
+// reach 55 GB/s alone, but PCIe-bound stores parked in the write queues stall every other kernel's stores; 16
+// workgroups with 2 KB in flight per wave are the best compromise found (66 us per frame next to 3 rendering lanes).
+// ---------------------------------------------------------------------------------------
+constexpr int DELIVER_BLOCKS = 16, DELIVER_THREADS = 256, DELIVER_KB_PER_WAVE = 2;
+constexpr int DELIVER_MAX_POLLS = 4096;     // x ~1 us
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct DeliverCtl { uint32_t serving; uint32_t pad[31]; uint32_t done[32]; };
+static_assert(sizeof(DeliverCtl) <= 256, "kbe_video_stage_bytes reserves 256 bytes");      // serving: copies finished so far; done: per-copy workgroup count
+
+// the turn of a runtime transfer: pass == 0 waits (bounded) until `ticket` is served, pass == 1 hands the turn on
+__global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, uint32_t ticket, int pass)
+{
+    if (threadIdx.x != 0) return;
+    if (pass) { atomicMax(&ctl->serving, ticket + 1); return; }
+    for (int polls = 0; polls < DELIVER_MAX_POLLS; polls++) {
+        if (__hip_atomic_load(&ctl->serving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ticket) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ void __launch_bounds__(DELIVER_THREADS) k_deliver(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes,
+                                                             DeliverCtl* ctl, uint32_t ticket)
+{
+    if (ctl) {
+        if (threadIdx.x == 0) {
+            for (int polls = 0; polls < DELIVER_MAX_POLLS; polls++) {
+                if (__hip_atomic_load(&ctl->serving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ticket) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
+    const size_t gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t) gridDim.x * blockDim.x;
+    if ((((uintptr_t) src | (uintptr_t) dst) & 15) == 0) {          // uniform; the normal case (W*H*3 a multiple of 16)
+        const size_t n16 = bytes >> 4;
+        const u32x4* s16 = (const u32x4*) src;
+        u32x4* d16 = (u32x4*) dst;
+        // at most DELIVER_KB_PER_WAVE KB of stores in flight per wave: the link is fed (its bandwidth-delay product is
+        // ~100 KB) without parking megabytes of PCIe-bound writes in the L2 / fabric write queues, where every
+        // other kernel's stores wait behind them (measured: k_tiles 19 -> 89 us next to an unthrottled 64-workgroup copy)
+        for (size_t i0 = gtid; i0 < n16; i0 += gsz * DELIVER_KB_PER_WAVE) {
+#pragma unroll
+            for (int k = 0; k < DELIVER_KB_PER_WAVE; k++) {
+                const size_t i = i0 + (size_t) k * gsz;
+                if (i < n16) d16[i] = __builtin_nontemporal_load(s16 + i);      // the frame is read once: no L2 allocation
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (size_t i = (n16 << 4) + gtid; i < bytes; i += gsz) dst[i] = src[i];
+    } else {
+        for (size_t i = gtid; i < bytes; i += gsz) dst[i] = src[i];
+    }
+    if (ctl) {
+        // the last workgroup to get here passes the turn on (its own stores need not have landed: the next copy only
+        // competes for the link, it does not read them)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* cnt = &ctl->done[ticket & 31];
+            if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicMax(&ctl->serving, ticket + 1);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1365,6 +1446,20 @@ size_t kbe_frame_scratch_bytes(int W, int H)
 size_t kbe_video_scratch_stride(int W, int H)
 {
     return (W <= 0 || H <= 0) ? 0 : ((scratch_bytes(W, H) + 255) & ~(size_t) 255);
+}
+
+// stage = [lanes raw frames][lanes * fin finished frames][ring half 0: batch frames][ring half 1: batch frames][turn counter]
+static inline size_t stage_fin_per_lane(int batch) { return batch < -2 ? (size_t) -batch : 2; }
+static inline size_t stage_ctl_offset(int W, int H, int lanes, int batch)
+{
+    const size_t fb = (size_t) W * H * 3;
+    return (((size_t) lanes * (1 + stage_fin_per_lane(batch)) + 2 * (size_t) (batch > 0 ? batch : 0)) * fb + 255) & ~(size_t) 255;
+}
+
+size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch)
+{
+    if (W <= 0 || H <= 0 || lanes < 1) return 0;
+    return stage_ctl_offset(W, H, lanes, batch) + 256;      // frames + the hand-off's turn counter
 }
 
 int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
@@ -1478,39 +1573,42 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
                      kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams)
 {
-    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= 0, "kbe_render_video: bad arguments");
+    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64, "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
     KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
-    const hipStream_t cs = (hipStream_t) stream, ds = (hipStream_t) (copy_stream ? copy_stream : stream);
-    const bool overlap = ds != cs;
+    const hipStream_t cs = (hipStream_t) stream;
     const size_t fb = (size_t) W * H * 3;
     const size_t sb = (scratch_bytes(W, H) + 255) & ~(size_t) 255;      // == kbe_frame_scratch_bytes rounded: lane stride
     const bool crop = crop_w > 0;
     // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
     // frame: the fixed cost of a kernel boundary on this chip (launch ramp, tail, and the L2 write-back between
-    // dependent kernels: ~4-5 us per launch, 4 launches per frame) is then paid while another frame's kernels run.
-    // stage = [lanes raw frames][ring half 0: batch frames][ring half 1: batch frames].  A half is copied to
-    // the host with ONE transfer while the other half is being rendered; cross-stream events are per batch, not
-    // per frame (a cross-stream wait costs far more host time than a launch on this stack).
-    hipStream_t ls[KBE_MAX_LANES];
+    // dependent kernels) is then paid while another frame's kernels run.
+    // stage = [lanes raw frames][2 * lanes finished frames][ring half 0: batch frames][ring half 1: batch frames].
+    hipStream_t ls[KBE_MAX_LANES], ds[1];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? cs : (hipStream_t) lane_streams[l];
-    uint8_t* ring[2] = { stage + (size_t) lanes * fb, stage + (size_t) lanes * fb + (size_t) batch * fb };
-    hipEvent_t start = nullptr, rendered[2][KBE_MAX_LANES] = {}, copied[2] = { nullptr, nullptr };
-    auto make = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    bool ok = true;
-    if (lanes > 1) ok = ok && make(&start);
-    for (int h = 0; h < 2; h++) {
-        if (overlap || lanes > 1) ok = ok && make(&copied[h]);
-        for (int l = 0; l < lanes; l++) if (overlap || l > 0) ok = ok && make(&rendered[h][l]);
-    }
-    auto destroy = [&]() {
-        if (start) (void) hipEventDestroy(start);
-        for (int h = 0; h < 2; h++) {
-            if (copied[h]) (void) hipEventDestroy(copied[h]);
-            for (int l = 0; l < KBE_MAX_LANES; l++) if (rendered[h][l]) (void) hipEventDestroy(rendered[h][l]);
+    ds[0] = copy_stream ? (hipStream_t) copy_stream : cs;        // only the staged ring (batch > 0) uses it
+    const int fin = (int) stage_fin_per_lane(batch);                    // finished-frame buffers per lane
+    const int slots = fin * lanes;
+    uint8_t* const finished = stage + (size_t) lanes * fb;
+    uint8_t* ring[2] = { finished + (size_t) slots * fb, finished + ((size_t) slots + (size_t) (batch > 0 ? batch : 0)) * fb };
+    // where do the frames go?  (a pointer the runtime does not know is taken for device memory, as before)
+    uint8_t* host_dev = nullptr;                // host_out as the device sees it, when it is pinned host memory
+    if (batch <= 0) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, host_out) == hipSuccess && attr.type == hipMemoryTypeHost) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, host_out, 0) != hipSuccess || !dp)
+                return fail(KBE_E_INVALID, "kbe_render_video: host_out is host memory the device cannot address (pin it with hipHostMalloc / hipHostRegister)");
+            host_dev = (uint8_t*) dp;
+        } else {
+            (void) hipGetLastError();           // unknown to the runtime: not an error here
         }
-    };
-    if (!ok) { destroy(); return fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate"); }
+    }
+    const bool per_frame = host_dev != nullptr;                         // per-frame hand-off to pinned host memory
+    // the hand-off's turn counter sits behind the frame buffers of `stage`, 256-byte aligned
+    const size_t ctl_offset = stage_ctl_offset(W, H, lanes, batch);
+    KBE_REQUIRE(((uintptr_t) stage & 255) == 0, "kbe_render_video: stage must be 256-byte aligned");
+    const bool ringed = batch > 0;
     int rect[4] = { 0, 0, W - 1, H - 1 };
     if (crop) {
         // the pixels cv2.getRectSubPix reads (common.py:256), padded by one: see kbe_render_frame_stages
@@ -1519,13 +1617,31 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         rect[2] = x0 + crop_w + 2 < W - 1 ? x0 + crop_w + 2 : W - 1;
         rect[3] = y0 + crop_h + 2 < H - 1 ? y0 + crop_h + 2 : H - 1;
     }
-    // the other lanes start once everything enqueued on `stream` so far (the cloud) is done
-    if (lanes > 1) {
+    // events (created and destroyed per call): `start`, per slot / ring half `rendered` and `copied`, per stream `idle`
+    constexpr int MAX_EV = 4 + 4 * KBE_MAX_LANES;
+    hipEvent_t pool[MAX_EV];
+    int n_ev = 0;
+    bool ok = true;
+    auto make = [&]() -> hipEvent_t {
+        hipEvent_t e = nullptr;
+        if (n_ev >= MAX_EV || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+        pool[n_ev++] = e;
+        return e;
+    };
+    auto destroy = [&]() { for (int k = 0; k < n_ev; k++) (void) hipEventDestroy(pool[k]); };
+    if (per_frame && lanes > 1) {
+        // the turn counter of the hand-off starts at 0 for every call (on `stream`, before the other lanes start)
+        const hipError_t e = hipMemsetAsync(stage + ctl_offset, 0, sizeof(DeliverCtl), cs);
+        if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
+    }
+    hipEvent_t start = lanes > 1 || (ringed && ds[0] != cs) ? make() : nullptr;
+    // the other streams start once everything enqueued on `stream` so far (the cloud) is done
+    if (start && ok) {
         (void) hipEventRecord(start, cs);
         for (int l = 1; l < lanes; l++) (void) hipStreamWaitEvent(ls[l], start, 0);
+        if (ringed && ds[0] != cs) (void) hipStreamWaitEvent(ds[0], start, 0);
     }
-    auto frame = [&](int i, uint8_t* out) {
-        const int l = i % lanes;
+    auto render = [&](int i, int l, uint8_t* out) {
         uint8_t* raw = stage + (size_t) l * fb;
         int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
@@ -1538,38 +1654,76 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #endif
         return rc;
     };
+    // whoever synchronises `stream` afterwards also sees every frame delivered and every other stream idle
+    auto join = [&]() {
+        for (int l = 1; l < lanes && ok; l++) { hipEvent_t e = make(); if (e) { (void) hipEventRecord(e, ls[l]); (void) hipStreamWaitEvent(cs, e, 0); } }
+        if (ringed && ds[0] != cs && ok) { hipEvent_t e = make(); if (e) { (void) hipEventRecord(e, ds[0]); (void) hipStreamWaitEvent(cs, e, 0); } }
+    };
     int rc = KBE_OK;
-    int n_batches = 0;
-    if (batch == 0) {
-        // no staging: the last kernel of every frame stores straight into host_out -- device memory (the frames stay
-        // in HBM) or device-visible pinned host memory (zero-copy); no transfer engine, no copy stream
-        for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = frame(i, host_out + (size_t) i * fb);
-        for (int l = 1; l < lanes; l++) {
-            (void) hipEventRecord(rendered[0][l], ls[l]);
-            (void) hipStreamWaitEvent(cs, rendered[0][l], 0);
+    if (!ringed && !per_frame) {
+        // host_out is device memory: the last kernel of every frame stores straight into it (the frames stay in HBM)
+        for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = render(i, i % lanes, host_out + (size_t) i * fb);
+    } else if (!ringed) {
+        // Hand-off to pinned host memory in the lane's own stream (no event), the lanes taking turns:
+        //   batch == 0   per frame, k_deliver (a lane alternates between two finished-frame slots);
+        //   batch < 0    per group of G = -batch consecutive frames, rendered by ONE lane into its G slots and sent with one
+        //                runtime transfer (hipMemcpyAsync) between a gate kernel that waits for the turn and one that
+        //                passes it on.
+        DeliverCtl* ctl = lanes > 1 ? (DeliverCtl*) (stage + ctl_offset) : nullptr;
+        if (batch == 0) {
+            for (int i = 0; i < n_frames && rc == KBE_OK; i++) {
+                const int l = i % lanes, slot = i % slots;
+                uint8_t* out = finished + (size_t) slot * fb;
+                rc = render(i, l, out);
+                if (rc != KBE_OK) break;
+                hipLaunchKernelGGL(k_deliver, dim3(DELIVER_BLOCKS), dim3(DELIVER_THREADS), 0, ls[l], out, host_dev + (size_t) i * fb, fb,
+                                   ctl, (uint32_t) i);
+                rc = launched("kbe_render_video/deliver");
+            }
+        } else {
+            const int G = -batch;
+            for (int i0 = 0, g = 0; i0 < n_frames && rc == KBE_OK; i0 += G, g++) {
+                const int l = g % lanes, nb = n_frames - i0 < G ? n_frames - i0 : G;
+                uint8_t* base = finished + (size_t) l * fin * fb;
+                for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
+                if (rc != KBE_OK) break;
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, (uint32_t) g, 0);
+                const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
+                if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, (uint32_t) g, 1);
+                rc = launched("kbe_render_video/turn");
+            }
         }
-        destroy();
-        return rc;
-    }
-    for (int i0 = 0; i0 < n_frames && rc == KBE_OK; i0 += batch, n_batches++) {
-        const int half = n_batches & 1;
-        const int nb = n_frames - i0 < batch ? n_frames - i0 : batch;
-        if (copied[half] && n_batches >= 2)
-            for (int l = 0; l < lanes; l++) if (ls[l] != ds) (void) hipStreamWaitEvent(ls[l], copied[half], 0);    // the half is free again
-        for (int k = 0; k < nb && rc == KBE_OK; k++) rc = frame(i0 + k, ring[half] + (size_t) k * fb);
-        if (rc != KBE_OK) break;
-        for (int l = 0; l < lanes; l++) {
-            if (ls[l] == ds) continue;                                  // same stream as the transfer: ordered anyway
-            (void) hipEventRecord(rendered[half][l], ls[l]);
-            (void) hipStreamWaitEvent(ds, rendered[half][l], 0);
+    } else {
+        // staged ring: a half is copied to the host with ONE runtime transfer while the other half is being rendered;
+        // cross-stream events are per batch, not per frame
+        const hipStream_t dc = ds[0];
+        hipEvent_t rendered[2][KBE_MAX_LANES] = {}, copied[2] = { nullptr, nullptr };
+        for (int h = 0; h < 2; h++) {
+            copied[h] = make();
+            for (int l = 0; l < lanes; l++) if (ls[l] != dc) rendered[h][l] = make();
         }
-        const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, ring[half], (size_t) nb * fb, hipMemcpyDeviceToHost, ds);
-        if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
-        if (copied[half]) (void) hipEventRecord(copied[half], ds);
+        int n_batches = 0;
+        for (int i0 = 0; i0 < n_frames && rc == KBE_OK && ok; i0 += batch, n_batches++) {
+            const int half = n_batches & 1;
+            const int nb = n_frames - i0 < batch ? n_frames - i0 : batch;
+            if (n_batches >= 2)
+                for (int l = 0; l < lanes; l++) if (ls[l] != dc) (void) hipStreamWaitEvent(ls[l], copied[half], 0);    // the half is free again
+            for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, (i0 + k) % lanes, ring[half] + (size_t) k * fb);
+            if (rc != KBE_OK) break;
+            for (int l = 0; l < lanes; l++) {
+                if (ls[l] == dc) continue;                                  // same stream as the transfer: ordered anyway
+                (void) hipEventRecord(rendered[half][l], ls[l]);
+                (void) hipStreamWaitEvent(dc, rendered[half][l], 0);
+            }
+            const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, ring[half], (size_t) nb * fb, hipMemcpyDeviceToHost, dc);
+            if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
+            (void) hipEventRecord(copied[half], dc);
+        }
     }
-    // whoever synchronises `stream` also sees every frame in host memory (and every lane idle)
-    if (overlap) for (int b = 0; b < 2 && b < n_batches; b++) (void) hipStreamWaitEvent(cs, copied[(n_batches - 1 - b) & 1], 0);
+    join();
     destroy();
+    if (rc == KBE_OK && !ok) rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate");
     return rc;
 }
 

@@ -157,6 +157,30 @@ __global__ void __launch_bounds__(kBlock) k_degrid(const uint32_t* __restrict__ 
     zout[base + i] = degrid_pixel(x, y, W, H, at);
 }
 
+// The reference kernel executed ONE PIXEL AFTER THE OTHER in index order (what the host shim that produced
+// tests/golden/*_serial vectors does; Gauss-Seidel): pixel (x, y) sees the new values of (x-1, y), (x-1, y-1),
+// (x, y-1), (x+1, y-1) and the old values of its other four neighbours (common.py:556-566 reads and writes the same
+// buffer).  Proof-of-fidelity entry, not a production path: one workgroup per image walks the skewed wavefront
+// t = x + 2 y -- every pixel of a front depends only on fronts t-1, t-2, t-3 and reads nothing a same-front or
+// earlier-front pixel still has to overwrite -- so the result IS the serial one, in W + 2 H barrier steps.
+__global__ void __launch_bounds__(1024) k_degrid_serial(int W, int H, float* __restrict__ z)
+{
+    float* Z = z + (size_t) blockIdx.x * H * W;
+    // agent-scope relaxed accesses: served by L2, never by a stale line of this CU's vector L1
+    auto at = [&](int xx, int yy) -> float { return __hip_atomic_load(&Z[(size_t) yy * W + xx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int t = 0; t <= (W - 1) + 2 * (H - 1); t++) {
+        for (int y = threadIdx.x; y < H; y += blockDim.x) {
+            const int x = t - 2 * y;
+            if (x >= 0 && x < W) {
+                const float v = degrid_pixel_one(x, y, W, H, at);
+                __hip_atomic_store(&Z[(size_t) y * W + x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel_pointrender_updateOutput (common.py:586-669), any channel count
 // ---------------------------------------------------------------------------------------
@@ -644,6 +668,24 @@ int kbe_degrid(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int
     else
         hipLaunchKernelGGL(k_degrid<true>, grid, dim3(kBlock), 0, (hipStream_t) stream, zkeys, zee_in_f32, W, H, zee_out);
     return launched("kbe_degrid");
+}
+
+int kbe_degrid_serial(const uint32_t* zkeys, const float* zee_in_f32, int B, int W, int H, float* zee_out, kbe_stream_t stream)
+{
+    KBE_REQUIRE((zkeys || zee_in_f32) && zee_out && B > 0 && W > 0 && H > 0, "kbe_degrid_serial: bad arguments");
+    const size_t n = (size_t) B * W * H;
+    const hipStream_t s = (hipStream_t) stream;
+    if (zee_in_f32) {
+        if (zee_in_f32 != zee_out) {
+            const hipError_t e = hipMemcpyAsync(zee_out, zee_in_f32, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_degrid_serial: hipMemcpyAsync", e);
+        }
+    } else {
+        int rc = kbe_zkeys_decode(zkeys, n, zee_out, stream);
+        if (rc != KBE_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_degrid_serial, dim3(B), dim3(H < 1024 ? ((H + 63) / 64) * 64 : 1024), 0, s, W, H, zee_out);
+    return launched("kbe_degrid_serial");
 }
 
 int kbe_accumulate(const float* points, const float* data, int B, int N, int C, const float* zee, int W, int H,

@@ -325,6 +325,27 @@ def test_native_frame_loop_equals_per_frame_calls(K):
         assert d.max() <= 1 and (d > 0).mean() < 1e-3
     c2 = common.render_frames(cams, oc, None)
     assert c2.shape == (7, 160, 224, 3)
+    # every hand-off to pinned host memory delivers the same bytes: groups of frames per runtime transfer with the lanes
+    # taking turns (default; here explicit group sizes incl. a ragged last group), the per-frame copy kernel, and
+    # round 1's staged ring
+    for batch in (-1, -2, -3, 0, 3):
+        other = common.render_frames(cams, oc, crop, batch=batch)
+        assert np.array_equal(other, a), 'hand-off batch=%d' % batch
+
+
+@pytest.mark.parametrize('size', [(50, 37), (33, 64)])
+def test_frame_hand_off_with_unaligned_frame_sizes(K, size):
+    """W*H*3 not a multiple of 16: the frames of a video start at unaligned host addresses (k_deliver's byte path)."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene(size, 5)
+    cams = common.frame_cameras(settings, oc)
+    host = common.render_frames(cams, oc, None)
+    dev = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+    assert host.shape == dev.shape == (len(cams), size[0], size[1], 3)
+    d = np.abs(host.astype(np.int32) - dev.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3           # two renders: the accumulation order may differ in the last bit
+    with pytest.raises(Exception):
+        common.render_frames(cams, oc, None, host_out=torch.empty(len(cams), size[0], size[1], 3, dtype=torch.uint8))   # not pinned
 
 
 def test_render_frame_is_repeatable_and_order_independent(K):

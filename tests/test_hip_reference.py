@@ -1,0 +1,352 @@
+"""GPU parity against REFERENCE-RUN vectors for the rows round 1 only covered on the CPU (a3, a4, a9,
+a11, a13, a14, a15; 8f: f2): the set-up half of process_kenburns, the networks on MIOpen, and the reference's own
+frames reproduced by the HIP kernels.
+
+Two kernel sets are used:
+  * the product set (`_native.kernels()`): tile renderer, out-of-place (Jacobi) degrid;
+  * `HipSerialKernels` (below, test infrastructure): the library's stage-by-stage HIP kernels with the degrid run under
+    the SERIAL schedule (`kbe_degrid_serial`).  The golden vectors were produced by the reference's kernel text
+    executed one element after the other (tests/golden/make_golden.py), so this is the schedule under which a HIP
+    run can be compared with a reference run bit for bit (z-buffers) and count for count (frames).
+
+Tolerances for MIOpen fp32 convolutions (different algorithms and summation orders than the CPU run that produced the
+fixtures) are written at each assertion; index / mask / byte work is exact.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+# MIOpen fp32 vs the fixture's CPU fp32 (measured on MI355X: image <= 4e-6, disparity <= 2e-5 of its range; the bars
+# leave a margin for other solver choices, and are ~1/50 of a uint8 count for colours)
+TOL_IMAGE = 1e-4
+TOL_DISPARITY_REL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def K():
+    from ken_burns_effect_amd import _native
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return _native.kernels()          # raises if libkbe_hip.so is missing: no fallback
+
+
+def g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def c(t):
+    return t.detach().cpu().numpy()
+
+
+class HipSerialKernels:
+    """Test seam: every op is the HIP library's; render_pointcloud / render_frame run stage by stage with the degrid
+    under the serial schedule (the product's tile renderer uses the out-of-place one)."""
+    name = 'hip-serial'
+
+    def __init__(self, K):
+        self.K, self.zee_log = K, []
+
+    def __getattr__(self, name):
+        if name == 'render_video':            # forces common.render_frames onto the per-frame loop below
+            raise AttributeError(name)
+        return getattr(self.K, name)
+
+    def render_pointcloud(self, points, data, W, H, focal, baseline):
+        zkeys, _ = self.K.zsplat(points, W, H, focal, baseline)
+        zee = self.K.degrid_serial(zkeys=zkeys)
+        self.zee_log.append(zee)
+        return self.K.normalize(self.K.accumulate(points, data, zee, focal, baseline))
+
+    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None):
+        return {'points': points.reshape(1, 3, -1), 'data': torch.cat([image.reshape(1, 3, -1), depth.reshape(1, 1, -1)], 1), 'W': W, 'H': H}
+
+    def render_frame(self, state, shift3, focal, baseline, fill_rect=None, **kw):
+        pts = self.K.shift_points(state['points'], shift3)                                          # common.py:238-244
+        render, existing = self.render_pointcloud(pts, state['data'], state['W'], state['H'], focal, baseline)   # :246-251
+        filled = self.K.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())       # :253
+        return self.K.frame_u8(filled)                                                              # :255
+
+
+def _depthrange(v):
+    return (float(v[0]), float(v[1]), (int(v[2]), int(v[3])), (int(v[4]), int(v[5])))
+
+
+def _scene(z, K):
+    from ken_burns_effect_amd import synthetic
+    image, disp = g(z['image']), g(z['disparity'])
+    H, W = image.shape[2:]
+    depth = (512.0 * 120) / (disp + 1e-7)
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H,
+          'dblDispmin': disp.min().item(), 'dblDispmax': disp.max().item(), 'objectDepthrange': _depthrange(z['depthrange']),
+          'tensorRawPoints': K.depth_to_points(depth, 512.0).view(1, 3, -1), 'tensorRawImage': image,
+          'tensorRawDisparity': disp, 'tensorRawDepth': depth}
+    ofrom, oto = synthetic.default_windows(H, W, bool(z['dolly']))
+    settings = {'dblSteps': [float(s) for s in z['steps']], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True,
+                'dolly': bool(z['dolly']), 'boolCrop': False}
+    return settings, oc
+
+
+class ReplayInpaint:
+    """Returns what the reference's Inpaint returned for the same call (recorded in the fixture), on the GPU."""
+
+    def __init__(self, z):
+        self.z, self.i = z, 0
+
+    def pointcloud_inpainting(self, tensorImage, tensorDisparity, tensorShift, objectCommon, dblFocal=None):
+        out = {k: g(self.z['inpaint%d_%s' % (self.i, k)]) for k in ('tensorExisting', 'tensorImage', 'tensorDisparity')}
+        self.i += 1
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's own frames on the HIP kernels (VERDICT r1 "what's weak" 1b / 1c)
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', ['kenburns_kbe', 'kenburns_dolly'])
+def test_reference_run_frames_on_the_hip_kernels_serial_schedule(K, monkeypatch, name):
+    """process_kenburns of the reference (kernel text executed serially) vs the same call on the HIP kernels with the
+    serial degrid: per-frame z-buffers bit for bit, the appended point cloud bit for bit, frames within one uint8 count
+    (the accumulation order of atomicAdd is the only freedom left; the reference's own is not defined either)."""
+    from ken_burns_effect_amd import common
+    z = load_golden(name)
+    ks = HipSerialKernels(K)
+    monkeypatch.setattr(common, '_kernel_set', ks)
+    settings, oc = _scene(z, K)
+    frames = common.process_kenburns(settings, oc, ReplayInpaint(z) if not z['dolly'] else None)
+    for key, ref in (('tensorInpaPoints', 'inpa_points'), ('tensorInpaImage', 'inpa_image'), ('tensorInpaDepth', 'inpa_depth'),
+                     ('tensorInpaDisparity', 'inpa_disparity')):
+        assert_bits_equal(c(oc[key]), z[ref], key)
+    assert len(frames) == len(z['frames']) == len(ks.zee_log)
+    for i, (f, ref) in enumerate(zip(frames, z['frames'])):
+        assert_bits_equal(c(ks.zee_log[i])[0, 0], z['frame_zee_serial'][i], 'frame %d: z-buffer after the serial degrid' % i)
+        d = np.abs(f.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, 'frame %d: %d values differ, max %d' % (i, int((d > 0).sum()), int(d.max()))
+
+
+@pytest.mark.parametrize('case', ['render_f512', 'render_f409', 'render_f153', 'render_noise', 'render_b2c7'])
+def test_serial_degrid_entry_bit_exact_against_reference_vectors(K, case):
+    z = load_golden(case)
+    pts = g(z['points'])
+    W, H = int(z['W']), int(z['H'])
+    baseline = int(z['baseline']) if bool(z['baseline_is_int']) else float(z['baseline'])
+    zkeys, _ = K.zsplat(pts, W, H, float(z['focal']), baseline)
+    assert_bits_equal(c(K.degrid_serial(zkeys=zkeys)), z['zee_serial_fma'], 'serial-schedule degrid from keys')
+    assert_bits_equal(c(K.degrid_serial(zee=g(z['zee_pre_fma']))), z['zee_serial_fma'], 'serial-schedule degrid from floats')
+
+
+def test_serial_degrid_entry_at_size_equals_the_oracle(K, oracle):
+    """512 x 384, white-noise depth (long cascades: the schedules differ in most pixels), batch 2."""
+    rng = np.random.default_rng(5)
+    zee = (1e6 - 61440.0 / (rng.random((2, 1, 384, 512)) * 900 + 100)).astype(np.float32)
+    zee[rng.random(zee.shape) < 0.1] = 1e6
+    ser = oracle.degrid(torch.from_numpy(zee), 'serial').numpy()
+    assert (ser != oracle.degrid(torch.from_numpy(zee), 'jacobi').numpy()).mean() > 0.05
+    assert_bits_equal(c(K.degrid_serial(zee=g(zee))), ser, 'serial degrid at size')
+
+
+# ---------------------------------------------------------------------------------------
+# a3 process_inpaint / build_pointcloud on the product kernel set
+# ---------------------------------------------------------------------------------------
+
+def test_process_inpaint_appends_the_reference_points(K):
+    """common.py:47-81 on the GPU (laplacian validity, unprojection, hole gather, append): the grown cloud equals the
+    reference's bit for bit.  The Inpaint outputs are replayed from the fixture, so nothing but process_inpaint's own
+    arithmetic is under test."""
+    from ken_burns_effect_amd import common
+    z = load_golden('kenburns_kbe')
+    settings, oc = _scene(z, K)
+    common.build_pointcloud(settings, oc, ReplayInpaint(z))
+    assert oc['tensorInpaPoints'].is_cuda and oc['tensorInpaPoints'].shape[2] == z['inpa_points'].shape[2] > oc['intWidth'] * oc['intHeight']
+    for key, ref in (('tensorInpaPoints', 'inpa_points'), ('tensorInpaImage', 'inpa_image'), ('tensorInpaDepth', 'inpa_depth'),
+                     ('tensorInpaDisparity', 'inpa_disparity')):
+        assert_bits_equal(c(oc[key]), z[ref], key)
+
+
+# ---------------------------------------------------------------------------------------
+# a4 process_load
+# ---------------------------------------------------------------------------------------
+
+def test_process_load_on_the_gpu_equals_the_cpu_restatement(K, oracle, monkeypatch):
+    from ken_burns_effect_amd import common, synthetic
+    image, disp = synthetic.make_rgbd(72, 88, 9)
+    img8 = (image[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    gpu = {}
+    common.process_load(img8, {'tensorDisparity': disp, 'device': 'cuda:0'}, gpu)
+    monkeypatch.setattr(common, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+    cpu = {}
+    common.process_load(img8, {'tensorDisparity': disp, 'device': 'cpu'}, cpu)
+    assert set(gpu) == set(cpu)
+    for k, v in cpu.items():
+        if torch.is_tensor(v):
+            assert gpu[k].is_cuda and gpu[k].shape == v.shape
+            assert_bits_equal(c(gpu[k]), v.numpy(), k)
+        else:
+            assert gpu[k] == v, k
+    assert gpu['dblBaseline'] == 40.0 and gpu['dblFocal'] == 512.0 and gpu['tensorRawPoints'].shape == (1, 3, 72 * 88)
+
+
+# ---------------------------------------------------------------------------------------
+# a9 Inpaint (MIOpen) and pointcloud_inpainting
+# ---------------------------------------------------------------------------------------
+
+@pytest.fixture(scope='module')
+def net():
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    return synthetic.seeded_fill_(Inpaint().eval(), 3).cuda()
+
+
+def _close(out, ref, tol, what):
+    err = float(np.abs(c(out) - ref).max())
+    print('%s: max abs error %.3g (bar %.3g)' % (what, err, tol))
+    assert err <= tol, '%s: max abs error %.3g > %.3g' % (what, err, tol)
+
+
+def test_inpaint_forward_on_miopen_matches_reference(net):
+    z = load_golden('inpaint')
+    with torch.no_grad():
+        net.normalize_images_disp(g(z['image']), g(z['disparity']), not_normed=True)
+        out = net(tensorData=g(z['fw_data']), tensorMasks=g(z['fw_mask']))
+    assert_bits_equal(c(out['tensorExisting']), z['fw_mask'], 'tensorExisting is the input mask')
+    _close(out['tensorImage'], z['fw_image'], TOL_IMAGE, 'Inpaint.forward image')
+    _close(out['tensorDisparity'], z['fw_disparity'], TOL_DISPARITY_REL * max(1.0, float(np.abs(z['fw_disparity']).max())), 'Inpaint.forward disparity')
+    with torch.no_grad():
+        out = net(tensorMasks=g(z['fw_mask']), tensorImage=g(z['image']), tensorDisparity=g(z['disparity']))
+    _close(out['tensorImage'], z['fi_image'], TOL_IMAGE, 'Inpaint.forward(image, disparity) image')
+    _close(out['tensorDisparity'], z['fi_disparity'], TOL_DISPARITY_REL * max(1.0, float(np.abs(z['fi_disparity']).max())), 'Inpaint.forward(image, disparity) disparity')
+
+
+def test_pointcloud_inpainting_on_the_hip_kernels_matches_reference(net, K, monkeypatch):
+    """pointcloud_inpainting.py:185-213 end to end on the GPU: unprojection, validity mask, context net, 68-channel
+    forward warp, median-5 hole dilation, GridNet.  Serial-schedule kernel set: z-buffer and hole mask bit for bit
+    against the reference run; then the product set (tile renderer, Jacobi): same holes wherever the two legal schedules
+    agree, colours within the bars."""
+    from ken_burns_effect_amd import common
+    z = load_golden('inpaint')
+    image, disp = g(z['image']), g(z['disparity'])
+    H, W = image.shape[2:]
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H}
+    ks = HipSerialKernels(K)
+    monkeypatch.setattr(common, '_kernel_set', ks)
+    with torch.no_grad():
+        out = net.pointcloud_inpainting(image, disp, g(z['pi_shift']), oc)
+    assert_bits_equal(c(ks.zee_log[-1]), z['pi_zee'], 'z-buffer of the 68-channel forward warp (serial schedule)')
+    assert_bits_equal(c(out['tensorExisting']), z['pi_existing'], 'existing mask after median-5 dilation')
+    _close(out['tensorImage'], z['pi_image'], TOL_IMAGE, 'pointcloud_inpainting image')
+    _close(out['tensorDisparity'], z['pi_disparity'], TOL_DISPARITY_REL * max(1.0, float(np.abs(z['pi_disparity']).max())), 'pointcloud_inpainting disparity')
+    monkeypatch.setattr(common, '_kernel_set', None)
+    with torch.no_grad():
+        prod = net.pointcloud_inpainting(image, disp, g(z['pi_shift']), oc)
+    same = c(prod['tensorExisting']) == z['pi_existing']
+    print('product (Jacobi) vs reference-run (serial) hole mask: %.4f of pixels agree' % same.mean())
+    assert same.mean() > 0.97
+    assert_bits_equal(c(image), z['image'], 'inputs are not modified')
+
+
+# ---------------------------------------------------------------------------------------
+# a10 / a11 partial convolution and the partial-conv GridNet
+# ---------------------------------------------------------------------------------------
+
+def test_partial_conv_layers_on_the_gpu_match_reference(K):
+    from ken_burns_effect_amd.partial_conv import PartialConv2d
+    z = load_golden('partial_conv')
+    for tag in 'abc':
+        cin, cout, k, s, p = [int(v) for v in z['cfg_' + tag]]
+        conv = PartialConv2d(cin, cout, kernel_size=k, stride=s, padding=p, bias=True, multi_channel=True, return_mask=True).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(g(z['w_' + tag]))
+            conv.bias.copy_(g(z['b_' + tag]))
+            out, um = conv(g(z['x_' + tag]), g(z['m_' + tag]))
+        assert_bits_equal(c(um.contiguous()), z['mask_' + tag], 'update_mask ' + tag)
+        _close(out, z['out_' + tag], 1e-5 * max(1.0, float(np.abs(z['out_' + tag]).max())), 'PartialConv2d ' + tag)
+
+
+def test_partial_inpaint_forward_on_the_gpu_matches_reference(K):
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.partial_inpainting import Inpaint
+    z = load_golden('partial_inpaint')
+    pnet = synthetic.seeded_fill_(Inpaint().eval(), 5).cuda()
+    image, disp = synthetic.make_rgbd(32, 40, 43, 'smooth')
+    with torch.no_grad():
+        pnet.normalize_images_disp(image.cuda(), disp.cuda(), not_normed=True)
+        out = pnet(tensorData=g(z['fw_data']), tensorMasks=g(z['fw_mask']))
+    assert list(out['tensorMaskOut'].shape) == [int(v) for v in z['fw_existing_shape']] and out['tensorExisting'].shape[1] == 1
+    _close(out['tensorImage'], z['fw_image'], 2 * TOL_IMAGE, 'partial Inpaint image')
+    _close(out['tensorDisparity'], z['fw_disparity'], 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(z['fw_disparity']).max())), 'partial Inpaint disparity')
+
+
+# ---------------------------------------------------------------------------------------
+# a13 / a14 Disparity, Refine
+# ---------------------------------------------------------------------------------------
+
+def test_disparity_and_refine_networks_on_miopen_match_reference():
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.disparity_estimation import Disparity
+    from ken_burns_effect_amd.disparity_refinement import Refine, RefinePretrained
+    z = load_golden('disparity')
+    dnet = synthetic.seeded_fill_(Disparity().eval(), 11).cuda()
+    with torch.no_grad():
+        out = dnet(g(z['image']), g(z['semantics']))
+    assert out.shape == (1, 1, 32, 48)
+    _close(out, z['disp_out'], 2e-4 * max(1.0, float(np.abs(z['disp_out']).max())), 'Disparity')
+    for tag, cls in (('refine', Refine), ('refinep', RefinePretrained)):
+        rnet = synthetic.seeded_fill_(cls().eval(), 13).cuda()
+        coarse = g(z['coarse'])
+        with torch.no_grad():
+            out = rnet(g(z['image']), coarse)
+        assert out.shape == (1, 1, 64, 96)
+        _close(out, z[tag + '_out'], 2e-4 * max(1.0, float(np.abs(z[tag + '_out']).max())), tag)
+        assert_bits_equal(c(coarse), z['coarse'], 'inputs untouched')
+
+
+# ---------------------------------------------------------------------------------------
+# a15 / f2: Pipeline at BASELINE configs[1] (512 x 512, 64 frames, seeded weights)
+# ---------------------------------------------------------------------------------------
+
+def test_pipeline_config1_full_size_front_half_and_a_frame_against_the_oracle(K, oracle):
+    """The whole Pipeline call of BASELINE.json configs[1] on the GPU.  Front half (resize, Semantics + Disparity,
+    Refine, normalisation, depth, unprojection; pipeline.py:61-100) against the same modules run on the CPU (which
+    test_models.py pins to the reference); then frame 37 of the 64 against the oracle rendering the pipeline's own
+    final cloud, crop + resize included."""
+    from ken_burns_effect_amd import common, kbe, synthetic
+    from ken_burns_effect_amd.pipeline import Pipeline
+    size, steps = 512, 64
+    image, _ = synthetic.make_rgbd(size, size, 21)
+    zoom = kbe.windows_for(size, size, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipe = Pipeline(model_paths=None, device='cuda:0', steps=steps)
+        frames = pipe(image, zoom)
+        cpu = Pipeline(model_paths=None, device='cpu', steps=steps)
+    assert len(frames) == steps and frames[0].shape == (size, size, 3) and frames[0].dtype == np.uint8
+    oc = pipe.objectCommon
+    n = oc['tensorInpaPoints'].shape[2]
+    assert n > size * size and oc['tensorInpaImage'].shape == (1, 3, n) and oc['tensorInpaDepth'].shape == (1, 1, n)
+    # front half: the GPU's disparity against the CPU's (seeded weights amplify rounding: the bar is relative to the range)
+    torch.set_num_threads(8)
+    common_saved = common._kernel_set
+    try:
+        common._kernel_set = oracle.OracleKernels(schedule='jacobi')      # the CPU twin's depth_to_points
+        ref = cpu.estimate(image)
+    finally:
+        common._kernel_set = common_saved
+    scale = float(ref['tensorRawDisparity'].abs().max())
+    err = float((oc['tensorRawDisparity'].cpu() - ref['tensorRawDisparity']).abs().max())
+    print('Pipeline front half: disparity max abs error %.3g of a range of %.3g' % (err, scale))
+    assert err <= 2e-3 * scale
+    assert abs(oc['dblDispmax'] - ref['dblDispmax']) <= 2e-3 * scale and oc['objectDepthrange'][2] == ref['objectDepthrange'][2]
+    # a frame from the middle of the path against the oracle on the SAME cloud (Jacobi schedule, as the product)
+    k = 37
+    settings = {'dblSteps': np.linspace(0.0, 1.0, steps).tolist(), 'objectFrom': zoom['objectFrom'], 'objectTo': zoom['objectTo'], 'dolly': False}
+    focal, shift3 = common.frame_cameras(settings, oc)[k]
+    ok = oracle.OracleKernels('jacobi')
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), size, size)
+    crop = common.crop_size(settings)
+    want = ok.crop_resize_u8(ok.render_frame(state, shift3, focal, oc['dblBaseline']), crop[0], crop[1]).numpy()
+    d = np.abs(frames[k].astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 2 and (d > 0).mean() < 2e-3, 'frame %d: %.5f of values differ, max %d' % (k, (d > 0).mean(), int(d.max()))

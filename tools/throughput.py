@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""us per frame of the bench workload with the frames left in HBM (dev aid; KBE_LIB_PATH = variant build)."""
+"""us per frame of the bench workload, frames left in HBM or (HOST=1) delivered to pinned host memory; BATCH > 0 selects
+the staged-ring hand-off (dev aid; KBE_LIB_PATH = variant build)."""
 import os
 import sys
 import time
@@ -24,15 +25,18 @@ oc = bench.build_scene(size, dev, os.environ.get('CLOUD', 'inpaint') == 'inpaint
                        int(os.environ.get('UPSAMPLE', '1')))
 cams = common.frame_cameras(settings, oc)
 crop = common.crop_size(settings)
-out = torch.empty(n, size, size, 3, dtype=torch.uint8, device=dev)
-common.render_frames(cams[:8], oc, crop, keep_on_device=True, host_out=out[:8])
+host = os.environ.get('HOST', '0') == '1'
+batch = int(os.environ.get('BATCH', '0')) or None
+out = torch.zeros(n, size, size, 3, dtype=torch.uint8, pin_memory=True) if host else torch.empty(n, size, size, 3, dtype=torch.uint8, device=dev)
+kw = dict(host_out=out, batch=batch) if host else dict(keep_on_device=True, host_out=out)
+common.render_frames(cams, oc, crop, **kw)
 best = 1e9
 enq = 1e9
 for _ in range(int(os.environ.get("REPS", "7"))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    common.render_frames(cams, oc, crop, keep_on_device=True, host_out=out)
+    common.render_frames(cams, oc, crop, **kw)
     enq = min(enq, (time.perf_counter() - t0) / n)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / n)
-print('throughput: %.1f us/frame (host enqueue %.1f us/frame; %d frames, %d lanes, best of runs)' % (best * 1e6, enq * 1e6, n, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
+print(('host-delivered' if host else 'device-only') + ' throughput: %.1f us/frame (host enqueue %.1f us/frame; %d frames, %d lanes, best of runs)' % (best * 1e6, enq * 1e6, n, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
