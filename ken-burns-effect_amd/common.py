@@ -152,7 +152,9 @@ def process_load(numpyImage, objectSettings, objectCommon):
     objectCommon['intWidth'] = numpyImage.shape[1]
     objectCommon['intHeight'] = numpyImage.shape[0]
     device = objectSettings.get('device', 'cuda:0') if isinstance(objectSettings, dict) else 'cuda:0'
-    tensorImage = torch.from_numpy(np.ascontiguousarray(numpyImage.transpose(2, 0, 1))).float().unsqueeze(0).to(device) / 255.0
+    # the division runs on the host (IEEE): torch's GPU kernels multiply by the rounded reciprocal of a scalar divisor,
+    # which is 1 ulp off for about half of the 256 values -- the same image must give the same cloud on every device
+    tensorImage = (torch.from_numpy(np.ascontiguousarray(numpyImage.transpose(2, 0, 1))).float().unsqueeze(0) / 255.0).to(device)
     if isinstance(objectSettings, dict) and objectSettings.get('tensorDisparity') is not None:
         tensorDisparity = objectSettings['tensorDisparity'].to(device).float()
     else:
@@ -325,7 +327,7 @@ def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_o
         if crop is not None:
             frame = K.crop_resize_u8(frame, crop[0], crop[1])
         out[i].copy_(frame)
-    return out if keep_on_device else out.numpy()
+    return out if keep_on_device else out.cpu().numpy()
 
 
 def process_kenburns(objectSettings, objectCommon, moduleInpaint):
