@@ -119,9 +119,6 @@ size_t scratch_bytes(int W, int H)
            align16(4 * (size_t) H * ((W + 31) / 32)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
-#if defined(KBE_PROBE_NOP_CROP)
-__global__ void k_probe_nop() { }
-#endif
 
 __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
 {
@@ -251,12 +248,6 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
         for (int e = 0; e < 2; e++) {
             const int tx = tx0 + e;
             want[e] = ok && (e == 0 || spx) && ((unsigned) tx < (unsigned) a.tiles_x) & ((unsigned) ty0 < (unsigned) a.tiles_y);
-#if defined(KBE_PROBE_NO_SPILLS)
-            if (e > 0) want[e] = false;
-#endif
-#if defined(KBE_PROBE_NO_BUCKETS)
-            want[e] = false;
-#endif
             tgt[e] = __mul24(ty0, a.tiles_x) + tx;                      // 24-bit multiply: full rate (the 32-bit one is quarter rate)
             base[e] = 0;
         }
@@ -271,18 +262,13 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
         int zidx = -1;
         if (ok) {
             project_weights(ox, oy, p);
-#if defined(KBE_PROBE_EXACT_ERR)
-            err = project_err(cam, z);
-#else
             err = project_err_fast(cam, z);
-#endif
             const int k = winner_corner(p);                             // common.py:486-506
             if (k >= 0) {
                 const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
                 if (inside(cx, cy, cam.W, cam.H)) zidx = __mul24(cy, cam.W) + cx;
             }
         }
-#if !defined(KBE_PROBE_NO_ZSPLAT)
         if (a.dense) {
             // a cloud denser than the target raster (BASELINE configs[4]: 4 points per pixel): the 2 x 2 source
             // neighbours (lanes ^1, ^32, ^33 of a 32 x 2 patch) mostly splat onto the same pixel and their atomics
@@ -304,7 +290,6 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
         } else if (zidx >= 0) {
             atomicMin(&a.zkeys[(uint32_t) zidx], zkey_encode(err));
         }
-#endif
         const float4 rec = make_float4(ox, oy, err, __int_as_float((int) i));
         // all buckets within 4 GB (frames up to 4096 x 4096): a 32-bit byte offset from a 24-bit multiply on the
         // uniform base; otherwise 64-bit arithmetic (a quarter-rate multiply-add)
@@ -322,7 +307,6 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
             }
         }
         // round 1 (rare): south and south-east neighbours
-#if !defined(KBE_PROBE_NO_SPILLS) && !defined(KBE_PROBE_NO_BUCKETS)
         if (__ballot(spy) != 0ull) {                                    // wave-uniform
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -345,7 +329,6 @@ __global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
                 }
             }
         }
-#endif
     }
 }
 
@@ -418,9 +401,6 @@ __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float 
 
 __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
 {
-#if defined(KBE_PROBE_NO_RGBD)
-    return make_float4(0.5f, 0.25f, 0.125f, 700.0f + (float) (id & 1));
-#endif
     // uniform plane bases + one 32-bit byte offset per record (N <= 2^30): the loads take the scalar-base form and
     // the lane computes a single shift instead of four 64-bit address additions
     const uint32_t off = (uint32_t) id << 2;
@@ -489,29 +469,14 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
     }
 }
 
-#if defined(KBE_PROBE_TIMING)
-#define KBE_TICK(i) do { if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + (i)] = (long long) __builtin_readcyclecounter(); } while (0)
-#else
-#define KBE_TICK(i) do { } while (0)
-#endif
 
 #ifndef KBE_TILE_WAVES
 #define KBE_TILE_WAVES 4
 #endif
-#if defined(KBE_TILE_NUM_VGPR)      // probe: a register cap (gfx90a+ counts the unified file, so the value is HALF the cap)
-#define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES), amdgpu_num_vgpr(KBE_TILE_NUM_VGPR)
-#else
 #define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES)
-#endif
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileArgs a)
 {
     __shared__ TileLds L;
-#if defined(KBE_PROBE_TIMING)
-    if (threadIdx.x == 0 && a.render) {
-        ((long long*) a.render)[(size_t) blockIdx.x * 16 + 0] = (long long) __builtin_readcyclecounter();
-        ((long long*) a.render)[(size_t) blockIdx.x * 16 + 11] = (long long) wall_clock64();
-    }
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -576,25 +541,15 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         const unsigned long long odd = __ballot(!band);
         if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
     }
-    KBE_TICK(1);
     __syncthreads();
-    KBE_TICK(2);
     // one decision per tile: every z of tile + halo in [2^19, 1e6] (any scene whose points are farther than
     // F*B/475712 from the camera) -> fp32-only, branch-free degrid and z test
     bool fast = true;
 #pragma unroll
     for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
-#if defined(KBE_PROBE_NO_FAST)
-    fast = false;
-#endif
     fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
     // degrid (common.py:525-568), out of place
-#if defined(KBE_PROBE_SKIP_DEGRID)
-    for (int i = tid; i < TH * TW; i += TILE_THREADS) L.zee[i] = L.zpre[(i / TW + 1) * KW + (i % TW) + 1];
-    if (false) {
-#else
     if (fast && !a.zee_pre) {
-#endif
 #pragma unroll
         for (int u = 0; u < PIX_PER_THREAD; u++) {
             const int i = tid + u * TILE_THREADS;
@@ -642,8 +597,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
                 }
                 __syncthreads();
             }
-            KBE_TICK(3);
-#if !defined(KBE_PROBE_SKIP_INSERT)
             {
                 // all of this thread's list exchanges first, then the records with the links they returned (one after
                 // the other each exchange was an LDS round trip in front of the next)
@@ -664,19 +617,12 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
                     if (i < n) L.rec[i] = make_float4(rr[u].x, rr[u].y, rr[u].z, __int_as_float(nxt[u]));
                 }
             }
-#endif
-            KBE_TICK(4);
             __syncthreads();
-            KBE_TICK(5);
-#if !defined(KBE_PROBE_SKIP_GATHER)
             if (fast) gather<true>(a, L, tid, x0, y0, acc);
             else gather<false>(a, L, tid, x0, y0, acc);
-#endif
-            KBE_TICK(6);
         }
         // no barrier here: what follows stages its bytes and per-wave partial results in the z-buffer area, dead since
         // the barrier in front of the gather, so a wave that is done resolves its pixels while others still walk
-        KBE_TICK(7);
     } else {
         // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
         // records from the whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
@@ -740,11 +686,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         res[m][0] = quot(acc[m].rg.x); res[m][1] = quot(acc[m].rg.y); res[m][2] = quot(acc[m].bd.x); res[m][3] = quot(acc[m].bd.y);
         dms[m] = res[m][3] * (w > 0.0f ? 1.0f : 0.0f);
         valid[m] = in && dms[m] > 0.0f;
-#if defined(KBE_PROBE_NO_HOLES)
-        hole[m] = false;
-#else
         hole[m] = in && !(dms[m] > 0.0f);
-#endif
         hm[m] = __ballot(hole[m]);
         n_holes += __popcll(hm[m]);
     }
@@ -772,19 +714,15 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
                 vx0 = min(vx0, x0 + __builtin_ctz(any)); vx1 = max(vx1, x0 + 31 - __builtin_clz(any));
                 vy0 = min(vy0, lo ? wrow : wrow + 1); vy1 = max(vy1, hi ? wrow + 1 : wrow);
                 // which 8 x 8 blocks of the tile hold a valid pixel (the hole fill skips through blocks that do not)
-#if !defined(KBE_PROBE_NO_COARSE)
                 const uint32_t cols = (any & 0xFFu ? 1u : 0u) | (any & 0xFF00u ? 2u : 0u) | (any & 0xFF0000u ? 4u : 0u) | (any & 0xFF000000u ? 8u : 0u);
                 cbits |= cols << ((TW / 8) * ((wrow - y0) >> 3));
-#endif
             }
         }
         if (in) {
             // W * H <= 2^30: a 32-bit element index (24-bit multiply) and scalar plane bases instead of 64-bit vector arithmetic
             const uint32_t o = __umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x;
             a.depth[o] = dms[m];
-#if !defined(KBE_PROBE_TIMING)
             if (a.render) { a.render[o] = res[m][0]; (a.render + HW)[o] = res[m][1]; (a.render + 2 * HW)[o] = res[m][2]; (a.render + 3 * HW)[o] = res[m][3]; }
-#endif
             if (a.existing) a.existing[o] = acc[m].w;
         }
     }
@@ -795,7 +733,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         int* sb = s_part;
         if (lane == 0) { sb[4 * wave_s + 0] = vx0; sb[4 * wave_s + 1] = vy0; sb[4 * wave_s + 2] = vx1; sb[4 * wave_s + 3] = vy1; sb[64 + wave_s] = (int) cbits; }
     }
-    KBE_TICK(8);
     __syncthreads();
     if (tid == 0) {
         const int* sb = s_part;
@@ -808,7 +745,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         for (int w = 0; w < TILE_THREADS / 64; w++) cb |= (uint32_t) sb[64 + w];
         a.coarse[tile] = cb;
     }
-    KBE_TICK(9);
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
     const bool dword_rows = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
     if (dword_rows) {
@@ -843,10 +779,6 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             base += __popcll(hm[m]);
         }
     }
-    KBE_TICK(10);
-#if defined(KBE_PROBE_TIMING)
-    if (threadIdx.x == 0 && a.render) ((long long*) a.render)[(size_t) blockIdx.x * 16 + 12] = (long long) wall_clock64();
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1187,18 +1119,12 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                                     int tiles_x, int tiles_y)
 {
     // leave the scratch ready for the next frame: empty z-buffer, empty buckets
-#if !defined(KBE_PROBE_NO_RESET)
     {
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int i = gtid; i < W * H; i += gsz) zkeys[i] = KBE_ZKEY_EMPTY;
         for (int i = gtid; i < n_tiles; i += gsz) tile_count[i * CNT_STRIDE] = 0;
     }
-#endif
-#if defined(KBE_PROBE_NO_WALK)
-    const int n = 0;
-#else
     const int n = min(*hole_count, W * H);
-#endif
     // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
     // (common.py:880-885) without walking there.  Exact, and it is what makes a zoomed-out (dolly) frame,
@@ -1565,9 +1491,7 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
     return launched("kbe_render_pointcloud_tiled/reset");
 }
 
-#ifndef KBE_VIDEO_STAGES            // probe builds time a subset of the frame's launches in the multi-lane loop (tools/gpu_cases.sh)
-#define KBE_VIDEO_STAGES (KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL)
-#endif
+constexpr int KBE_VIDEO_STAGES = KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL;
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
@@ -1647,11 +1571,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
                                          KBE_VIDEO_STAGES | (lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0),
                                          crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
-#if defined(KBE_PROBE_NOP_CROP)
-        hipLaunchKernelGGL(k_probe_nop, dim3(KBE_PROBE_NOP_CROP), dim3(64), 0, ls[l]);     // what does a launch cost by itself?
-#elif !defined(KBE_PROBE_NO_CROP)
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
-#endif
         return rc;
     };
     // whoever synchronises `stream` afterwards also sees every frame delivered and every other stream idle
