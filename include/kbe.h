@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 2
+#define KBE_ABI_VERSION 3
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -182,11 +182,41 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_FILL_PER_LANE 8
 #define KBE_STAGE_FILL_PER_HALFWAVE 16
 #define KBE_STAGE_FILL_BY_COUNT 32
+/* kbe_render_frame_fused with parity -1 only: do not zero the hole counter first (bench.py times the scatter launch
+ * alone, back to back; the frames of such a run are not valid) */
+#define KBE_STAGE_KEEP_HOLE_COUNT 64
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
                                     float* zee_pre_f32, int stages, const int* fill_rect, int raster_w, int raster_n,
                                     kbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The same frame from the PACKED cloud, with the whole of render_pointcloud in ONE launch (the default route of the
+ * Python host side).
+ *
+ * kbe_cloud_pack, once per video after the set-up loop has grown the cloud: sorts the points by where they lie in
+ * the cloud's own view (Morton order of 8 x 8-pixel cells for points projected with `focal` onto a W x H raster; any
+ * order is correct, this one is fast), cuts them into blocks of 64, and builds over them a hierarchy of boxes that
+ * bound where a block's points can land in any view.  `packed`: DEVICE buffer of kbe_cloud_pack_bytes(N) bytes,
+ * 256-byte aligned, owned by the caller; the original three tensors are not needed afterwards.
+ *
+ * kbe_render_frame_fused: one frame.  `stages`: KBE_STAGE_TILES = the scatter (z-splat into an LDS z-tile, degrid,
+ * z-tested gather, normalise, uint8 -- a tile pulls the points that can reach it through the box hierarchy; no
+ * z-buffer, bucket or accumulator in HBM, no global atomic), KBE_STAGE_FILL (+ schedule flags) = the hole fill.
+ * `cloud_focal` = the focal given to kbe_cloud_pack.  `parity`: the scratch holds two hole counters; consecutive
+ * frames on one scratch alternate 0, 1, 0, ... (the fill of a frame zeroes the counter of the next), starting from
+ * a scratch whose counters are zero (kbe_frame_scratch_init, or any frame rendered with parity -1); -1 = a frame on
+ * its own: the counter is zeroed by a memset in front of the scatter.  Outputs, scratch and fill_rect as
+ * kbe_render_frame_stages; results equal the bucket path's up to the order of the fp32 sums.
+ * ------------------------------------------------------------------------------------- */
+KBE_API size_t kbe_cloud_pack_bytes(int N);
+KBE_API int kbe_cloud_pack(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
+                           void* packed, kbe_stream_t stream);
+KBE_API int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W, int H, double focal, double baseline,
+                                   const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
+                                   float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages,
+                                   const int* fill_rect, int parity, kbe_stream_t stream);
 
 /* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
  * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
@@ -203,6 +233,8 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  * not filled), then the hand-off of the finished uint8 frame to host_out[i] ([n_frames,H,W,3]; the
  * `.cpu()` of common.py:255).  focals [n_frames] and shifts [n_frames][3] are HOST arrays (shift as
  * the fp32 values process_shift produces).
+ * `packed` / `cloud_focal`: the packed cloud of kbe_cloud_pack (then every frame is kbe_render_frame_fused and points /
+ * image / depth / raster_* are not used), or NULL / 0 for the bucket path.
  * Frames are independent, so consecutive frames are enqueued on `lanes` (1..KBE_MAX_LANES) streams,
  * lane 0 on `stream`, lane l on lane_streams[l] (may be NULL when lanes == 1); each lane has its
  * own scratch, raw frame and finished frame.  Synchronising `stream` afterwards guarantees every
@@ -228,8 +260,8 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
-                             int raster_w, int raster_n, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
-                             const kbe_stream_t* lane_streams);
+                             int raster_w, int raster_n, const void* packed, double cloud_focal, kbe_stream_t stream,
+                             kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams);
 
 /* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where
  * point i of points[B,3,N] + shift[B,3] (a DEVICE array, the tensorShift of :690) owns the pixel its z-splat

@@ -20,11 +20,11 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory (env KBE_HOST_LANES)
@@ -52,6 +52,7 @@ def load():
     lib.kbe_frame_scratch_bytes.restype = ctypes.c_size_t
     lib.kbe_video_scratch_stride.restype = ctypes.c_size_t
     lib.kbe_video_stage_bytes.restype = ctypes.c_size_t
+    lib.kbe_cloud_pack_bytes.restype = ctypes.c_size_t
     if lib.kbe_abi_version() != ABI_VERSION:
         raise KbeError('libkbe_hip.so ABI %d != expected %d' % (lib.kbe_abi_version(), ABI_VERSION))
     _lib = lib
@@ -241,14 +242,31 @@ class HipKernels:
         for l in range(lanes):
             self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
                         'kbe_frame_scratch_init')
+        # the packed form the fused frame kernel renders from (kbe_cloud_pack: once per cloud); KBE_FUSED=0 keeps the
+        # bucket path (k_project + k_tiles) as the route of render_frame / render_video instead
+        state['fused'] = os.environ.get('KBE_FUSED', '1') != '0'
+        state['cloud_focal'] = float(focal) if focal else 512.0
+        if state['fused']:
+            state['packed'] = torch.empty(int(self.lib.kbe_cloud_pack_bytes(_i(N))), dtype=torch.uint8, device=dev)
+            self._check(self.lib.kbe_cloud_pack(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(N), _i(W), _i(H),
+                                                _d(state['cloud_focal']), _ptr(state['packed'], torch.uint8), _stream()), 'kbe_cloud_pack')
         return state
 
     def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None, zee_f32=None,
-                     zee_pre_f32=None, out=None, stages=7, fill_rect=None):
+                     zee_pre_f32=None, out=None, stages=7, fill_rect=None, fused=None):
         """One frame of common.py:238-255 (shift -> render -> fill -> uint8) -> uint8 [H,W,3] on the device.
-        fill_rect = (x0, y0, x1, y1): only holes inside are filled (see include/kbe.h)."""
+        fill_rect = (x0, y0, x1, y1): only holes inside are filled (see include/kbe.h).  ``fused`` (default: the
+        state's route): the one-launch scatter on the packed cloud; False: the bucket path (k_project + k_tiles).
+        ``stages``: bit 1 = projection launch (bucket path only), 2 = scatter / tile launch, 4 = hole fill (+ flags)."""
         frame = state['frame'] if out is None else out
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
+        if state.get('fused') if fused is None else fused:
+            self._check(self.lib.kbe_render_frame_fused(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']),
+                                                        _i(state['W']), _i(state['H']), _d(float(focal)), _d(float(baseline)),
+                                                        _shift(shift3), _ptr(state['scratch'], torch.uint8), _ptr(frame, torch.uint8),
+                                                        _ptr(render_f32), _ptr(existing_f32), _ptr(zee_f32), _ptr(zee_pre_f32),
+                                                        _i(int(stages) & ~1), rect, _i(-1), _stream()), 'kbe_render_frame_fused')
+            return frame
         self._check(self.lib.kbe_render_frame_stages(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']),
                                                      _i(state['N']), _i(state['W']), _i(state['H']), _d(float(focal)),
                                                      _d(float(baseline)), _shift(shift3), _ptr(state['scratch'], torch.uint8),
@@ -298,6 +316,7 @@ class HipKernels:
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
+                                              _ptr(state['packed'], torch.uint8) if state.get('fused') else None, _d(state['cloud_focal']),
                                               _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
         return host_out
 

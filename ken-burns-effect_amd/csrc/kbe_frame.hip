@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "kbe.h"
+#include "kbe_cloud.h"
 #include "kbe_device.h"
 #include "kbe_fill.h"
 #include "kbe_host.h"
@@ -42,6 +43,8 @@
 #pragma clang fp contract(off)
 
 using namespace kbe;
+
+namespace kbe { PackedCloud cloud_open(const void* packed, int N, double focal); }      // kbe_cloud.hip
 
 namespace {
 
@@ -125,7 +128,7 @@ __global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int 
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += stride) zkeys[i] = KBE_ZKEY_EMPTY;
     for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
-    if (gtid == 0) *hole_count = 0;
+    if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -470,85 +473,12 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
 }
 
 
-#ifndef KBE_TILE_WAVES
-#define KBE_TILE_WAVES 4
-#endif
-#define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES)
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileArgs a)
+// degrid (common.py:525-568), out of place: L.zpre (tile + halo, decoded) -> L.zee.  `fast`: every z of tile + halo in
+// [2^19, 1e6] (any scene whose points are farther than F*B/475712 from the camera) -> fp32-only, branch-free
+template <class Args>
+__device__ __forceinline__ void tile_degrid(const Args& a, TileLds& L, int tid, int x0, int y0, bool fast)
 {
-    __shared__ TileLds L;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
     const int W = a.cam.W, H = a.cam.H;
-
-    // The launch is latency-bound, so the loads are ordered by what depends on them: the bucket count and this
-    // thread's share of the first REC_CAP records first (the colour fetch needs the point indices in them),
-    // then its share of the z-buffer tile; the colour loads are issued as soon as the records are in and fly
-    // during the z-buffer decode, the first barrier and the degrid.  None of these loads sits under a branch:
-    // the compiler's wait-count bookkeeping is per program point, and a load that MAY have been issued makes
-    // every later wait on an older load a wait for everything (measured: the colour loads were waited for
-    // in front of the degrid instead of behind it).
-    const int count = a.tile_count[tile * CNT_STRIDE];
-    const bool bucketed = count <= BUCKET_CAP;
-    const float4* B = a.buckets + (size_t) tile * BUCKET_STRIDE;
-    constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
-    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
-    float4 rr[PER], cc[PER];
-    // the first REC_CAP records are loaded WITHOUT waiting for the count (the bucket is at least that
-    // large, so the addresses are valid; slots past the count hold stale records and are masked below)
-    static_assert(BUCKET_CAP >= ((REC_CAP + TILE_THREADS - 1) / TILE_THREADS) * TILE_THREADS, "speculative bucket loads stay in bounds");
-#pragma unroll
-    for (int u = 0; u < PER; u++) rr[u] = B[tid + u * TILE_THREADS];
-    uint32_t zk[ZPER];
-    bool zin[ZPER];
-#pragma unroll
-    for (int u = 0; u < ZPER; u++) {
-        const int i = tid + u * TILE_THREADS;
-        const int py = i / KW, pxl = i - py * KW;
-        const int xr = x0 - 1 + pxl, yr = y0 - 1 + py;
-        zin[u] = inside(xr, yr, W, H);
-        const int x = min(max(xr, 0), W - 1), y = min(max(yr, 0), H - 1);       // clamped: always a valid address
-        // W * H < 2^31 / 4: a 32-bit byte offset on the uniform base
-        // (24-bit multiply: full rate, the 32-bit one is quarter rate; y, W < 2^24)
-        zk[u] = *(const uint32_t*) ((const char*) a.zkeys + ((__umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x) << 2));
-    }
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
-    if (tid == 0) {
-        L.nrec = 0;
-        lds_dummy_record(L);
-    }
-    // colours of the records (slots past the count: point 0, discarded later; the host never passes a NULL cloud)
-    const int n0 = bucketed ? min(REC_CAP, count) : 0;
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int i = tid + u * TILE_THREADS;
-        cc[u] = fetch_rgbd(a, i < n0 ? __float_as_int(rr[u].w) : 0);
-    }
-    bool band = true;
-#pragma unroll
-    for (int u = 0; u < ZPER; u++) {
-        const int i = tid + u * TILE_THREADS;
-        if (i < KH * KW) {
-            const float z = zkey_decode(zin[u] ? zk[u] : KBE_ZKEY_EMPTY);       // common.py:430 outside
-            L.zpre[i] = z;
-            band = band && degrid_fast_ok(z);
-        }
-    }
-    {
-        const unsigned long long odd = __ballot(!band);
-        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
-    }
-    __syncthreads();
-    // one decision per tile: every z of tile + halo in [2^19, 1e6] (any scene whose points are farther than
-    // F*B/475712 from the camera) -> fp32-only, branch-free degrid and z test
-    bool fast = true;
-#pragma unroll
-    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
-    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
-    // degrid (common.py:525-568), out of place
     if (fast && !a.zee_pre) {
 #pragma unroll
         for (int u = 0; u < PIX_PER_THREAD; u++) {
@@ -574,93 +504,15 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         }
     }
 
-    PixAcc acc[PIX_PER_THREAD];
-#pragma unroll
-    for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
+}
 
-    if (bucketed) {
-        // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
-        for (int r0 = 0; r0 == 0 || r0 < count; r0 += REC_CAP) {
-            const int n = min(REC_CAP, count - r0);
-            if (r0 > 0) {
-                __syncthreads();                                // the previous round's gather is done with the lists
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int i = tid + u * TILE_THREADS;
-                    rr[u] = i < n ? B[r0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int i = tid + u * TILE_THREADS;
-                    cc[u] = i < n ? fetch_rgbd(a, __float_as_int(rr[u].w)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                __syncthreads();
-            }
-            {
-                // all of this thread's list exchanges first, then the records with the links they returned (one after
-                // the other each exchange was an LDS round trip in front of the next)
-                int nxt[PER];
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int i = tid + u * TILE_THREADS;
-                    nxt[u] = REC_NULL;
-                    if (i < n) {
-                        const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
-                        L.rgbd[i] = cc[u];
-                        nxt[u] = atomicExch(&L.head[__mul24(by, BW) + bx], i << 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int i = tid + u * TILE_THREADS;
-                    if (i < n) L.rec[i] = make_float4(rr[u].x, rr[u].y, rr[u].z, __int_as_float(nxt[u]));
-                }
-            }
-            __syncthreads();
-            if (fast) gather<true>(a, L, tid, x0, y0, acc);
-            else gather<false>(a, L, tid, x0, y0, acc);
-        }
-        // no barrier here: what follows stages its bytes and per-wave partial results in the z-buffer area, dead since
-        // the barrier in front of the gather, so a wave that is done resolves its pixels while others still walk
-    } else {
-        // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
-        // records from the whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
-        __syncthreads();
-        const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
-        for (int i0 = 0; i0 < n_round; i0 += TILE_THREADS) {
-            const int i = i0 + tid;
-            bool ok = i < a.N;
-            float ox = 0.0f, oy = 0.0f, z = 0.0f;
-            if (ok) {
-                float x = a.points[i], y = a.points[(size_t) a.N + i];
-                z = a.points[2 * (size_t) a.N + i];
-                apply_shift(a.cam, x, y, z);
-                ok = project_xy(a.cam, x, y, z, ox, oy);
-            }
-            if (ok) {
-                const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
-                ok = (bx >= 0) & (bx < BW) & (by >= 0) & (by < BH);
-            }
-            const unsigned long long m = __ballot(ok);
-            if (m) {
-                int base = 0;
-                const int leader = __ffsll((long long) m) - 1;
-                if (lane == leader) base = atomicAdd(&L.nrec, __popcll(m));
-                base = __shfl(base, leader);
-                if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), fetch_rgbd(a, i), x0, y0);
-            }
-            __syncthreads();
-            if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
-                gather<false>(a, L, tid, x0, y0, acc);
-                __syncthreads();
-                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
-                if (tid == 0) L.nrec = 0;
-                __syncthreads();
-            }
-        }
-    }
-
+// resolve + store of a tile whose pixels hold their accumulated sums: normalise (common.py:686), hole mask (:253),
+// uint8 (:255), validity bitmask / bounding box / coarse bits / hole list for the fill, coalesced stores
+template <class Args>
+__device__ __forceinline__ void tile_epilogue(const Args& a, TileLds& L, PixAcc (&acc)[PIX_PER_THREAD], int tile, int x0, int y0)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = a.cam.W, H = a.cam.H;
     // resolve: normalise (common.py:686), hole mask (:253), uint8 (:255)
     const size_t HW = (size_t) W * H;
     static_assert(sizeof(L.zpre) >= TW * TH * 3 + (64 + TILE_THREADS / 64) * sizeof(int), "uint8 staging + per-wave partials fit the z-buffer area");
@@ -779,6 +631,542 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             base += __popcll(hm[m]);
         }
     }
+}
+
+#ifndef KBE_TILE_WAVES
+#define KBE_TILE_WAVES 4
+#endif
+#define KBE_TILE_ATTR amdgpu_waves_per_eu(KBE_TILE_WAVES, KBE_TILE_WAVES)
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileArgs a)
+{
+    __shared__ TileLds L;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int W = a.cam.W, H = a.cam.H;
+
+    // The launch is latency-bound, so the loads are ordered by what depends on them: the bucket count and this
+    // thread's share of the first REC_CAP records first (the colour fetch needs the point indices in them),
+    // then its share of the z-buffer tile; the colour loads are issued as soon as the records are in and fly
+    // during the z-buffer decode, the first barrier and the degrid.  None of these loads sits under a branch:
+    // the compiler's wait-count bookkeeping is per program point, and a load that MAY have been issued makes
+    // every later wait on an older load a wait for everything (measured: the colour loads were waited for
+    // in front of the degrid instead of behind it).
+    const int count = a.tile_count[tile * CNT_STRIDE];
+    const bool bucketed = count <= BUCKET_CAP;
+    const float4* B = a.buckets + (size_t) tile * BUCKET_STRIDE;
+    constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
+    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
+    float4 rr[PER], cc[PER];
+    // the first REC_CAP records are loaded WITHOUT waiting for the count (the bucket is at least that
+    // large, so the addresses are valid; slots past the count hold stale records and are masked below)
+    static_assert(BUCKET_CAP >= ((REC_CAP + TILE_THREADS - 1) / TILE_THREADS) * TILE_THREADS, "speculative bucket loads stay in bounds");
+#pragma unroll
+    for (int u = 0; u < PER; u++) rr[u] = B[tid + u * TILE_THREADS];
+    uint32_t zk[ZPER];
+    bool zin[ZPER];
+#pragma unroll
+    for (int u = 0; u < ZPER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        const int py = i / KW, pxl = i - py * KW;
+        const int xr = x0 - 1 + pxl, yr = y0 - 1 + py;
+        zin[u] = inside(xr, yr, W, H);
+        const int x = min(max(xr, 0), W - 1), y = min(max(yr, 0), H - 1);       // clamped: always a valid address
+        // W * H < 2^31 / 4: a 32-bit byte offset on the uniform base
+        // (24-bit multiply: full rate, the 32-bit one is quarter rate; y, W < 2^24)
+        zk[u] = *(const uint32_t*) ((const char*) a.zkeys + ((__umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x) << 2));
+    }
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+    if (tid == 0) {
+        L.nrec = 0;
+        lds_dummy_record(L);
+    }
+    // colours of the records (slots past the count: point 0, discarded later; the host never passes a NULL cloud)
+    const int n0 = bucketed ? min(REC_CAP, count) : 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        cc[u] = fetch_rgbd(a, i < n0 ? __float_as_int(rr[u].w) : 0);
+    }
+    bool band = true;
+#pragma unroll
+    for (int u = 0; u < ZPER; u++) {
+        const int i = tid + u * TILE_THREADS;
+        if (i < KH * KW) {
+            const float z = zkey_decode(zin[u] ? zk[u] : KBE_ZKEY_EMPTY);       // common.py:430 outside
+            L.zpre[i] = z;
+            band = band && degrid_fast_ok(z);
+        }
+    }
+    {
+        const unsigned long long odd = __ballot(!band);
+        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
+    }
+    __syncthreads();
+    // one decision per tile: every z of tile + halo in [2^19, 1e6] (any scene whose points are farther than
+    // F*B/475712 from the camera) -> fp32-only, branch-free degrid and z test
+    bool fast = true;
+#pragma unroll
+    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
+    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
+    tile_degrid(a, L, tid, x0, y0, fast);
+
+    PixAcc acc[PIX_PER_THREAD];
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
+
+    if (bucketed) {
+        // the normal path: the tile's records, REC_CAP at a time (one round unless points pile up)
+        for (int r0 = 0; r0 == 0 || r0 < count; r0 += REC_CAP) {
+            const int n = min(REC_CAP, count - r0);
+            if (r0 > 0) {
+                __syncthreads();                                // the previous round's gather is done with the lists
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    rr[u] = i < n ? B[r0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    cc[u] = i < n ? fetch_rgbd(a, __float_as_int(rr[u].w)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                __syncthreads();
+            }
+            {
+                // all of this thread's list exchanges first, then the records with the links they returned (one after
+                // the other each exchange was an LDS round trip in front of the next)
+                int nxt[PER];
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    nxt[u] = REC_NULL;
+                    if (i < n) {
+                        const int bx = (int) floorf(rr[u].x) - (x0 - 1), by = (int) floorf(rr[u].y) - (y0 - 1);
+                        L.rgbd[i] = cc[u];
+                        nxt[u] = atomicExch(&L.head[__mul24(by, BW) + bx], i << 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int i = tid + u * TILE_THREADS;
+                    if (i < n) L.rec[i] = make_float4(rr[u].x, rr[u].y, rr[u].z, __int_as_float(nxt[u]));
+                }
+            }
+            __syncthreads();
+            if (fast) gather<true>(a, L, tid, x0, y0, acc);
+            else gather<false>(a, L, tid, x0, y0, acc);
+        }
+        // no barrier here: what follows stages its bytes and per-wave partial results in the z-buffer area, dead since
+        // the barrier in front of the gather, so a wave that is done resolves its pixels while others still walk
+    } else {
+        // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's
+        // records from the whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
+        __syncthreads();
+        const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
+        for (int i0 = 0; i0 < n_round; i0 += TILE_THREADS) {
+            const int i = i0 + tid;
+            bool ok = i < a.N;
+            float ox = 0.0f, oy = 0.0f, z = 0.0f;
+            if (ok) {
+                float x = a.points[i], y = a.points[(size_t) a.N + i];
+                z = a.points[2 * (size_t) a.N + i];
+                apply_shift(a.cam, x, y, z);
+                ok = project_xy(a.cam, x, y, z, ox, oy);
+            }
+            if (ok) {
+                const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
+                ok = (bx >= 0) & (bx < BW) & (by >= 0) & (by < BH);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                int base = 0;
+                const int leader = __ffsll((long long) m) - 1;
+                if (lane == leader) base = atomicAdd(&L.nrec, __popcll(m));
+                base = __shfl(base, leader);
+                if (ok) lds_insert(L, base + __popcll(m & ((1ull << lane) - 1ull)), ox, oy, project_err(a.cam, z), fetch_rgbd(a, i), x0, y0);
+            }
+            __syncthreads();
+            if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
+                gather<false>(a, L, tid, x0, y0, acc);
+                __syncthreads();
+                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
+                if (tid == 0) L.nrec = 0;
+                __syncthreads();
+            }
+        }
+    }
+
+    tile_epilogue(a, L, acc, tile, x0, y0);
+}
+
+// ---------------------------------------------------------------------------------------
+// THE FUSED SCATTER: render_pointcloud (common.py:428-686) of one frame in ONE launch, from the packed cloud
+// (kbe_cloud.h).  No global z-buffer, no bucket records, no global atomic: a tile PULLS its points.
+//   cull     the tile walks the node hierarchy of the cloud (a node = a conservative box of where its points can land
+//            in this view) down to its candidate blocks of 64 points: ~20 of 18 k at 1024^2, 2-3 node tests per thread;
+//   splat    every candidate point is shifted (common.py:104-109) and projected (:447-468); a point whose north-west
+//            corner lies in the tile or within two pixels of it min-splats the key of its dblError into the tile's
+//            z-buffer IN LDS (tile + 1-pixel halo: one ds_min_u32 on the winner corner, :486-506), and a point whose
+//            corner can colour a tile pixel becomes a record {ox, oy, dblError, index} in LDS, threaded into the
+//            per-pixel lists at once;
+//   then     exactly k_tiles: degrid (:525-568) in LDS, colours by point index, z-tested gather in registers
+//            (:586-669), normalise (:686), hole mask (:253), uint8 (:255), coalesced stores.
+// A halo pixel's z is the minimum over the points whose WINNER corner it is; those have their north-west corner
+// within one more pixel, hence the two-pixel reach of the splat.  Neighbouring tiles project the blocks they share
+// again (~2.3 tiles per block of an 8 x 8 patch): arithmetic that replaces 16-byte records written to and read back
+// from HBM, the 4-byte z-buffer's atomics, its reset, and a kernel boundary.
+// More than REC_CAP records on a tile (piled-up points, a cloud denser than the raster): the z-buffer is finished
+// first, then the candidates are taken again in runs that fit (their record counts were noted on the first pass).
+// More candidate blocks than the LDS list holds (MAXC: > 32 k points on one tile): the tile scans block ranges
+// instead of a list, testing each block's node inline.  Slow paths, but any cloud renders correctly.
+// ---------------------------------------------------------------------------------------
+constexpr int MAXC = 512;                   // candidate blocks a tile lists in LDS at once
+constexpr int UNIT_BATCH = 6;               // candidate blocks whose coordinates a wave loads before it works on them
+static_assert(MAXC % TILE_THREADS == 0 && MAXC / TILE_THREADS == 2, "the prefix scan of the slow path takes two entries per thread");
+
+struct FrameArgs {
+    PackedCloud pc;
+    Camera cam;
+    int tiles_x, tiles_y;
+    uint8_t* frame;         // [H,W,3]
+    float* depth;           // [H*W]
+    uint32_t* mask;         // [H][ceil(W/32)]
+    int* holes;
+    int* hole_count;
+    int4* bbox;
+    uint32_t* coarse;
+    float* render;          // optional [4,H,W] (unfilled; the fill kernel patches the holes)
+    float* existing;        // optional [H*W]
+    float* zee;             // optional [H*W] degridded z-buffer
+    float* zee_pre;         // optional [H*W] pre-degrid z-buffer
+};
+
+struct FrameLds {
+    TileLds T;
+    int list[2][MAXC];      // node ids of the level being expanded / the candidate blocks
+    int cnt[MAXC];          // records each candidate contributes (slow path: prefix sums)
+    int n_at[kCloudMaxLevels];      // survivors per level
+    int overflow;           // some level had more than MAXC survivors
+    int wave_sum[TILE_THREADS / 64];
+    int run_end;
+};
+
+struct CullView {           // the view, as the node tests need it
+    float g, Sx, Sy;        // F' / Fd, shift_x * Fd, shift_y * Fd
+    float focal, sx, sy, sz;
+    float rx0, rx1, ry0, ry1;       // the tile's reach in (image position - principal point): [x0 - 2, x0 + TW + 1) etc.
+};
+
+// can a point of this node have its north-west corner within the tile's reach?  Conservative: the projection is
+// monotone in each box coordinate (kbe_cloud.h), so the box corners bound it; a pixel of slack covers the rounding
+// of these few operations and of the exact projection.
+__device__ __forceinline__ bool node_hits(const CloudNode& n, const CullView& q)
+{
+    bool hit = false;
+    if (n.flags & 1u) {
+        const float d0 = n.z0 + q.sz, d1 = n.z1 + q.sz;
+        if (d1 >= 0.001f) {                                     // else: all behind the near plane (common.py:453)
+            if (d0 < 0.001f) {
+                hit = true;                                     // straddles it: no bound
+            } else {
+                const float t0 = q.g * __builtin_amdgcn_rcpf(d0), t1 = q.g * __builtin_amdgcn_rcpf(d1);
+                const float xa = __builtin_fmaf(n.px0, n.z0, q.Sx) * t0, xb = __builtin_fmaf(n.px1, n.z0, q.Sx) * t0;
+                const float xc = __builtin_fmaf(n.px0, n.z1, q.Sx) * t1, xd = __builtin_fmaf(n.px1, n.z1, q.Sx) * t1;
+                const float ya = __builtin_fmaf(n.py0, n.z0, q.Sy) * t0, yb = __builtin_fmaf(n.py1, n.z0, q.Sy) * t0;
+                const float yc = __builtin_fmaf(n.py0, n.z1, q.Sy) * t1, yd = __builtin_fmaf(n.py1, n.z1, q.Sy) * t1;
+                const float xlo = fminf(fminf(xa, xb), fminf(xc, xd)), xhi = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+                const float ylo = fminf(fminf(ya, yb), fminf(yc, yd)), yhi = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+                const float mx = 1.0f + 1.0e-4f * fmaxf(fabsf(xlo), fabsf(xhi)), my = 1.0f + 1.0e-4f * fmaxf(fabsf(ylo), fabsf(yhi));
+                hit = (xhi + mx >= q.rx0) & (xlo - mx < q.rx1) & (yhi + my >= q.ry0) & (ylo - my < q.ry1);
+            }
+        }
+    }
+    if (!hit && (n.flags & 2u)) {
+        const float d0 = n.Z0 + q.sz, d1 = n.Z1 + q.sz;
+        if (d1 >= 0.001f) {
+            if (d0 < 0.001f) {
+                hit = true;
+            } else {
+                const float t0 = q.focal * __builtin_amdgcn_rcpf(d0), t1 = q.focal * __builtin_amdgcn_rcpf(d1);
+                const float x0 = n.X0 + q.sx, x1 = n.X1 + q.sx, y0 = n.Y0 + q.sy, y1 = n.Y1 + q.sy;
+                const float xlo = fminf(fminf(x0 * t0, x0 * t1), fminf(x1 * t0, x1 * t1)), xhi = fmaxf(fmaxf(x0 * t0, x0 * t1), fmaxf(x1 * t0, x1 * t1));
+                const float ylo = fminf(fminf(y0 * t0, y0 * t1), fminf(y1 * t0, y1 * t1)), yhi = fmaxf(fmaxf(y0 * t0, y0 * t1), fmaxf(y1 * t0, y1 * t1));
+                const float mx = 1.0f + 1.0e-4f * fmaxf(fabsf(xlo), fabsf(xhi)), my = 1.0f + 1.0e-4f * fmaxf(fabsf(ylo), fabsf(yhi));
+                hit = (xhi + mx >= q.rx0) & (xlo - mx < q.rx1) & (yhi + my >= q.ry0) & (ylo - my < q.ry1);
+            }
+        }
+    }
+    return hit;
+}
+
+__device__ __forceinline__ float4 fetch_rgbd(const FrameArgs& a, int id)
+{
+    const uint32_t off = (uint32_t) id << 2;
+    const char* r = (const char*) a.pc.rgb;
+    const char* g = (const char*) (a.pc.rgb + (size_t) a.pc.Np);
+    const char* b = (const char*) (a.pc.rgb + 2 * (size_t) a.pc.Np);
+    const char* d = (const char*) a.pc.depth;
+    return make_float4(*(const float*) (r + off), *(const float*) (g + off), *(const float*) (b + off), *(const float*) (d + off));
+}
+
+// what a pass over candidate blocks does with each point
+enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4 };
+
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_frame(FrameArgs a)
+{
+    __shared__ FrameLds F;
+    TileLds& L = F.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int W = a.cam.W, H = a.cam.H;
+    const Camera& cam = a.cam;
+    const PackedCloud& pc = a.pc;
+    uint32_t* const zk = (uint32_t*) L.zpre;            // the tile's z-buffer as keys until the splat is complete
+
+    CullView q;
+    q.g = cam.focal_f / pc.fd;
+    q.sx = cam.has_shift ? cam.sx : 0.0f; q.sy = cam.has_shift ? cam.sy : 0.0f; q.sz = cam.has_shift ? cam.sz : 0.0f;
+    q.Sx = q.sx * pc.fd; q.Sy = q.sy * pc.fd;
+    q.focal = cam.focal_f;
+    q.rx0 = (float) (x0 - 2) - cam.cx_f; q.rx1 = (float) (x0 + TW + 1) - cam.cx_f;
+    q.ry0 = (float) (y0 - 2) - cam.cy_f; q.ry1 = (float) (y0 + TH + 1) - cam.cy_f;
+
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+    for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
+    if (tid < kCloudMaxLevels) F.n_at[tid] = 0;
+    if (tid == 0) {
+        L.nrec = 0;
+        F.overflow = 0;
+        lds_dummy_record(L);
+    }
+    __syncthreads();
+
+    // ---- cull: top level, then level by level down to the blocks
+    auto append = [&](int* list, int* counter, bool hit, int id) {
+        const unsigned long long m = __ballot(hit);
+        if (m) {                                                // wave-uniform
+            int base = 0;
+            const int leader = __ffsll((long long) m) - 1;
+            if (lane == leader) base = atomicAdd(counter, __popcll(m));
+            base = __builtin_amdgcn_readlane(base, leader);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit) {
+                if (pos < MAXC) list[pos] = id;
+                else F.overflow = 1;
+            }
+        }
+    };
+    const int top = pc.n_levels - 1;
+    int cur = 0;
+    for (int n0 = 0; n0 < pc.count[top]; n0 += TILE_THREADS) {
+        const int n = n0 + tid;
+        const bool hit = n < pc.count[top] && node_hits(pc.level[top][n], q);
+        append(F.list[0], &F.n_at[top], hit, n);
+    }
+    __syncthreads();
+    for (int lvl = top - 1; lvl >= 0 && !F.overflow; lvl--) {
+        const int items = min(F.n_at[lvl + 1], MAXC) * kCloudFan;
+        for (int it0 = 0; it0 < items; it0 += TILE_THREADS) {
+            const int it = it0 + tid;
+            int child = 0;
+            bool hit = false;
+            if (it < items) {
+                child = F.list[cur][it / kCloudFan] * kCloudFan + (it % kCloudFan);
+                hit = child < pc.count[lvl] && node_hits(pc.level[lvl][child], q);
+            }
+            append(F.list[cur ^ 1], &F.n_at[lvl], hit, child);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    const bool ranged = F.overflow != 0;                        // uniform: scan block ranges instead of a list
+    const int n_blocks = pc.count[0];
+    const int* const cand = F.list[cur];
+
+    // ---- one pass over candidates [c0, c1) of the window starting at block `wbase` (list mode: wbase unused)
+    // Per point: PASS_Z min-splats its dblError; PASS_COUNT notes how many records the block contributes;
+    // PASS_INSERT threads its record into the lists while there is room (slots >= REC_CAP are dropped: the
+    // caller then knows from the total that the tile needs the slow path).
+    auto pass = [&](int flags, int c0, int c1, int wbase) {
+        for (int cb = c0 + wave; cb < c1; cb += (TILE_THREADS / 64) * UNIT_BATCH) {
+            float xs[UNIT_BATCH], ys[UNIT_BATCH], zs[UNIT_BATCH];
+            int blk[UNIT_BATCH];
+            // coordinates of the whole batch first: the loads of up to UNIT_BATCH blocks are in flight together
+#pragma unroll
+            for (int u = 0; u < UNIT_BATCH; u++) {
+                const int c = cb + u * (TILE_THREADS / 64);
+                int b = -1;
+                if (c < c1) {                                   // wave-uniform
+                    if (!ranged) b = cand[c];
+                    else { b = wbase + c; if (b >= n_blocks || !node_hits(pc.level[0][b], q)) b = -1; }
+                }
+                blk[u] = b;
+                const uint32_t off = (uint32_t) ((b < 0 ? 0 : b) * kCloudBlock + lane) << 2;       // Np <= 2^30: 32-bit byte offsets
+                xs[u] = *(const float*) ((const char*) pc.xyz + off);
+                ys[u] = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
+                zs[u] = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
+            }
+#pragma unroll
+            for (int u = 0; u < UNIT_BATCH; u++) {
+                const int c = cb + u * (TILE_THREADS / 64);
+                if (c >= c1) break;                             // wave-uniform
+                if (blk[u] < 0) { if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = 0; continue; }
+                float x = xs[u], y = ys[u], z = zs[u], ox = 0.0f, oy = 0.0f;
+                apply_shift(cam, x, y, z);
+                const bool ok = project_xy(cam, x, y, z, ox, oy);
+                Proj p;
+                p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
+                const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
+                // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
+                const bool in_z = ok && ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
+                // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
+                const bool in_r = in_z && ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &&
+                                  ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H);
+                float err = 0.0f;
+                if (in_z) {
+                    err = project_err_fast(cam, z);
+                    if (flags & PASS_Z) {
+                        project_weights(ox, oy, p);
+                        const int k = winner_corner(p);                             // common.py:486-506
+                        if (k >= 0) {
+                            const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+                            const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
+                            if (inside(cx, cy, W, H) && ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
+                                atomicMin(&zk[__mul24(ly, KW) + lx], zkey_encode(err));
+                        }
+                    }
+                }
+                if (flags & (PASS_COUNT | PASS_INSERT)) {
+                    const unsigned long long m = __ballot(in_r);
+                    const int n_r = __popcll(m);
+                    if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = n_r;
+                    if ((flags & PASS_INSERT) && m) {           // wave-uniform
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&L.nrec, n_r);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (in_r && slot < REC_CAP) {
+                            const int next = atomicExch(&L.head[__mul24(ry - 1, BW) + (rx - 1)], slot << 4);
+                            L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
+                            L.rgbd[slot].x = __int_as_float(blk[u] * kCloudBlock + lane);          // the point, until its colours arrive
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
+    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
+    // keys -> floats in place (a pixel outside the image was never splatted: it reads 1e6 like common.py:430), and the
+    // one decision per tile whether the fp32-only degrid and z test apply
+    auto decode_z = [&]() {
+        bool band = true;
+#pragma unroll
+        for (int u = 0; u < ZPER; u++) {
+            const int i = tid + u * TILE_THREADS;
+            if (i < KH * KW) {
+                const float z = zkey_decode(zk[i]);
+                L.zpre[i] = z;
+                band = band && degrid_fast_ok(z);
+            }
+        }
+        const unsigned long long odd = __ballot(!band);
+        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
+    };
+    auto tile_is_fast = [&]() {
+        bool fast = true;
+#pragma unroll
+        for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
+        return (bool) __builtin_amdgcn_readfirstlane((int) fast);
+    };
+
+    PixAcc acc[PIX_PER_THREAD];
+#pragma unroll
+    for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
+
+    const int n_cand = ranged ? 0 : min(F.n_at[0], MAXC);
+    if (!ranged) pass(PASS_Z | PASS_COUNT | PASS_INSERT, 0, n_cand, 0);
+    else for (int wb = 0; wb < n_blocks; wb += MAXC) pass(PASS_Z, 0, min(MAXC, n_blocks - wb), wb);
+    __syncthreads();
+    const int total = L.nrec;
+    bool fast;
+    if (!ranged && total <= REC_CAP) {
+        // ---- the normal path: everything is in LDS.  Colours by point index now (in flight during the degrid)
+        float4 cc[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = tid + u * TILE_THREADS;
+            cc[u] = fetch_rgbd(a, i < total ? __float_as_int(L.rgbd[i].x) : 0);
+        }
+        decode_z();
+        __syncthreads();
+        fast = tile_is_fast();
+        tile_degrid(a, L, tid, x0, y0, fast);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = tid + u * TILE_THREADS;
+            if (i < total) L.rgbd[i] = cc[u];
+        }
+        __syncthreads();
+        if (fast) gather<true>(a, L, tid, x0, y0, acc);
+        else gather<false>(a, L, tid, x0, y0, acc);
+    } else {
+        // ---- the slow path: the z-buffer is complete; take the candidates again in runs of at most REC_CAP records
+        decode_z();
+        __syncthreads();
+        fast = tile_is_fast();
+        tile_degrid(a, L, tid, x0, y0, fast);
+        for (int wb = 0; wb < (ranged ? n_blocks : 1); wb += MAXC) {
+            const int n_win = ranged ? min(MAXC, n_blocks - wb) : n_cand;
+            __syncthreads();
+            if (ranged) { pass(PASS_COUNT, 0, n_win, wb); __syncthreads(); }
+            // inclusive prefix sums of the counts, two entries per thread
+            {
+                const int e0 = 2 * tid < n_win ? F.cnt[2 * tid] : 0, e1 = 2 * tid + 1 < n_win ? F.cnt[2 * tid + 1] : 0;
+                int v = e0 + e1;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
+                if (lane == 63) F.wave_sum[tid >> 6] = v;
+                __syncthreads();
+                int before = 0;
+                for (int w = 0; w < (tid >> 6); w++) before += F.wave_sum[w];
+                v += before;
+                __syncthreads();
+                if (2 * tid < n_win) F.cnt[2 * tid] = v - e1;
+                if (2 * tid + 1 < n_win) F.cnt[2 * tid + 1] = v;
+            }
+            int c0 = 0, done = 0;                               // candidates before c0 are rendered; they held `done` records
+            while (c0 < n_win) {                                // uniform
+                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+                if (tid == 0) { L.nrec = 0; F.run_end = n_win; }
+                __syncthreads();
+                // the run ends in front of the first candidate whose prefix sum exceeds done + REC_CAP
+                for (int c = c0 + tid; c < n_win; c += TILE_THREADS)
+                    if (F.cnt[c] - done > REC_CAP && (c == c0 || F.cnt[c - 1] - done <= REC_CAP)) F.run_end = c;
+                __syncthreads();
+                const int c1 = F.run_end;
+                pass(PASS_INSERT, c0, c1, wb);
+                __syncthreads();
+                const int n = L.nrec;
+                for (int i = tid; i < n; i += TILE_THREADS) L.rgbd[i] = fetch_rgbd(a, __float_as_int(L.rgbd[i].x));
+                __syncthreads();
+                if (fast) gather<true>(a, L, tid, x0, y0, acc);
+                else gather<false>(a, L, tid, x0, y0, acc);
+                __syncthreads();
+                done = F.cnt[c1 - 1];
+                c0 = c1;
+            }
+        }
+    }
+    tile_epilogue(a, L, acc, tile, x0, y0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1110,20 +1498,26 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
 #ifndef KBE_FILL_BLOCK
 #define KBE_FILL_BLOCK 256
 #endif
+#ifndef KBE_FILL_MAX_BLOCKS
+#define KBE_FILL_MAX_BLOCKS 2048
+#endif
 __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
                                                     const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
                                                     FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
                                                     const int4* __restrict__ bbox, int fill_mode, const uint32_t* __restrict__ coarse,
-                                                    int tiles_x, int tiles_y)
+                                                    int tiles_x, int tiles_y, int reset_scatter_scratch, int* __restrict__ next_hole_count)
 {
-    // leave the scratch ready for the next frame: empty z-buffer, empty buckets
-    {
+    // leave the scratch ready for the next frame.  Bucket path: empty z-buffer, empty buckets.  Fused path: it has
+    // neither; its hole counters alternate between frames, and this launch zeroes the one the NEXT frame will count in
+    // (nobody reads or writes that one while this launch runs).
+    if (reset_scatter_scratch) {
         const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
         for (int i = gtid; i < W * H; i += gsz) zkeys[i] = KBE_ZKEY_EMPTY;
         for (int i = gtid; i < n_tiles; i += gsz) tile_count[i * CNT_STRIDE] = 0;
     }
+    if (next_hole_count && blockIdx.x == 0 && threadIdx.x == 0) *next_hole_count = 0;
     const int n = min(*hole_count, W * H);
     // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
@@ -1440,9 +1834,6 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     }
     if (stages & KBE_STAGE_FILL) {
         const size_t hw = (size_t) W * H;
-#ifndef KBE_FILL_MAX_BLOCKS
-#define KBE_FILL_MAX_BLOCKS 2048
-#endif
         const size_t want_fill = hw / 64, max_fill = (size_t) KBE_FILL_MAX_BLOCKS * 256 / KBE_FILL_BLOCK;       // the same number of threads
         const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
@@ -1450,7 +1841,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
                            (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y);
+                           sc.coarse, sc.tiles_x, sc.tiles_y, 1, (int*) nullptr);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -1463,6 +1854,51 @@ int kbe_render_frame(const float* points, const float* image, const float* depth
     return kbe_render_frame_stages(points, image, depth, N, W, H, focal, baseline, shift3, scratch, frame_u8, render_f32,
                                    existing_f32, zee_f32, zee_pre_f32, KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL,
                                    nullptr, 0, 0, stream);
+}
+
+int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W, int H, double focal, double baseline,
+                           const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32, float* existing_f32,
+                           float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect, int parity, kbe_stream_t stream)
+{
+    KBE_REQUIRE(packed && scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
+                W < (1 << 24) && H < (1 << 24) && ((uintptr_t) scratch & 15) == 0 && cloud_focal > 0.0 && parity >= -1 && parity <= 1,
+                "kbe_render_frame_fused: bad arguments");
+    static const FillDirs dirs = make_fill_dirs();
+    const hipStream_t s = (hipStream_t) stream;
+    const Scratch sc = carve(scratch, W, H);
+    const Camera cam = make_camera(W, H, focal, baseline, shift3);
+    const int n_tiles = sc.tiles_x * sc.tiles_y;
+    int* const count_now = sc.hole_count + (parity == 1 ? 1 : 0);
+    int* const count_next = sc.hole_count + (parity == 1 ? 0 : 1);
+    int rc = KBE_OK;
+    if (parity < 0 && !(stages & KBE_STAGE_KEEP_HOLE_COUNT)) {
+        // a frame on its own: the caller keeps no frame parity, so the hole counter is zeroed in front of the launch
+        const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 2 * sizeof(int), s);
+        if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_fused: hipMemsetAsync", e);
+    }
+    if (stages & KBE_STAGE_TILES) {
+        FrameArgs a;
+        a.pc = cloud_open(packed, N, cloud_focal);
+        a.cam = cam;
+        a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+        a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = count_now; a.bbox = sc.bbox; a.coarse = sc.coarse;
+        a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
+        hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
+        if ((rc = launched("kbe_render_frame_fused/scatter"))) return rc;
+    }
+    if (stages & KBE_STAGE_FILL) {
+        const size_t hw = (size_t) W * H;
+        const size_t want_fill = hw / 64, max_fill = (size_t) KBE_FILL_MAX_BLOCKS * 256 / KBE_FILL_BLOCK;
+        const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
+        FillRect rect = { 0, 0, W - 1, H - 1 };
+        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, count_now, sc.depth, sc.mask, W, H, dirs, rect,
+                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
+                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
+                           sc.coarse, sc.tiles_x, sc.tiles_y, 0, parity >= 0 ? count_next : (int*) nullptr);
+        rc = launched("kbe_render_frame_fused/fill");
+    }
+    return rc;
 }
 
 int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
@@ -1494,10 +1930,11 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
 constexpr int KBE_VIDEO_STAGES = KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL;
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
-                     uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, kbe_stream_t stream,
-                     kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams)
+                     uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, const void* packed,
+                     double cloud_focal, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams)
 {
-    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64, "kbe_render_video: bad arguments");
+    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64 && (!packed || cloud_focal > 0.0),
+                "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
     KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
     const hipStream_t cs = (hipStream_t) stream;
@@ -1558,6 +1995,13 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         const hipError_t e = hipMemsetAsync(stage + ctl_offset, 0, sizeof(DeliverCtl), cs);
         if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
     }
+    if (packed) {
+        // every lane starts the call on hole counter 0: both of its counters are zeroed here, on `stream`, before the lanes start
+        for (int l = 0; l < lanes; l++) {
+            const hipError_t e = hipMemsetAsync(carve((char*) scratch + (size_t) l * sb, W, H).hole_count, 0, 2 * sizeof(int), cs);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
+        }
+    }
     hipEvent_t start = lanes > 1 || (ringed && ds[0] != cs) ? make() : nullptr;
     // the other streams start once everything enqueued on `stream` so far (the cloud) is done
     if (start && ok) {
@@ -1565,12 +2009,20 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         for (int l = 1; l < lanes; l++) (void) hipStreamWaitEvent(ls[l], start, 0);
         if (ringed && ds[0] != cs) (void) hipStreamWaitEvent(ds[0], start, 0);
     }
+    int lane_frames[KBE_MAX_LANES] = {};
     auto render = [&](int i, int l, uint8_t* out) {
         uint8_t* raw = stage + (size_t) l * fb;
-        int rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
+        const int fill_flags = lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0;
+        int rc;
+        if (packed)         // the fused scatter on the packed cloud; a lane's frames alternate between its two hole counters
+            rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
+                                        (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
+                                        KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags, crop ? rect : nullptr, lane_frames[l]++ & 1,
+                                        (kbe_stream_t) ls[l]);
+        else
+            rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_VIDEO_STAGES | (lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0),
-                                         crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
+                                         KBE_VIDEO_STAGES | fill_flags, crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
         return rc;
     };

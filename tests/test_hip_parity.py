@@ -363,6 +363,52 @@ def test_render_frame_is_repeatable_and_order_independent(K):
     assert (a.int() - cc.int()).abs().max() <= 1 and float((a != cc).float().mean()) < 1e-3
 
 
+def _grown_scene(size, seed, dolly=False, kind='smooth'):
+    """A scene whose cloud has an appended tail like process_inpaint's (common.py:69-80): pixels of a displaced view,
+    in that view's raster order, only where a mask says so."""
+    settings, oc = _scene(size, seed, kind, dolly)
+    gen = torch.Generator('cuda').manual_seed(seed)
+    H, W = size
+    n = H * W
+    pick = torch.nonzero(torch.rand(n, device='cuda', generator=gen) < 0.08).view(-1)
+    pts = oc['tensorInpaPoints'][:, :, pick].clone()
+    pts[:, 2] *= 1.0 + 0.3 * torch.rand(pick.numel(), device='cuda', generator=gen)          # behind the surface they came from
+    pts[:, 0] += 25.0
+    pts[:, 1] -= 11.0
+    oc['tensorInpaPoints'] = torch.cat([oc['tensorInpaPoints'], pts], 2)
+    oc['tensorInpaImage'] = torch.cat([oc['tensorInpaImage'], torch.rand(1, 3, pick.numel(), device='cuda', generator=gen)], 2)
+    oc['tensorInpaDepth'] = torch.cat([oc['tensorInpaDepth'], pts[:, 2:3]], 2)
+    return settings, oc
+
+
+@pytest.mark.parametrize('size,dolly,kind', [((96, 128), False, 'smooth'), ((200, 312), False, 'noise'), ((256, 256), True, 'smooth'),
+                                             ((37, 50), False, 'smooth'), ((512, 512), False, 'smooth')])
+def test_fused_scatter_equals_the_bucket_path(K, size, dolly, kind):
+    """The one-launch scatter on the packed cloud (a tile pulls its points through the box hierarchy, z-buffer in LDS)
+    against round 1's k_project + k_tiles (global z-buffer, bucket records): z-buffers before and after the degrid
+    bit for bit, the same holes, frames within the accumulation order."""
+    from ken_burns_effect_amd import common
+    settings, oc = _grown_scene(size, 13, dolly, kind)
+    H, W = size
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, 512.0)
+    assert state['fused'] and state['packed'].numel() > 28 * state['N']
+    for focal, shift3 in common.frame_cameras(dict(settings, dblSteps=[0.0, 0.35, 1.0]), oc):
+        outs = []
+        for fused in (True, False):
+            rf, ex = torch.empty(4, H, W, device='cuda'), torch.empty(H * W, device='cuda')
+            zd, zp = torch.empty_like(ex), torch.empty_like(ex)
+            f = K.render_frame(state, shift3, focal, 120, render_f32=rf, existing_f32=ex, zee_f32=zd, zee_pre_f32=zp, fused=fused).clone()
+            outs.append((c(f), c(rf), c(ex), c(zd), c(zp)))
+        a, b = outs
+        assert_bits_equal(a[4], b[4], 'z-buffer before the degrid')
+        assert_bits_equal(a[3], b[3], 'z-buffer after the degrid')
+        assert np.array_equal(a[2] > 0, b[2] > 0), 'same pixels covered'
+        assert np.abs(a[2] - b[2]).max() <= 1e-4 * max(1.0, float(b[2].max()))
+        d = np.abs(a[0].astype(np.int32) - b[0].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        assert psnr(a[1][:3], b[1][:3], 1.0) > 100.0
+
+
 def test_tiled_frame_equals_generic_stages(K):
     """The tile renderer against the stage-by-stage global-atomic path (two independent HIP implementations)."""
     settings, oc = _scene((300, 420), 6)           # sizes that are not multiples of the tile or of 4
