@@ -12,8 +12,8 @@
 //     ordinary points (the projection (p z + s Fd) F' / ((z + sz) Fd) is monotone in p and in z, so the four corners
 //     of the box bound it), and an {x, y, z} box for degenerate points (z < 1, masked points at the origin, points
 //     behind the camera);
-//   * levels of nodes over 32 children each, up to a top level of at most 512 nodes, so that a tile finds its
-//     ~20 candidate blocks among 18 k (1024^2) with ~3 node tests per thread.
+//   * levels of nodes over 32 children each, up to a top level of at most 64 nodes, so that a tile finds its
+//     ~28 candidate blocks among 18 k (1024^2) with four wave-wide rounds of node tests.
 // Nothing of this changes a result: every point a tile's pixels can see passes the (conservative) node tests, and a
 // point that passes without landing in the tile is dropped by the exact projection.
 #pragma once
@@ -24,8 +24,8 @@ namespace kbe {
 
 constexpr int kCloudBlock = 64;         // points per block (one per lane)
 constexpr int kCloudFan = 32;           // children per node
-constexpr int kCloudTopMax = 512;       // nodes of the top level at most
-constexpr int kCloudMaxLevels = 5;      // 512 * 32^4 blocks: far beyond the 2^30-point limit of the frame loop
+constexpr int kCloudTopMax = 64;        // nodes of the top level at most (one wave tests them in one go)
+constexpr int kCloudMaxLevels = 6;      // 64 * 32^5 blocks: far beyond the 2^30-point limit of the frame loop
 
 struct CloudNode {                      // 64 bytes
     float px0, px1, py0, py1, z0, z1;   // ordinary points: p = coordinate * Fd / z (pixels from the principal point), and z

@@ -30,6 +30,7 @@
 // is the out-of-place schedule, accumulation order is bucket order (not point order).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -824,9 +825,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 // More candidate blocks than the LDS list holds (MAXC: > 32 k points on one tile): the tile scans block ranges
 // instead of a list, testing each block's node inline.  Slow paths, but any cloud renders correctly.
 // ---------------------------------------------------------------------------------------
-constexpr int MAXC = 512;                   // candidate blocks a tile lists in LDS at once
-constexpr int UNIT_BATCH = 6;               // candidate blocks whose coordinates a wave loads before it works on them
-static_assert(MAXC % TILE_THREADS == 0 && MAXC / TILE_THREADS == 2, "the prefix scan of the slow path takes two entries per thread");
+constexpr int MAXC = 256;                   // candidate blocks a tile lists in LDS at once
+constexpr int RING = 128;                   // a wave's ring of waiting points: at most 63 left over + 64 new
+static_assert(MAXC == TILE_THREADS, "one candidate per thread in the prefix scan of the slow path");
 
 struct FrameArgs {
     PackedCloud pc;
@@ -843,6 +844,7 @@ struct FrameArgs {
     float* existing;        // optional [H*W]
     float* zee;             // optional [H*W] degridded z-buffer
     float* zee_pre;         // optional [H*W] pre-degrid z-buffer
+    float4* spill;          // [n_tiles][BUCKET_STRIDE]: where a tile's records beyond REC_CAP wait for their round
 };
 
 struct FrameLds {
@@ -851,6 +853,8 @@ struct FrameLds {
     int cnt[MAXC];          // records each candidate contributes (slow path: prefix sums)
     int n_at[kCloudMaxLevels];      // survivors per level
     int overflow;           // some level had more than MAXC survivors
+    int n_ovf;              // records that did not fit the first round and went to the tile's spill area
+    int ring[TILE_THREADS / 64][RING];      // per wave: indices of the points waiting for the exact work
     int wave_sum[TILE_THREADS / 64];
     int run_end;
 };
@@ -905,6 +909,9 @@ __device__ __forceinline__ bool node_hits(const CloudNode& n, const CullView& q)
 
 __device__ __forceinline__ float4 fetch_rgbd(const FrameArgs& a, int id)
 {
+#if defined(KBE_FRAME_STOP) && defined(KBE_FRAME_NO_RGBD)       // (dev) what do the colour loads cost?
+    return make_float4(0.5f, 0.25f, 0.125f, 700.0f + (float) (id & 1));
+#endif
     const uint32_t off = (uint32_t) id << 2;
     const char* r = (const char*) a.pc.rgb;
     const char* g = (const char*) (a.pc.rgb + (size_t) a.pc.Np);
@@ -914,7 +921,16 @@ __device__ __forceinline__ float4 fetch_rgbd(const FrameArgs& a, int id)
 }
 
 // what a pass over candidate blocks does with each point
-enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4 };
+enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4, PASS_SPILL = 8 };
+
+#if defined(KBE_FRAME_STATS)     // dev build only (tools/frame_stats.py): what the tiles of k_frame did, summed over launches
+__device__ unsigned long long g_frame_stats[8];     // tiles, top-level survivors, candidate blocks, points in z reach, records, slow tiles, ranged tiles
+#endif
+#if defined(KBE_FRAME_STOP)      // dev build only (tools/gpu_variant_pmc.sh): the kernel ends after stage KBE_FRAME_STOP, to cost the stages
+#define KBE_STOP_AFTER(n) do { if (KBE_FRAME_STOP == (n)) return; } while (0)
+#else
+#define KBE_STOP_AFTER(n) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_frame(FrameArgs a)
 {
@@ -944,6 +960,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
     if (tid == 0) {
         L.nrec = 0;
         F.overflow = 0;
+        F.n_ovf = 0;
         lds_dummy_record(L);
     }
     __syncthreads();
@@ -986,80 +1003,100 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         cur ^= 1;
         __syncthreads();
     }
+    KBE_STOP_AFTER(1);                                          // (dev) the cull
     const bool ranged = F.overflow != 0;                        // uniform: scan block ranges instead of a list
     const int n_blocks = pc.count[0];
     const int* const cand = F.list[cur];
 
-    // ---- one pass over candidates [c0, c1) of the window starting at block `wbase` (list mode: wbase unused)
-    // Per point: PASS_Z min-splats its dblError; PASS_COUNT notes how many records the block contributes;
-    // PASS_INSERT threads its record into the lists while there is room (slots >= REC_CAP are dropped: the
-    // caller then knows from the total that the tile needs the slow path).
+    // ---- the exact work on one point per lane: shift (common.py:104-109), projection (:447-468), then by `flags`
+    // PASS_Z the min-splat of its dblError on the winner corner (:470-506), PASS_COUNT how many of the wave's points
+    // become records (noted for candidate `c`), PASS_INSERT its record threaded into the per-pixel lists while there
+    // is room (slots >= REC_CAP are dropped: the caller then knows from the total that the tile needs the slow path).
+    auto exact_point = [&](int flags, float x, float y, float z, bool valid, int idx, int c, float4* spill) {
+        float ox = 0.0f, oy = 0.0f;
+        apply_shift(cam, x, y, z);
+        const bool ok = project_xy(cam, x, y, z, ox, oy) && valid;
+        Proj p;
+        p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
+        const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
+        // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
+        const bool in_z = ok && ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
+        // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
+        const bool in_r = in_z && ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &&
+                          ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H);
+        float err = 0.0f;
+#if defined(KBE_FRAME_STATS)
+        { const unsigned long long mz = __ballot(in_z); if (lane == 0 && (flags & PASS_Z)) atomicAdd(&g_frame_stats[3], (unsigned long long) __popcll(mz)); }
+#endif
+        if (in_z) {
+            err = project_err_fast(cam, z);
+            if (flags & PASS_Z) {
+                project_weights(ox, oy, p);
+                const int k = winner_corner(p);                                     // common.py:486-506
+                if (k >= 0) {
+                    const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+                    const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
+                    if (inside(cx, cy, W, H) && ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
+                        atomicMin(&zk[__mul24(ly, KW) + lx], zkey_encode(err));
+                }
+            }
+        }
+        if (flags & (PASS_COUNT | PASS_INSERT)) {
+            const unsigned long long m = __ballot(in_r);
+            const int n_r = __popcll(m);
+            if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = n_r;
+            if ((flags & PASS_INSERT) && m) {                   // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.nrec, n_r);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in_r && slot < REC_CAP) {
+                    const int next = atomicExch(&L.head[__mul24(ry - 1, BW) + (rx - 1)], slot << 4);
+                    L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
+                    L.rgbd[slot].x = __int_as_float(idx);                           // the point, until its colours arrive
+                }
+                if ((flags & PASS_SPILL) && base + n_r > REC_CAP) {                 // wave-uniform; a few tiles in a hundred
+                    const bool sp = in_r && slot >= REC_CAP;
+                    const unsigned long long ms = __ballot(sp);
+                    int sbase = 0;
+                    if (lane == 0) sbase = atomicAdd(&F.n_ovf, __popcll(ms));
+                    sbase = __builtin_amdgcn_readfirstlane(sbase);
+                    const int o = sbase + __popcll(ms & ((1ull << lane) - 1ull));
+                    if (sp && o < BUCKET_CAP) spill[o] = make_float4(ox, oy, err, __int_as_float(idx));
+                }
+            }
+        }
+    };
+
+    constexpr int WAVES = TILE_THREADS / 64;
+    auto load_block = [&](int b, float& x, float& y, float& z) {
+        const uint32_t off = (uint32_t) ((b < 0 ? 0 : b) * kCloudBlock + lane) << 2;               // Np <= 2^30: 32-bit byte offsets
+        x = *(const float*) ((const char*) pc.xyz + off);
+        y = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
+        z = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
+    };
+
+    // ---- slow path only: one exact pass over candidates [c0, c1) of the window starting at block `wbase` (list mode:
+    // wbase unused).  A wave takes every fourth candidate; the coordinates of its next block are loaded before it
+    // works on the current one.
     auto pass = [&](int flags, int c0, int c1, int wbase) {
-        for (int cb = c0 + wave; cb < c1; cb += (TILE_THREADS / 64) * UNIT_BATCH) {
-            float xs[UNIT_BATCH], ys[UNIT_BATCH], zs[UNIT_BATCH];
-            int blk[UNIT_BATCH];
-            // coordinates of the whole batch first: the loads of up to UNIT_BATCH blocks are in flight together
-#pragma unroll
-            for (int u = 0; u < UNIT_BATCH; u++) {
-                const int c = cb + u * (TILE_THREADS / 64);
-                int b = -1;
-                if (c < c1) {                                   // wave-uniform
-                    if (!ranged) b = cand[c];
-                    else { b = wbase + c; if (b >= n_blocks || !node_hits(pc.level[0][b], q)) b = -1; }
-                }
-                blk[u] = b;
-                const uint32_t off = (uint32_t) ((b < 0 ? 0 : b) * kCloudBlock + lane) << 2;       // Np <= 2^30: 32-bit byte offsets
-                xs[u] = *(const float*) ((const char*) pc.xyz + off);
-                ys[u] = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
-                zs[u] = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
-            }
-#pragma unroll
-            for (int u = 0; u < UNIT_BATCH; u++) {
-                const int c = cb + u * (TILE_THREADS / 64);
-                if (c >= c1) break;                             // wave-uniform
-                if (blk[u] < 0) { if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = 0; continue; }
-                float x = xs[u], y = ys[u], z = zs[u], ox = 0.0f, oy = 0.0f;
-                apply_shift(cam, x, y, z);
-                const bool ok = project_xy(cam, x, y, z, ox, oy);
-                Proj p;
-                p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
-                const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
-                // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
-                const bool in_z = ok && ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
-                // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
-                const bool in_r = in_z && ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &&
-                                  ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H);
-                float err = 0.0f;
-                if (in_z) {
-                    err = project_err_fast(cam, z);
-                    if (flags & PASS_Z) {
-                        project_weights(ox, oy, p);
-                        const int k = winner_corner(p);                             // common.py:486-506
-                        if (k >= 0) {
-                            const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-                            const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
-                            if (inside(cx, cy, W, H) && ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
-                                atomicMin(&zk[__mul24(ly, KW) + lx], zkey_encode(err));
-                        }
-                    }
-                }
-                if (flags & (PASS_COUNT | PASS_INSERT)) {
-                    const unsigned long long m = __ballot(in_r);
-                    const int n_r = __popcll(m);
-                    if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = n_r;
-                    if ((flags & PASS_INSERT) && m) {           // wave-uniform
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&L.nrec, n_r);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                        if (in_r && slot < REC_CAP) {
-                            const int next = atomicExch(&L.head[__mul24(ry - 1, BW) + (rx - 1)], slot << 4);
-                            L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
-                            L.rgbd[slot].x = __int_as_float(blk[u] * kCloudBlock + lane);          // the point, until its colours arrive
-                        }
-                    }
-                }
-            }
+        auto block_of = [&](int c) -> int {                     // wave-uniform
+            if (c >= c1) return -1;
+            if (!ranged) return cand[c];
+            const int b = wbase + c;
+            return (b < n_blocks && node_hits(pc.level[0][b], q)) ? b : -1;
+        };
+        int c = c0 + wave;
+        int b_next = block_of(c);
+        float xn, yn, zn;
+        load_block(b_next, xn, yn, zn);
+        for (; c < c1; c += WAVES) {                            // wave-uniform
+            const int b = b_next;
+            const float x = xn, y = yn, z = zn;
+            b_next = block_of(c + WAVES);
+            load_block(b_next, xn, yn, zn);
+            if (b < 0) { if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = 0; continue; }
+            exact_point(flags, x, y, z, true, b * kCloudBlock + lane, c, nullptr);
         }
     };
 
@@ -1092,19 +1129,66 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
 
+    // ---- the normal path, a stream per wave with no workgroup barrier inside.  Every candidate point gets an
+    // APPROXIMATE position (one reciprocal, good to a thousandth of a pixel); two thirds of the candidates are near
+    // misses that belong to neighbouring tiles and end here, after ~20 instructions instead of ~130.  The points
+    // within a pixel of the tile's reach -- and every point nearer than z = 2, where process_shift's z / (z + 1e-7) is
+    // not exactly 1 and the approximation does not hold -- are pushed onto the wave's ring (their indices); whenever 64
+    // are waiting, the wave takes them off, reads their coordinates again (it has just read them: cache hits) and does
+    // the EXACT work with every lane busy: z-splat into the LDS z-tile, record into the per-pixel lists.  Records
+    // beyond REC_CAP (a few tiles in a hundred: two surfaces over one another at a depth edge) spill into the tile's
+    // own area of the scratch in HBM and are gathered in further rounds.
     const int n_cand = ranged ? 0 : min(F.n_at[0], MAXC);
-    if (!ranged) pass(PASS_Z | PASS_COUNT | PASS_INSERT, 0, n_cand, 0);
-    else for (int wb = 0; wb < n_blocks; wb += MAXC) pass(PASS_Z, 0, min(MAXC, n_blocks - wb), wb);
+    float4* const spill = a.spill + (size_t) tile * BUCKET_STRIDE;
+    if (!ranged) {
+        int* const ring = F.ring[wave];
+        int head = 0, tail = 0;                                 // wave-uniform
+        int c = wave;
+        int b_next = c < n_cand ? cand[c] : -1;
+        float xn, yn, zn;
+        load_block(b_next, xn, yn, zn);
+        const float wx = (float) (TW + 3) + 1.0f, wy = (float) (TH + 3) + 1.0f;
+        while (c < n_cand || tail > head) {                     // wave-uniform
+            if (c < n_cand) {
+                const int b = b_next;
+                const float x = xn, y = yn, z = zn;
+                c += WAVES;
+                b_next = c < n_cand ? cand[c] : -1;
+                load_block(b_next, xn, yn, zn);
+                const float zs = z + q.sz;
+                const float t = q.focal * __builtin_amdgcn_rcpf(zs);
+                const float ax = (x + q.sx) * t - q.rx0, ay = (y + q.sy) * t - q.ry0;      // position relative to the start of the reach
+                const bool take = (zs >= 0.0009f) && (!(z >= 2.0f) || ((ax >= -1.0f) & (ax < wx) & (ay >= -1.0f) & (ay < wy)));
+                const unsigned long long m = __ballot(take);
+                if (take) ring[(tail + __popcll(m & ((1ull << lane) - 1ull))) & (RING - 1)] = b * kCloudBlock + lane;
+                tail += __popcll(m);
+            }
+            if (tail - head >= 64 || (c >= n_cand && tail > head)) {
+                const int n = min(64, tail - head);
+                const bool valid = lane < n;
+                const int idx = valid ? ring[(head + lane) & (RING - 1)] : 0;
+                head += n;
+                const uint32_t off = (uint32_t) idx << 2;
+                const float x = *(const float*) ((const char*) pc.xyz + off);
+                const float y = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
+                const float z = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
+                exact_point(PASS_Z | PASS_INSERT | PASS_SPILL, x, y, valid ? z : 4.0f, valid, idx, 0, spill);
+            }
+        }
+    }
     __syncthreads();
+    KBE_STOP_AFTER(3);                                          // (dev) + the stream
     const int total = L.nrec;
     bool fast;
-    if (!ranged && total <= REC_CAP) {
-        // ---- the normal path: everything is in LDS.  Colours by point index now (in flight during the degrid)
+    const int n_spill = F.n_ovf;
+    if (!ranged && n_spill <= BUCKET_CAP) {
+        // ---- the first REC_CAP records are in LDS.  Colours by point index now (in flight during the degrid)
+        const int n_first = min(total, REC_CAP);
         float4 cc[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int i = tid + u * TILE_THREADS;
-            cc[u] = fetch_rgbd(a, i < total ? __float_as_int(L.rgbd[i].x) : 0);
+            cc[u] = fetch_rgbd(a, i < n_first ? __float_as_int(L.rgbd[i].x) : 0);
         }
         decode_z();
         __syncthreads();
@@ -1113,38 +1197,56 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int i = tid + u * TILE_THREADS;
-            if (i < total) L.rgbd[i] = cc[u];
+            if (i < n_first) L.rgbd[i] = cc[u];
         }
         __syncthreads();
+        KBE_STOP_AFTER(4);                                      // (dev) + colours, degrid
         if (fast) gather<true>(a, L, tid, x0, y0, acc);
         else gather<false>(a, L, tid, x0, y0, acc);
-    } else {
-        // ---- the slow path: the z-buffer is complete; take the candidates again in runs of at most REC_CAP records
-        decode_z();
-        __syncthreads();
-        fast = tile_is_fast();
-        tile_degrid(a, L, tid, x0, y0, fast);
-        for (int wb = 0; wb < (ranged ? n_blocks : 1); wb += MAXC) {
-            const int n_win = ranged ? min(MAXC, n_blocks - wb) : n_cand;
-            __syncthreads();
-            if (ranged) { pass(PASS_COUNT, 0, n_win, wb); __syncthreads(); }
-            // inclusive prefix sums of the counts, two entries per thread
-            {
-                const int e0 = 2 * tid < n_win ? F.cnt[2 * tid] : 0, e1 = 2 * tid + 1 < n_win ? F.cnt[2 * tid + 1] : 0;
-                int v = e0 + e1;
+        KBE_STOP_AFTER(5);                                      // (dev) + gather
+        // further rounds: the spilled records, REC_CAP at a time (already projected: only lists, colours and the walk)
+        for (int r0 = 0; r0 < n_spill; r0 += REC_CAP) {         // uniform
+            const int n = min(REC_CAP, n_spill - r0);
+            __syncthreads();                                    // the previous gather is done with the lists
+            for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+            float4 rr[PER];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
-                if (lane == 63) F.wave_sum[tid >> 6] = v;
-                __syncthreads();
-                int before = 0;
-                for (int w = 0; w < (tid >> 6); w++) before += F.wave_sum[w];
-                v += before;
-                __syncthreads();
-                if (2 * tid < n_win) F.cnt[2 * tid] = v - e1;
-                if (2 * tid + 1 < n_win) F.cnt[2 * tid + 1] = v;
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                rr[u] = i < n ? spill[r0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            int c0 = 0, done = 0;                               // candidates before c0 are rendered; they held `done` records
-            while (c0 < n_win) {                                // uniform
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                cc[u] = fetch_rgbd(a, i < n ? __float_as_int(rr[u].w) : 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                if (i < n) lds_insert(L, i, rr[u].x, rr[u].y, rr[u].z, cc[u], x0, y0);
+            }
+            __syncthreads();
+            if (fast) gather<true>(a, L, tid, x0, y0, acc);
+            else gather<false>(a, L, tid, x0, y0, acc);
+        }
+    } else {
+        // ---- the slow path, a small uniform state machine around ONE more copy of the pass: [ranged: the z-splat,
+        // window by window;] degrid; then per window [ranged: count,] prefix sums of the counts and runs of at most
+        // REC_CAP records: insert, colours, gather.
+        enum { S_ZWIN, S_DEGRID, S_COUNT, S_SCAN, S_RUN, S_DONE };
+        // (list mode gets here with a z-buffer that is complete only if phase B ran: it is simply done again, with the counts)
+        int state = S_ZWIN, wb = 0, c0 = 0, done = 0;
+#if defined(KBE_FRAME_STOP) && defined(KBE_FRAME_SKIP_SLOW)      // (dev) what would the launch cost without its slow tiles?
+        state = S_DONE;
+#endif
+        fast = false;
+        while (state != S_DONE) {                               // uniform
+            const int n_win = ranged ? min(MAXC, n_blocks - wb) : n_cand;
+            int flags = 0, p0 = 0, p1 = n_win;
+            if (state == S_ZWIN) flags = ranged ? PASS_Z : (PASS_Z | PASS_COUNT);
+            else if (state == S_COUNT) flags = PASS_COUNT;
+            else if (state == S_RUN) {
                 for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
                 if (tid == 0) { L.nrec = 0; F.run_end = n_win; }
                 __syncthreads();
@@ -1152,20 +1254,62 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
                 for (int c = c0 + tid; c < n_win; c += TILE_THREADS)
                     if (F.cnt[c] - done > REC_CAP && (c == c0 || F.cnt[c - 1] - done <= REC_CAP)) F.run_end = c;
                 __syncthreads();
-                const int c1 = F.run_end;
-                pass(PASS_INSERT, c0, c1, wb);
+                flags = PASS_INSERT; p0 = c0; p1 = F.run_end;
+            }
+            if (flags) pass(flags, p0, p1, wb);
+            __syncthreads();
+            if (state == S_ZWIN) {
+                wb += MAXC;
+                if (!ranged || wb >= n_blocks) state = S_DEGRID;
+            } else if (state == S_DEGRID) {
+                decode_z();
                 __syncthreads();
-                const int n = L.nrec;
+                fast = tile_is_fast();
+                tile_degrid(a, L, tid, x0, y0, fast);
+                wb = 0;
+                state = ranged ? S_COUNT : S_SCAN;
+            } else if (state == S_COUNT) {
+                state = S_SCAN;
+            } else if (state == S_SCAN) {
+                // inclusive prefix sums of the counts, one entry per thread
+                const int e = tid < n_win ? F.cnt[tid] : 0;
+                int v = e;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
+                if (lane == 63) F.wave_sum[tid >> 6] = v;
+                __syncthreads();
+                for (int w = 0; w < (tid >> 6); w++) v += F.wave_sum[w];
+                if (tid < n_win) F.cnt[tid] = v;
+                c0 = 0; done = 0;
+                state = n_win > 0 ? S_RUN : S_DONE;
+                if (state == S_DONE && ranged && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
+            } else if (state == S_RUN) {
+                const int n = min(L.nrec, REC_CAP);
                 for (int i = tid; i < n; i += TILE_THREADS) L.rgbd[i] = fetch_rgbd(a, __float_as_int(L.rgbd[i].x));
                 __syncthreads();
                 if (fast) gather<true>(a, L, tid, x0, y0, acc);
                 else gather<false>(a, L, tid, x0, y0, acc);
-                __syncthreads();
-                done = F.cnt[c1 - 1];
-                c0 = c1;
+                c0 = p1;
+                done = c0 > 0 ? F.cnt[c0 - 1] : 0;
+                if (c0 >= n_win) {
+                    state = S_DONE;
+                    if (ranged && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
+                }
             }
+            __syncthreads();
         }
     }
+#if defined(KBE_FRAME_STATS)
+    if (tid == 0) {
+        atomicAdd(&g_frame_stats[0], 1ull);
+        atomicAdd(&g_frame_stats[1], (unsigned long long) F.n_at[top]);
+        atomicAdd(&g_frame_stats[2], (unsigned long long) n_cand);
+        atomicAdd(&g_frame_stats[4], (unsigned long long) total);
+        atomicAdd(&g_frame_stats[5], (unsigned long long) !(!ranged && n_spill <= BUCKET_CAP));
+        atomicAdd(&g_frame_stats[6], (unsigned long long) (n_spill > 0));
+        atomicAdd(&g_frame_stats[7], (unsigned long long) n_spill);
+    }
+#endif
     tile_epilogue(a, L, acc, tile, x0, y0);
 }
 
@@ -1882,7 +2026,7 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
         a.cam = cam;
         a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
         a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = count_now; a.bbox = sc.bbox; a.coarse = sc.coarse;
-        a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
+        a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32; a.spill = sc.buckets;
         hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
         if ((rc = launched("kbe_render_frame_fused/scatter"))) return rc;
     }
@@ -1900,6 +2044,15 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     }
     return rc;
 }
+
+#if defined(KBE_FRAME_STATS)
+extern "C" __attribute__((visibility("default"))) int kbe_debug_frame_stats(unsigned long long* out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_frame_stats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_frame_stats), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
                                 double baseline, const float* shift3, void* scratch, float* render, float* existing,

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""What the tiles of the fused frame kernel do, per tile, on the bench workload (dev aid).  Builds a variant library with
+-DKBE_FRAME_STATS under /tmp (the product library carries no counters) and renders a few frames with it."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = '/tmp/libkbe_stats.so'
+src = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
+subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared',
+                       '-fvisibility=hidden', '-DKBE_FRAME_STATS', '-I' + os.path.join(ROOT, 'include'), '-I' + src,
+                       os.path.join(src, 'kbe_hip.hip'), os.path.join(src, 'kbe_frame.hip'), os.path.join(src, 'kbe_cloud.hip'), '-o', so])
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
+
+_native._lib, _native._kernels, _native.LIB_PATH = None, None, so
+size = int(os.environ.get('SIZE', '1024'))
+dolly = os.environ.get('DOLLY', '0') == '1'
+up = int(os.environ.get('UPSAMPLE', '1'))
+ofrom, oto = synthetic.default_windows(size, size, dolly)
+settings = {'dblSteps': [i / 8 for i in range(9)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
+oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly and up == 1, settings, up)
+K = _native.kernels()
+state = common._prepared_cloud(K, oc)
+out = (ctypes.c_ulonglong * 8)()
+torch.cuda.synchronize()
+K.lib.kbe_debug_frame_stats(out, 1)
+for focal, shift3 in common.frame_cameras(settings, oc):
+    K.render_frame(state, shift3, focal, oc['dblBaseline'])
+    torch.cuda.synchronize()
+    K.lib.kbe_debug_frame_stats(out, 1)
+    t = max(1, out[0])
+    print('tiles %d: top-level survivors %.1f, candidate blocks %.1f (%.0f points), points in z reach %.0f, staged %.0f, records %.0f per tile; tiles on the slow path %d, with a second round %d'
+          % (out[0], out[1] / t, out[2] / t, 64.0 * out[2] / t, out[3] / t, out[7] / t, out[4] / t, out[5], out[6]))

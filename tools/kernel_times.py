@@ -13,7 +13,7 @@ per = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     per[r['Kernel_Name']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 total = 0.0
-for key in ('k_project', 'k_tiles', 'k_fill_holes', 'k_crop_resize_u8'):
+for key in ('k_project', 'k_tiles', 'k_frame', 'k_fill_holes', 'k_crop_resize_u8'):
     for name, v in per.items():
         if key + '(' in name:
             total += statistics.median(v)
