@@ -116,27 +116,24 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     empty = (1, 1, 0, 0)
-    out = {}
-    if state.get('fused'):
-        # the scatter = ONE launch (k_frame); back to back on the stream, hole counter left alone (stage flag 64) so that
-        # nothing but the kernel sits between the events
-        out['scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2 | 64))
-        out['scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect))     # + the 8-byte memset of a frame on its own
-        out['fill'] = out['scatter+fill'] - out['scatter']
-    # the bucket path (round 1's route: k_project -> k_tiles, z-buffer and bucket records in HBM), for comparison.
-    # Every timed variant ends with the fill launch because that launch also resets its scratch (z-buffer, bucket
-    # counters); with an empty fill rectangle it does no hole work.
+    out = {'route': 'fused' if state.get('fused') else 'bucket'}
+    # the fused route: the scatter = ONE launch (k_frame); back to back on the stream, hole counter left alone (stage flag
+    # 64) so that nothing but the kernel sits between the events
+    out['fused:scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2 | 64, fused=True))
+    out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
+    # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM; the scatter's z-buffer / bucket reset
+    # rides in the fill launch, so every timed variant ends with that launch (with an empty fill rectangle it does no hole work)
     b = dict(fused=False)
     out['bucket:reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b))
     out['bucket:project+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=5, fill_rect=empty, **b))
-    out['bucket:project+tiles+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty, **b))
+    out['bucket:scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty, **b))      # project + tiles + reset
+    out['bucket:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=fill_rect, **b))
     K.render_frame(state, shift3, focal, Bl, stages=1, **b)
-    out['bucket:tiles'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2, **b))
+    out['bucket:tiles'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2, **b))       # k_tiles alone on a prepared scratch
     K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b)           # leave the scratch clean
-    if not state.get('fused'):
-        out['scatter'] = out['bucket:project+tiles+reset']
-        out['scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=fill_rect, **b))
-        out['fill'] = out['scatter+fill'] - out['scatter']
+    for k in ('scatter', 'scatter+fill'):
+        out[k] = out[out['route'] + ':' + k]
+    out['fill'] = out['scatter+fill'] - out['scatter']
     frame = K.render_frame(state, shift3, focal, Bl)
     cw, ch = int(0.9 * W), int(0.9 * H)
     out['crop_resize'] = timed(lambda: K.crop_resize_u8(frame, cw, ch))
@@ -323,16 +320,21 @@ def main():
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch)
-        # over the HIP-event time of the launch that implements it, back to back alone on a stream: k_frame (the
-        # fused scatter on the packed cloud).  With KBE_FUSED=0 the scatter is the bucket path's three launches.
-        fused = os.environ.get('KBE_FUSED', '1') != '0'
+        # over the HIP-event time of the launches that implement it, back to back alone on a stream -- for the route the
+        # timed region took at this size (bucket: k_project + k_tiles + the z-buffer / bucket reset riding in k_fill_holes;
+        # fused: k_frame), with the other route's figures beside it.
+        route = kt.pop('route')
         scatter_bytes = 28 * n_points + 20 * HW
-        t_scatter = kt['scatter']
-        achieved = scatter_bytes / t_scatter / 1e9
-        launches = ['k_frame'] if fused else ['k_project', 'k_tiles', 'k_fill_holes']
+        route_launches = {'fused': ['k_frame'], 'bucket': ['k_project', 'k_tiles', 'k_fill_holes']}
         # the committed PMC passes are of the default workload only
         per_kernel, traffic_src = measured_traffic() if (size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1) else ({}, None)
-        traffic = sum(per_kernel[k] for k in launches) if all(k in per_kernel for k in launches) else None
+
+        def roof(r):
+            t = kt[r + ':scatter']
+            tr = sum(per_kernel[k] for k in route_launches[r]) if all(k in per_kernel for k in route_launches[r]) else None
+            return {'kernel': ' + '.join(route_launches[r]), 'us': round(t * 1e6, 2), 'achieved': scatter_bytes / t / 1e9,
+                    'frac': scatter_bytes / t / 1e9 / HBM_PEAK_GBS, 'traffic': tr}
+        main, other = roof(route), roof('bucket' if route == 'fused' else 'fused')
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
@@ -341,17 +343,18 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%dx%d %s path, %d pts (%s cloud), frame=shift+scatter+fill+u8%s' % (
                            size, size, 'dolly' if args.dolly else 'KBE', n_points, cloud, '' if crop is None else '+crop/resize'),
-                       'delivery': delivery, 'frames_per_rank': args.steps, 'lanes': lanes if args.device_only else host_lanes,
+                       'delivery': delivery, 'scatter_route': route, 'frames_per_rank': args.steps, 'lanes': lanes if args.device_only else host_lanes,
                        'device_only_lanes': lanes, 'passes': len(times),
                        'pass_ms': {'median': round(elapsed * 1e3, 3), 'min': round(min(times) * 1e3, 3), 'max': round(max(times) * 1e3, 3)},
                        'sharding': 'frames round-robin over ranks; one cloud broadcast (set-up, cloud_broadcast_ms)'},
             'device_only': {'value': args.steps * world_size / elapsed_dev, 'unit': 'frames/s', 'ms_per_step': elapsed_dev / args.steps * 1e3,
                             'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
-            'roofline': {'bound': 'hbm', 'kernel': ' + '.join(launches) + ' (the scatter = render_pointcloud)',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': scatter_bytes,
-                         'formula': '28 N + 20 HW (SURVEY.md 8d)', 'us': round(t_scatter * 1e6, 2),
-                         'note': 'launch timed alone on one stream, back to back (HIP events, 40 repetitions); the matching rocprofv3 --stats '
+            'roofline': {'bound': 'hbm', 'kernel': main['kernel'] + ' (the scatter = render_pointcloud, %s route)' % route,
+                         'achieved': main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': main['frac'],
+                         'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': scatter_bytes,
+                         'formula': '28 N + 20 HW (SURVEY.md 8d)', 'us': main['us'],
+                         'other_route': dict(other, route='bucket' if route == 'fused' else 'fused'),
+                         'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions); the matching rocprofv3 --stats '
                                  'summary is the one taken with KBE_LANES=1 KBE_HOST_LANES=1 (profiles/): in the timed region the kernels of '
                                  'several frames overlap and per-kernel durations stretch',
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},

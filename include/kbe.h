@@ -197,7 +197,8 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
  *
  * kbe_cloud_pack, once per video after the set-up loop has grown the cloud: sorts the points by where they lie in
  * the cloud's own view (Morton order of 8 x 8-pixel cells for points projected with `focal` onto a W x H raster; any
- * order is correct, this one is fast), cuts them into blocks of 64, and builds over them a hierarchy of boxes that
+ * order is correct, this one is fast; raster_w / raster_n: the layout hint of kbe_render_frame_stages, 0, 0 if unknown:
+ * the first raster_n points then keep their own 8 x 8 cells), cuts them into blocks of 64, and builds over them a hierarchy of boxes that
  * bound where a block's points can land in any view.  `packed`: DEVICE buffer of kbe_cloud_pack_bytes(N) bytes,
  * 256-byte aligned, owned by the caller; the original three tensors are not needed afterwards.
  *
@@ -212,7 +213,7 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
  * ------------------------------------------------------------------------------------- */
 KBE_API size_t kbe_cloud_pack_bytes(int N);
 KBE_API int kbe_cloud_pack(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
-                           void* packed, kbe_stream_t stream);
+                           int raster_w, int raster_n, void* packed, kbe_stream_t stream);
 KBE_API int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W, int H, double focal, double baseline,
                                    const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
                                    float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages,

@@ -27,6 +27,7 @@ SYMBOLS = (
 ABI_VERSION = 3
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
+FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory (env KBE_HOST_LANES)
 _lib = None
 
@@ -242,15 +243,28 @@ class HipKernels:
         for l in range(lanes):
             self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
                         'kbe_frame_scratch_init')
-        # the packed form the fused frame kernel renders from (kbe_cloud_pack: once per cloud); KBE_FUSED=0 keeps the
-        # bucket path (k_project + k_tiles) as the route of render_frame / render_video instead
-        state['fused'] = os.environ.get('KBE_FUSED', '1') != '0'
+        # Two routes for the scatter of a frame, same results (tests/test_hip_parity.py::test_fused_scatter_equals_the_bucket_path):
+        #   bucket  k_project -> k_tiles: every point projected once, 16-byte records through HBM; fewer instructions;
+        #   fused   k_frame on the packed cloud (kbe_cloud_pack, once per cloud): one launch, z-tile in LDS, no global
+        #           atomics, ~0.7x the algorithmic HBM bytes, but every point is projected by the ~2.3 tiles it may reach.
+        # Both are bound by instruction issue, so at 1024^2 and above the bucket route is 15-25 % faster (28.5 vs 39 us per
+        # frame); below ~640^2 a frame is bound by its launches and the fused route wins (512^2: 12.1 vs 16.7 us per frame).
+        # KBE_FUSED = auto (default) | 1 | 0.
+        mode = os.environ.get('KBE_FUSED', 'auto')
+        state['fused'] = (W * H <= FUSED_MAX_PIXELS) if mode == 'auto' else mode != '0'
         state['cloud_focal'] = float(focal) if focal else 512.0
         if state['fused']:
-            state['packed'] = torch.empty(int(self.lib.kbe_cloud_pack_bytes(_i(N))), dtype=torch.uint8, device=dev)
-            self._check(self.lib.kbe_cloud_pack(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(N), _i(W), _i(H),
-                                                _d(state['cloud_focal']), _ptr(state['packed'], torch.uint8), _stream()), 'kbe_cloud_pack')
+            self._pack(state)
         return state
+
+    def _pack(self, state):
+        """kbe_cloud_pack, once per cloud (on first use of the fused route)."""
+        if 'packed' not in state:
+            N, W, H = state['N'], state['W'], state['H']
+            state['packed'] = torch.empty(int(self.lib.kbe_cloud_pack_bytes(_i(N))), dtype=torch.uint8, device=state['points'].device)
+            self._check(self.lib.kbe_cloud_pack(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(N), _i(W), _i(H),
+                                                _d(state['cloud_focal']), _i(state['raster_w']), _i(state['raster_n']),
+                                                _ptr(state['packed'], torch.uint8), _stream()), 'kbe_cloud_pack')
 
     def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None, zee_f32=None,
                      zee_pre_f32=None, out=None, stages=7, fill_rect=None, fused=None):
@@ -261,6 +275,7 @@ class HipKernels:
         frame = state['frame'] if out is None else out
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
         if state.get('fused') if fused is None else fused:
+            self._pack(state)
             self._check(self.lib.kbe_render_frame_fused(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']),
                                                         _i(state['W']), _i(state['H']), _d(float(focal)), _d(float(baseline)),
                                                         _shift(shift3), _ptr(state['scratch'], torch.uint8), _ptr(frame, torch.uint8),

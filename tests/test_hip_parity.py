@@ -391,7 +391,6 @@ def test_fused_scatter_equals_the_bucket_path(K, size, dolly, kind):
     settings, oc = _grown_scene(size, 13, dolly, kind)
     H, W = size
     state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, 512.0)
-    assert state['fused'] and state['packed'].numel() > 28 * state['N']
     for focal, shift3 in common.frame_cameras(dict(settings, dblSteps=[0.0, 0.35, 1.0]), oc):
         outs = []
         for fused in (True, False):

@@ -30,5 +30,11 @@ size = int(os.environ.get('SIZE', '1024'))
 ofrom, oto = synthetic.default_windows(size, size, False)
 settings = {'dblSteps': [i / 15.0 for i in range(16)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False}
 oc = bench.build_scene(size, dev, os.environ.get('CLOUD', 'inpaint') == 'inpaint', settings)
-frames = common.render_frames(common.frame_cameras(settings, oc), oc, common.crop_size(settings))
+cams = common.frame_cameras(settings, oc)
+frames = common.render_frames(cams, oc, common.crop_size(settings), keep_on_device=True)      # the route in use at this size
+state = common._prepared_cloud(K, oc)
+for focal, shift3 in cams:                                                                    # and both routes explicitly, one frame at a time
+    K.render_frame(state, shift3, focal, oc['dblBaseline'], fused=True)
+    K.render_frame(state, shift3, focal, oc['dblBaseline'], fused=False)
+torch.cuda.synchronize()
 print('frames', frames.shape, 'points', oc['tensorInpaPoints'].shape[-1])
