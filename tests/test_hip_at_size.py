@@ -1,0 +1,114 @@
+"""GPU parity at BASELINE.json's large sizes: configs[4] at size -- a 2048 x 2048 frame from a
+16.8 M-point cloud, four points per pixel -- and rasters beyond 4096^2 (the 64-bit bucket-offset switch of
+k_project), for BOTH scatter routes.  What is compared:
+  * the z-buffer before the degrid against an independent torch scatter-min over the winner pixels, bit for bit;
+  * a 256 x 256 window of the un-filled render against the CPU oracle run on the points that can reach the window;
+  * the two hole-fill schedules against each other; the tile renderers against the stage-by-stage atomic kernels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    from ken_burns_effect_amd import _native
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return _native.kernels()
+
+
+def c(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def dense_cloud(K):
+    """BASELINE.json configs[4]: the RGBD of a 4096^2 image unprojected with focal 2 F lands on sub-pixel positions of
+    the 2048^2 view: 16 777 216 points, four per target pixel."""
+    from ken_burns_effect_amd import synthetic
+    size, up = 2048, 2
+    image, disp = synthetic.make_rgbd(size * up, size * up, 0)
+    depth = ((synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)).cuda()
+    pts = K.depth_to_points(depth, synthetic.FOCAL * up).view(1, 3, -1)
+    return size, pts, image.cuda().reshape(1, 3, -1), depth.reshape(1, 1, -1)
+
+
+@pytest.mark.parametrize('fused', [False, True], ids=['bucket', 'fused'])
+def test_config4_2048_frame_from_16m_points(K, oracle, dense_cloud, fused, monkeypatch):
+    monkeypatch.setenv('KBE_LANES', '1')                # one scratch: 0.9 GB of buckets at this size
+    from ken_burns_effect_amd import synthetic
+    size, pts, img, dep = dense_cloud
+    n = pts.shape[2]
+    assert n == 16777216
+    focal, Bl = synthetic.FOCAL, synthetic.BASELINE
+    shift3 = (14.0, -9.0, -31.0)
+    state = K.prepare_cloud(pts, img, dep, size, size, focal, raster=(size * 2, n))
+    rf = torch.empty(4, size, size, device='cuda')
+    ex, zp, zd = (torch.empty(size * size, device='cuda') for _ in range(3))
+    K.render_frame(state, shift3, focal, Bl, render_f32=rf, existing_f32=ex, zee_f32=zd, zee_pre_f32=zp, stages=3, fused=fused)
+    # (1) z-buffer before the degrid == scatter-min of dblError over each point's winner pixel (independent kernels + torch)
+    _, winner = K.zsplat(pts, size, size, focal, Bl, shift3=shift3, want_winner=True)
+    shifted = K.shift_points(pts, shift3)
+    err = (1000000.0 - (focal * Bl) / (shifted[0, 2].double() + 0.0000001)).float()
+    w = winner[0].long()
+    keep = w >= 0
+    want = torch.full((size * size,), 1000000.0, device='cuda')
+    want.scatter_reduce_(0, w[keep], err[keep], reduce='amin')
+    assert torch.equal(zp.view(torch.int32), want.view(torch.int32)), 'pre-degrid z-buffer at 2048^2 / 16.8 M points'
+    assert int(keep.sum()) > 15000000
+    del err, want, keep
+    # (2) a window of the un-filled render against the oracle on the points that can reach it (+ 8 px of context; the
+    # comparison stays 4 px inside so that nothing outside the subset can matter: degrid reads 1 px, a point colours 2 x 2)
+    wx0, wy0, ws = 1100, 700, 256
+    py, px = w // size, w % size
+    sel = (w >= 0) & (px >= wx0 - 8) & (px < wx0 + ws + 8) & (py >= wy0 - 8) & (py < wy0 + ws + 8)
+    sub = torch.nonzero(sel).view(-1)
+    assert 200000 < sub.numel() < 400000
+    sp = shifted[:, :, sub].cpu()
+    data = torch.cat([img[:, :, sub], dep[:, :, sub]], 1).cpu()
+    ref, ref_ex = oracle.render_pointcloud(sp, data, size, size, focal, Bl, 'jacobi')
+    win = (slice(wy0 + 4, wy0 + ws - 4), slice(wx0 + 4, wx0 + ws - 4))
+    got_ex = c(ex).reshape(size, size)[win]
+    assert np.array_equal(got_ex > 0, ref_ex.numpy()[0, 0][win] > 0), 'same pixels covered'
+    assert np.abs(got_ex - ref_ex.numpy()[0, 0][win]).max() <= 1e-4 * float(ref_ex.max())
+    for ch in range(4):
+        a, b = c(rf[ch])[win], ref.numpy()[0, ch][win]
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, float(np.abs(b).max())), 'channel %d' % ch
+    zref = oracle.degrid(oracle.zsplat(sp, size, size, focal, Bl)[0], 'jacobi').numpy()[0, 0]
+    assert_bits_equal(c(zd).reshape(size, size)[win], zref[win], 'degridded z-buffer in the window')
+    # (3) the two hole-fill schedules give the same frame
+    frames = [c(K.render_frame(state, shift3, focal, Bl, stages=7 | mode, fused=fused)) for mode in (8, 16)]
+    d = np.abs(frames[0].astype(np.int32) - frames[1].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert int((c(ex) <= 0).sum()) > 0, 'the frame has holes to fill'
+
+
+@pytest.mark.parametrize('size', [4608, 5120])
+def test_rasters_beyond_4096_tile_renderers_against_the_atomic_kernels(K, size, monkeypatch):
+    """Above 4096^2 the buckets no longer end below byte 2^32 (k_project switches to 64-bit offsets); 5120^2 is also past
+    the coarse skip map of the per-lane hole fill.  Bucket route and fused route against the stage-by-stage kernels."""
+    monkeypatch.setenv('KBE_LANES', '1')
+    from ken_burns_effect_amd import synthetic
+    image, disp = synthetic.make_rgbd(size, size, seed=0)
+    depth = ((synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)).cuda()
+    pts = K.depth_to_points(depth, synthetic.FOCAL).view(1, 3, -1)
+    img, dep = image.cuda().reshape(1, 3, -1), depth.reshape(1, 1, -1)
+    shift3 = (size * 0.004, -size * 0.003, -size * 0.02)
+    p2 = K.shift_points(pts, shift3)
+    render, existing = K.render_pointcloud(p2, torch.cat([img, dep], 1), size, size, synthetic.FOCAL, synthetic.BASELINE, tiled=False)
+    filled = K.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())
+    want_u8 = K.frame_u8(filled)
+    assert int((existing[0, 0] <= 0).sum()) > 1000
+    state = K.prepare_cloud(pts, img, dep, size, size, synthetic.FOCAL, raster=(size, size * size))
+    for fused in (False, True):
+        rf = torch.empty(4, size, size, device='cuda')
+        ex = torch.empty(size * size, device='cuda')
+        frame = K.render_frame(state, shift3, synthetic.FOCAL, synthetic.BASELINE, render_f32=rf, existing_f32=ex, fused=fused)
+        assert torch.equal(ex.view(size, size) > 0, existing[0, 0] > 0), 'validity masks (fused=%s)' % fused
+        assert float((rf - filled[0]).abs().max()) <= 1e-4 * max(1.0, float(filled.abs().max()))
+        assert int((frame.int() - want_u8.int()).abs().max()) <= 1
+        del rf, ex
