@@ -277,16 +277,21 @@ __global__ void __launch_bounds__(kBlock) k_frame_u8(const float* __restrict__ r
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int cv_round(float v) { return (int) rintf(v); }
 
-// resize INTER_LINEAR 8u: source index and 11-bit coefficient pair of destination index d
-__device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, int& s0, int& s1, int& c0, int& c1)
+// resize INTER_LINEAR 8u: source index pair and 11-bit coefficient pair of destination index d.  OpenCV (resize.cpp)
+// treats the two directions differently: a COLUMN tap outside the row is clamped and its fraction zeroed (xmin / xmax),
+// a ROW tap outside the image only has its index clipped -- both taps then read the same row with weights (1 - f, f),
+// which rounds differently from (1, 0) by up to one count in the first and last output rows.
+__device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, bool horizontal, int& s0, int& s1, int& c0, int& c1)
 {
     float f = (float) ((d + 0.5) * scale - 0.5);
     int s = (int) floorf(f);
     f -= (float) s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= src_n - 1) { f = 0.f; s = src_n - 1; }
-    s0 = s;
-    s1 = min(s + 1, src_n - 1);
+    if (horizontal) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= src_n - 1) { f = 0.f; s = src_n - 1; }
+    }
+    s0 = min(max(s, 0), src_n - 1);
+    s1 = min(max(s + 1, 0), src_n - 1);
     c0 = cv_round((1.f - f) * 2048.f);
     c1 = cv_round(f * 2048.f);
 }
@@ -324,8 +329,8 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
         const bool col = tid < CR_TW;
         const int k = col ? tid : tid - CR_TW;
         int s0, s1, c0, c1;
-        if (col) resize_coeff(min(bx + k, W - 1), (double) cw / W, cw, s0, s1, c0, c1);
-        else resize_coeff(min(by + k, H - 1), (double) ch_ / H, ch_, s0, s1, c0, c1);
+        if (col) resize_coeff(min(bx + k, W - 1), (double) cw / W, cw, true, s0, s1, c0, c1);
+        else resize_coeff(min(by + k, H - 1), (double) ch_ / H, ch_, false, s0, s1, c0, c1);
         int* t = col ? &s_cx[0][k] : &s_cy[0][k];
         const int stride = col ? CR_TW : CR_TH;
         t[0] = s0; t[stride] = s1; t[2 * stride] = c0; t[3 * stride] = c1;

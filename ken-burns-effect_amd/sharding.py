@@ -94,9 +94,16 @@ def gather_frames(local_frames, indices, total, device, dst=0):
     return out
 
 
-def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather=True):
-    """process_kenburns over all ranks: rank 0 builds the cloud, broadcast, each rank renders its
-    round-robin share of ``dblSteps``; with ``gather`` rank 0 returns the full frame list."""
+def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather=False):
+    """process_kenburns over all ranks: rank 0 builds the cloud, one broadcast, each rank renders its round-robin share
+    of ``dblSteps``.
+
+    ``gather=False`` (default): every rank delivers ITS frames to its own pinned host memory over its own PCIe link (what
+    a node with one encoder / writer process per GPU wants; nothing funnels through one GPU) and gets
+    ``(indices, frames)`` back -- the positions of its frames in ``dblSteps`` and the uint8 HxWx3 frames.
+    ``gather=True``: the frames stay in HBM, are gathered on rank 0 (one collective) and rank 0 returns the full list in
+    step order, the other ranks None.  At 17 k frames/s per GPU that funnel is the bottleneck of an 8-GPU run; it exists
+    for callers that need the whole video in one process."""
     from . import common
     rank, world_size = world()
     if rank == 0 and ('boolInpaint' not in objectSettings or objectSettings['boolInpaint']):
@@ -108,8 +115,10 @@ def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device
     idx, steps = shard_steps(objectSettings['dblSteps'], rank, world_size)
     local_settings = dict(objectSettings, dblSteps=steps)
     crop = common.crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
-    frames = common.render_frames(common.frame_cameras(local_settings, objectCommon), objectCommon, crop, keep_on_device=True)
+    cameras = common.frame_cameras(local_settings, objectCommon)
     if not gather:
-        return [f for f in frames.cpu().numpy()]
+        frames = common.render_frames(cameras, objectCommon, crop)
+        return idx, [frames[i] for i in range(frames.shape[0])]
+    frames = common.render_frames(cameras, objectCommon, crop, keep_on_device=True)
     full = gather_frames(frames, idx, len(objectSettings['dblSteps']), device)
     return None if full is None else [f for f in full.cpu().numpy()]

@@ -198,21 +198,26 @@ def crop_resize_u8(frame, crop_w, crop_h):
     ys0 = np.clip(ipy + np.arange(crop_h), 0, H - 1); ys1 = np.clip(ipy + np.arange(crop_h) + 1, 0, H - 1)
     patch = (img[ys0][:, xs0] * a11 + img[ys0][:, xs1] * a12 + img[ys1][:, xs0] * a21 + img[ys1][:, xs1] * a22 + (1 << 15)) >> 16
 
-    def coeffs(dst_n, src_n):
+    def coeffs(dst_n, src_n, horizontal):
         d = np.arange(dst_n, dtype=np.float64)
         f = ((d + 0.5) * (float(src_n) / dst_n) - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
-        lo = s < 0
-        f[lo] = 0; s[lo] = 0
-        hi = s >= src_n - 1
-        f[hi] = 0; s[hi] = src_n - 1
+        if horizontal:
+            # resize.cpp clamps the COLUMN taps and zeroes their fraction (xmin / xmax) ...
+            lo = s < 0
+            f[lo] = 0; s[lo] = 0
+            hi = s >= src_n - 1
+            f[hi] = 0; s[hi] = src_n - 1
+        # ... but keeps the fraction of the ROW taps and only clips the two row indices: above the first / below the last
+        # row both taps read the same row with weights (1 - f, f), which rounds differently from (1, 0) by up to one count
+        # (found by the second restatement, tests/opencv_8u_restatement.c)
         c0 = np.rint((one - f) * np.float32(2048.0)).astype(np.int64)
         c1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
-        return s, np.minimum(s + 1, src_n - 1), c0, c1
+        return np.clip(s, 0, src_n - 1), np.clip(s + 1, 0, src_n - 1), c0, c1
 
-    sx, sx1, ax0, ax1 = coeffs(W, crop_w)
-    sy, sy1, by0, by1 = coeffs(H, crop_h)
+    sx, sx1, ax0, ax1 = coeffs(W, crop_w, True)
+    sy, sy1, by0, by1 = coeffs(H, crop_h, False)
     rows = patch[:, sx] * ax0[None, :, None] + patch[:, sx1] * ax1[None, :, None]          # [crop_h, W, 3], x2048
     r0, r1 = rows[sy], rows[sy1]
     v = (((by0[:, None, None] * (r0 >> 4)) >> 16) + ((by1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2

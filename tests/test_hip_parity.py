@@ -811,6 +811,22 @@ def test_sharded_video_on_the_hip_path_two_ranks():
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_sharded_video_over_rccl_when_the_box_has_two_gpus():
+    """The same check on backend "nccl" (= RCCL; one GPU per rank, the cloud broadcast device to device): runs wherever
+    two GPUs are visible, skipped on a 1-GPU box.  No scaling curve has been measured yet (no multi-GPU node was
+    available to the builder); this keeps the RCCL path from rotting until one is."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29534', os.path.join(root, 'tools', 'sharded_check.py')],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', KBE_DIST_BACKEND='nccl'))
+    assert out.returncode == 0 and 'OK (nccl' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_partial_conv_inpainting_pipeline_on_gpu(K):
     """BASELINE.json configs[3] in miniature: the partial-convolution Inpaint (fused HIP mask-update epilogue) driving
     the set-up of a KBE video, and a dolly video (no inpainting, common.py:217), both through Pipeline."""

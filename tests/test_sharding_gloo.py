@@ -50,11 +50,15 @@ def _worker(rank, world_size, port, out_path):
             oc = {}                    # only rank 0 owns the scene; the others learn it from the broadcast
         else:
             common._reset_inpa(oc)
-        frames = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'))
+        frames = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'), gather=True)
         idx, _ = sharding.shard_steps(settings['dblSteps'], rank, world_size)
         assert oc['tensorInpaPoints'].shape == (1, 3, 40 * 56) and oc['intWidth'] == 56 and isinstance(oc['dblBaseline'], int)
+        # the default: every rank keeps (delivers) its own frames; rank 0's must be its rows of the gathered video
+        mine_idx, mine = sharding.process_kenburns_sharded(dict(settings, boolInpaint=False), oc, None, torch.device('cpu'))
+        assert mine_idx == idx and len(mine) == len(idx) and mine[0].shape == (40, 56, 3) and mine[0].dtype == np.uint8
         if rank == 0:
             np.save(out_path, np.stack(frames))
+            assert all(np.array_equal(frames[i], f) for i, f in zip(idx, mine))
         else:
             assert frames is None and len(idx) == 3
     finally:
