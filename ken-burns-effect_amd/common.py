@@ -23,6 +23,7 @@ There is no CPU code path here: the kernel set comes from ``_native.kernels()`` 
 raises when the HIP library is missing.  (Tests substitute ``_kernel_set`` with the
 oracle explicitly to exercise the host logic without a GPU.)
 """
+import contextlib
 import math
 
 import numpy as np
@@ -40,6 +41,13 @@ _kernel_set = None     # tests assign an oracle-backed kernel set here; the prod
 
 def _K():
     return _kernel_set if _kernel_set is not None else _native.kernels()
+
+
+def on_device_of(t):
+    """Context in which `t`'s GPU is the current device: the C ABI launches on the CURRENT device's stream, so work on a
+    tensor of cuda:1 must run with device 1 current (a caller on a multi-GPU box need not call torch.cuda.set_device)."""
+    device = t if isinstance(t, torch.device) else (torch.device(t) if isinstance(t, str) else t.device)
+    return torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()
 
 
 # ---------------------------------------------------------------------------------------
@@ -145,13 +153,18 @@ def process_load(numpyImage, objectSettings, objectCommon):
     ([1,1,H,W]) bypasses them (depth estimation bypassed, BASELINE.json configs[0]).
     Constants as in the reference: F = 1024/2, B = 40.
     """
-    from . import synthetic
-    K = _K()
     objectCommon['dblFocal'] = 1024 / 2.0
     objectCommon['dblBaseline'] = 40.0
     objectCommon['intWidth'] = numpyImage.shape[1]
     objectCommon['intHeight'] = numpyImage.shape[0]
     device = objectSettings.get('device', 'cuda:0') if isinstance(objectSettings, dict) else 'cuda:0'
+    with on_device_of(device):
+        return _process_load(numpyImage, objectSettings, objectCommon, device)
+
+
+def _process_load(numpyImage, objectSettings, objectCommon, device):
+    from . import synthetic
+    K = _K()
     # the division runs on the host (IEEE): torch's GPU kernels multiply by the rounded reciprocal of a scalar divisor,
     # which is 1 ulp off for about half of the 256 values -- the same image must give the same cloud on every device
     tensorImage = (torch.from_numpy(np.ascontiguousarray(numpyImage.transpose(2, 0, 1))).float().unsqueeze(0) / 255.0).to(device)
@@ -336,8 +349,9 @@ def process_kenburns(objectSettings, objectCommon, moduleInpaint):
     objectSettings: dblSteps, objectFrom/objectTo {dblCenterU, dblCenterV, intCropWidth,
     intCropHeight}, boolInpaint (default True), dolly.  Returns a list of uint8 HxWx3 frames.
     Optional key ``boolCrop`` (default True): apply the crop + resize of :256-257."""
-    if 'boolInpaint' not in objectSettings or objectSettings['boolInpaint'] == True:   # noqa: E712
-        build_pointcloud(objectSettings, objectCommon, moduleInpaint)
-    crop = crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
-    frames = render_frames(frame_cameras(objectSettings, objectCommon), objectCommon, crop)
+    with on_device_of(objectCommon['tensorRawPoints']):
+        if 'boolInpaint' not in objectSettings or objectSettings['boolInpaint'] == True:   # noqa: E712
+            build_pointcloud(objectSettings, objectCommon, moduleInpaint)
+        crop = crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
+        frames = render_frames(frame_cameras(objectSettings, objectCommon), objectCommon, crop)
     return [frames[i] for i in range(frames.shape[0])]

@@ -3,6 +3,7 @@
     python -m ken_burns_effect_amd.kbe --in image.jpg --out outdir [--dolly] [--write-frames]
         [--inpaint-path P] [--refine-path P] [--estim-path P] [--inpaint-depth P] [--pretrained-refine]
         [--pretrained-estim] [--2d] [--startU/--startV/--endU/--endV/--startW/--startH/--endW/--endH N]
+        [--semantics-path vgg19_bn_state_dict.pth]     (new: the reference downloads these weights through torchvision)
 
 Images are read with PIL (OpenCV is not a dependency); like ``cv2.imread`` the pixels are handed to the
 networks in BGR order unless ``--pretrained-estim`` is given (kbe.py:96-98).
@@ -15,12 +16,12 @@ import numpy as np
 import torch
 
 LONG_OPTIONS = ['in=', 'out=', 'dolly', 'write-frames', 'inpaint-path=', 'refine-path=', 'estim-path=', 'startU=', 'startV=', 'endU=',
-                'endV=', 'startW=', 'startH=', 'endW=', 'endH=', 'pretrained-refine', 'pretrained-estim', 'inpaint-depth=', '2d']
+                'endV=', 'startW=', 'startH=', 'endW=', 'endH=', 'pretrained-refine', 'pretrained-estim', 'inpaint-depth=', '2d', 'semantics-path=']
 
 
 def parse(argv):
     cfg = {'in': 'images/doublestrike.jpg', 'out': 'images/kbe', 'dolly': False, 'write-frames': False, 'pretrained-refine': False,
-           'pretrained-estim': False, '2d': False, 'inpaint-depth': None,
+           'pretrained-estim': False, '2d': False, 'inpaint-depth': None, 'semantics-path': None,
            'inpaint-path': './models/trained/inpainting-color.tar', 'refine-path': './models/trained/disparity-refinement.tar',
            'estim-path': './models/trained/disparity-estimation-no-mask.tar'}
     window = dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH'))
@@ -81,7 +82,8 @@ def main(argv=None):
     image = load_image(cfg['in'], cfg['pretrained-estim'])
     zoom = windows_for(image.shape[3], image.shape[2], window, cfg['dolly'])
     paths = [cfg['estim-path'], cfg['refine-path'], cfg['inpaint-path']] + ([cfg['inpaint-depth']] if cfg['inpaint-depth'] else [])
-    pipe = Pipeline(model_paths=paths, dolly=cfg['dolly'], output_frames=cfg['write-frames'], pretrain=cfg['pretrained-refine'], d2=cfg['2d'])
+    pipe = Pipeline(model_paths=paths, dolly=cfg['dolly'], output_frames=cfg['write-frames'], pretrain=cfg['pretrained-refine'], d2=cfg['2d'],
+                    semantics_path=cfg['semantics-path'])
     frames = pipe(image, zoom, cfg['out'], pretrained_estim=cfg['pretrained-estim'])
     print('%d frames of %dx%d written to %s' % (len(frames), image.shape[3], image.shape[2], cfg['out']))
 

@@ -5,7 +5,8 @@ Drop-in for ``/root/reference/utils/pipeline.py`` (``Pipeline`` :23-134): same c
 normalisation, depth, unprojection, ``objectCommon``) runs as stock PyTorch-ROCm modules plus the
 HIP unprojection; the frame loop is :func:`ken_burns_effect_amd.common.process_kenburns`.
 
-Differences, on purpose: the unused Mask-RCNN of the reference (:36, deleted at :90) is not built;
+Differences, on purpose: the unused Mask-RCNN of the reference (:36, deleted at :90) is not built; the ImageNet
+weights of ``Semantics`` come from a file (``semantics_path``) instead of a torchvision download;
 ``cv2.minMaxLoc`` is replaced by :func:`synthetic.depthrange_of`; frames are written with PIL and the
 video through an ``ffmpeg`` binary if one is on PATH (OpenCV / moviepy are not dependencies) --
 otherwise only the PNG frames / an ``.npy`` stack are written.  Returns the frame list.
@@ -27,7 +28,7 @@ from .utils import load_models, resize_image
 
 class Pipeline():
     def __init__(self, model_paths=None, partial_inpainting=False, dolly=False, output_frames=False, pretrain=False, d2=False,
-                 device='cuda:0', steps=75, inpaint_dtype=None):
+                 device='cuda:0', steps=75, inpaint_dtype=None, semantics_path=None):
         self.objectCommon = {'dblFocal': 1024.0 / 2, 'dblBaseline': 120}       # pipeline.py:26-27
         self.partial_inpainting, self.dolly, self.output_frames, self.d2 = partial_inpainting, dolly, output_frames, d2
         self.device, self.steps = torch.device(device), steps
@@ -52,7 +53,21 @@ class Pipeline():
             inpaint_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(os.environ.get('KBE_INPAINT_DTYPE', ''))
         if inpaint_dtype is not None and hasattr(self.moduleInpaint, 'compute_dtype'):
             self.moduleInpaint.compute_dtype = inpaint_dtype
-        synthetic.seeded_fill_(self.moduleSemantics, 999)       # torchvision's ImageNet weights are not available offline
+        # Semantics = torchvision's vgg19_bn(pretrained=True) in the reference (disparity_estimation.py:86): an ImageNet
+        # checkpoint that torchvision downloads.  Neither torchvision nor the network is a dependency here, so the weights
+        # come from a file: ``semantics_path`` / env KBE_SEMANTICS_PATH = a torchvision vgg19_bn state dict
+        # (torch.save(torchvision.models.vgg19_bn(weights='IMAGENET1K_V1').state_dict(), path) on any machine).  Without
+        # it the module gets seeded random weights -- and says so: a trained Disparity checkpoint fed random semantic
+        # features gives a meaningless disparity.
+        semantics_path = semantics_path or os.environ.get('KBE_SEMANTICS_PATH')
+        if semantics_path and os.path.exists(semantics_path):
+            state = torch.load(semantics_path, map_location='cpu')
+            self.moduleSemantics.load_torchvision_state_dict(state.get('model_state_dict', state) if isinstance(state, dict) else state)
+        else:
+            import warnings
+            warnings.warn('checkpoint %r not found: semantics (VGG19-bn) network runs with seeded random weights; pass '
+                          'semantics_path / --semantics-path / KBE_SEMANTICS_PATH (a torchvision vgg19_bn state dict)' % (semantics_path,))
+            synthetic.seeded_fill_(self.moduleSemantics, 999)
 
     @torch.no_grad()
     def estimate(self, tensorImage):
@@ -79,6 +94,10 @@ class Pipeline():
 
     @torch.no_grad()
     def __call__(self, tensorImage, zoom_settings, output_path=None, inpaint_depth=False, pretrained_estim=False):
+        with common.on_device_of(getattr(self, 'device', torch.device('cpu'))):      # the C ABI launches on the current device's stream
+            return self._run(tensorImage, zoom_settings, output_path, inpaint_depth, pretrained_estim)
+
+    def _run(self, tensorImage, zoom_settings, output_path, inpaint_depth, pretrained_estim):
         self.estimate(tensorImage)
         if inpaint_depth:
             raise NotImplementedError('two-network depth inpainting is broken in the reference (common.py:50-69)')

@@ -105,6 +105,12 @@ def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device
     step order, the other ranks None.  At 17 k frames/s per GPU that funnel is the bottleneck of an 8-GPU run; it exists
     for callers that need the whole video in one process."""
     from . import common
+    with common.on_device_of(torch.device(device)):
+        return _process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather)
+
+
+def _process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather):
+    from . import common
     rank, world_size = world()
     if rank == 0 and ('boolInpaint' not in objectSettings or objectSettings['boolInpaint']):
         common.build_pointcloud(objectSettings, objectCommon, moduleInpaint)

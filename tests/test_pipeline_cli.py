@@ -33,3 +33,49 @@ def test_pipeline_end_to_end_on_cpu(oracle, monkeypatch, tmp_path, recwarn):
     assert (tmp_path / 'frames' / '2.png').exists()
     assert (tmp_path / '3d_kbe.mp4').exists() or (tmp_path / '3d_kbe.npy').exists()
     assert any('seeded random weights' in str(w.message) for w in recwarn.list)
+    assert any('semantics (VGG19-bn)' in str(w.message) for w in recwarn.list)
+
+
+def test_semantics_weights_come_from_a_file_when_given(tmp_path, recwarn):
+    """the VGG19-bn weights must be loadable (torchvision state-dict layout), and only their absence may fall
+    back to seeded weights -- loudly."""
+    from ken_burns_effect_amd import kbe
+    from ken_burns_effect_amd.disparity_estimation import Semantics
+    from ken_burns_effect_amd.pipeline import Pipeline
+    ref = Semantics()
+    state = {'features.' + k.split('.', 2)[2]: torch.full_like(v, 0.125) if v.is_floating_point() else v for k, v in ref.state_dict().items()}
+    path = str(tmp_path / 'vgg19_bn.pth')
+    torch.save(state, path)
+    pipe = Pipeline(model_paths=None, device='cpu', steps=2, semantics_path=path)
+    got = pipe.moduleSemantics.state_dict()
+    assert all(bool((v == 0.125).all()) for v in got.values() if v.is_floating_point())
+    assert not any('semantics (VGG19-bn)' in str(w.message) for w in recwarn.list)
+    cfg, _ = kbe.parse(['--semantics-path', path])
+    assert cfg['semantics-path'] == path
+
+
+def test_writers_frame_order_and_channel_flips(tmp_path, monkeypatch):
+    """pipeline.py:120-134 of the reference: PNG frames are the BGR->RGB flip of what process_kenburns returned (cv2.imwrite
+    of BGR data), unless --pretrained-estim (RGB input: no flip); the video holds frames + reversed(frames)[1:]."""
+    from PIL import Image
+    from ken_burns_effect_amd import pipeline as P
+    frames = [np.full((4, 6, 3), i, np.uint8) for i in range(4)]
+    for f in frames:
+        f[..., 0] += 100                                            # channel 0 is distinguishable
+    seen = {}
+    monkeypatch.setattr(P, 'write_video', lambda path, fr, fps=25: seen.update(path=path, frames=[f.copy() for f in fr], fps=fps))
+
+    class Stub(P.Pipeline):
+        def __init__(self):
+            self.output_frames, self.dolly, self.steps, self.objectCommon, self.moduleInpaint = True, False, 4, {}, None
+
+        def estimate(self, tensorImage):
+            return self.objectCommon
+
+    monkeypatch.setattr(P.common, 'process_kenburns', lambda *a, **k: [f.copy() for f in frames])
+    for pretrained_estim in (False, True):
+        out = tmp_path / ('rgb' if pretrained_estim else 'bgr')
+        Stub()(None, {'objectFrom': {}, 'objectTo': {}}, str(out), pretrained_estim=pretrained_estim)
+        assert [int(f[0, 0, 0 if pretrained_estim else 2]) for f in seen['frames']] == [100, 101, 102, 103, 102, 101, 100] and seen['fps'] == 25
+        png = np.asarray(Image.open(out / 'frames' / '3.png'))
+        assert png.shape == (4, 6, 3) and int(png[0, 0, 0 if pretrained_estim else 2]) == 103 and int(png[0, 0, 1]) == 3
