@@ -100,7 +100,7 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
     from ken_burns_effect_amd import _native
     K = _native.kernels()
     W, H = oc['intWidth'], oc['intHeight']
-    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, oc['dblFocal'])
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, oc['dblFocal'], raster=oc.get('_kbeCloudRaster'))
     focal, shift3 = cams[len(cams) // 2]
     Bl = oc['dblBaseline']
 

@@ -40,13 +40,15 @@ __device__ __forceinline__ int classify(float x, float y, float z, float fd, flo
     return 2;
 }
 
-// Sort key.  The first `raster_n` points are the pixels of a raster `raster_w` wide (how process_kenburns builds the
-// cloud, common.py:176-179): their cell is their 8 x 8 block of that raster, so that a block of 64 consecutive packed
-// points IS one cell (when the raster's sides are multiples of 8).  Appended points follow in a second run, in the
-// Morton order of the cells they project to: mixed into the raster run they would shift its blocks off the cell grid
-// (measured: 30 instead of ~23 candidate blocks per tile).
+// Sort key: the Morton code of the 8 x 8-pixel cell a point projects to in the cloud's own view (focal fd, W x H raster).
+// The first `raster_n` points are the pixels of the image raster (how process_kenburns builds the cloud,
+// common.py:176-179): pixel (x, y) projects to x + 0.5, so its cell is its own 8 x 8 block of the raster and -- in a run
+// of their own -- a block of 64 consecutive packed points IS one cell (when the raster's sides are multiples of 8; a
+// denser raster gives several blocks per cell).  Appended points follow in a second run: mixed into the raster run they
+// would shift its blocks off the cell grid (measured: 30 instead of ~23 candidate blocks per tile).  The hint only
+// decides the run; the cell always comes from the coordinates, so a wrong hint costs speed at worst.
 constexpr uint32_t KEY_APPENDED = 0x40000000u;
-__global__ void __launch_bounds__(256) k_cloud_keys(const float* __restrict__ points, int N, int Np, int W, int H, float fd, int raster_w, int raster_n,
+__global__ void __launch_bounds__(256) k_cloud_keys(const float* __restrict__ points, int N, int Np, int W, int H, float fd, int raster_n,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,19 +59,11 @@ __global__ void __launch_bounds__(256) k_cloud_keys(const float* __restrict__ po
         const int cls = classify(points[i], points[(size_t) N + i], points[2 * (size_t) N + i], fd, px, py);
         key = KEY_DEGENERATE;
         if (cls == 1) {
-            int cx, cy;
-            uint32_t run = KEY_APPENDED;
-            if (i < raster_n) {
-                const int y = i / raster_w, x = i - y * raster_w;
-                cx = min(x >> 3, 8190); cy = min(y >> 3, 8190);
-                run = 0u;
-            } else {
-                // the 8 x 8-pixel cell of the point in the cloud's own view, clamped to the raster's surroundings
-                const float u = px + 0.5f * (float) W, v = py + 0.5f * (float) H;
-                cx = (int) fminf(fmaxf(floorf(u * 0.125f) + 1.0f, 0.0f), 8190.0f);
-                cy = (int) fminf(fmaxf(floorf(v * 0.125f) + 1.0f, 0.0f), 8190.0f);
-            }
-            key = run | spread13((uint32_t) cx) | (spread13((uint32_t) cy) << 1);
+            // clamped to the raster's surroundings; + 1 keeps the cells left of / above the raster non-negative
+            const float u = px + 0.5f * (float) W, v = py + 0.5f * (float) H;
+            const int cx = (int) fminf(fmaxf(floorf(u * 0.125f) + 1.0f, 0.0f), 8190.0f);
+            const int cy = (int) fminf(fmaxf(floorf(v * 0.125f) + 1.0f, 0.0f), 8190.0f);
+            key = (i < raster_n ? 0u : KEY_APPENDED) | spread13((uint32_t) cx) | (spread13((uint32_t) cy) << 1);
         }
     }
     keys[i] = key;
@@ -185,7 +179,7 @@ int kbe_cloud_pack(const float* points, const float* image, const float* depth, 
     uint32_t* keys_in = (uint32_t*) (b + L.keys_in), *keys_out = (uint32_t*) (b + L.keys_out);
     uint32_t* idx_in = (uint32_t*) (b + L.idx_in), *idx_out = (uint32_t*) (b + L.idx_out);
     const unsigned grid = blocks_for((size_t) L.Np);
-    hipLaunchKernelGGL(k_cloud_keys, dim3(grid), dim3(256), 0, s, points, N, L.Np, W, H, (float) focal, raster_w > 0 ? raster_w : 1, raster_n, keys_in, idx_in);
+    hipLaunchKernelGGL(k_cloud_keys, dim3(grid), dim3(256), 0, s, points, N, L.Np, W, H, (float) focal, raster_n, keys_in, idx_in);
     size_t tmp = L.sort_tmp_bytes;
     const hipError_t e = rocprim::radix_sort_pairs((void*) (b + L.sort_tmp), tmp, keys_in, keys_out, idx_in, idx_out, (size_t) L.Np, 0, 32, s);
     if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_cloud_pack: radix_sort_pairs", e);
