@@ -234,6 +234,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     from ken_burns_effect_amd import common, sharding, synthetic
+    # multi-GPU: every rank's frames land in pinned memory of the NUMA node its GPU hangs off (best effort; the CPU
+    # baseline of a single-GPU run wants all cores, so N = 1 is left alone)
+    numa_node = sharding.bind_to_gpu_numa_node(dev_index) if world_size > 1 else None
 
     size = args.size
     ofrom, oto = synthetic.default_windows(size, size, args.dolly)
@@ -365,6 +368,7 @@ def main():
                                     % (size * size * 3 / 1e6)}
         if broadcast_ms is not None:
             line['cloud_broadcast_ms'] = broadcast_ms
+            line['config']['rank0_numa_node'] = numa_node
         if world_size == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(oc, cams, crop)
         print(json.dumps(line), flush=True)

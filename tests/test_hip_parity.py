@@ -811,6 +811,19 @@ def test_sharded_video_on_the_hip_path_two_ranks():
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_numa_binding_of_a_rank_is_best_effort():
+    """sharding.bind_to_gpu_numa_node: the CPUs of the GPU's NUMA node, or None (and nothing changed) when unknown."""
+    import os
+    from ken_burns_effect_amd import sharding
+    before = os.sched_getaffinity(0)
+    try:
+        node = sharding.bind_to_gpu_numa_node(0)
+        after = os.sched_getaffinity(0)
+        assert (node is None and after == before) or (isinstance(node, int) and node >= 0 and after and after <= before)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_sharded_video_over_rccl_when_the_box_has_two_gpus():
     """The same check on backend "nccl" (= RCCL; one GPU per rank, the cloud broadcast device to device): runs wherever
     two GPUs are visible, skipped on a 1-GPU box.  No scaling curve has been measured yet (no multi-GPU node was
