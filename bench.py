@@ -121,13 +121,27 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
     # 64) so that nothing but the kernel sits between the events
     out['fused:scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2 | 64, fused=True))
     out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
-    # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM; the scatter's z-buffer / bucket reset
-    # rides in the fill launch, so every timed variant ends with that launch (with an empty fill rectangle it does no hole work)
+    # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM.  In a video consecutive frames alternate
+    # between two z-buffers and each tile launch clears the other one (stage flags 128 / 256), so the scatter is these two
+    # launches; a frame on its own has the reset riding in its fill launch (`bucket:scatter_alone`, empty fill rectangle)
     b = dict(fused=False)
+    flip = [0]
+
+    def alternating(stages, **kw):
+        def run():
+            K.render_frame(state, shift3, focal, Bl, stages=stages | (256 if flip[0] & 1 else 128), **b, **kw)
+            flip[0] += 1
+        return run
+
+    def settle():           # a sequence must not end on z-buffer A (include/kbe.h): one more frame on B
+        if flip[0] & 1:
+            alternating(3)()
+    out['bucket:scatter'] = timed(alternating(3))
+    out['bucket:scatter+fill'] = timed(alternating(7, fill_rect=fill_rect))
+    settle()
     out['bucket:reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b))
     out['bucket:project+reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=5, fill_rect=empty, **b))
-    out['bucket:scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty, **b))      # project + tiles + reset
-    out['bucket:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=fill_rect, **b))
+    out['bucket:scatter_alone'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=7, fill_rect=empty, **b))      # project + tiles + reset
     K.render_frame(state, shift3, focal, Bl, stages=1, **b)
     out['bucket:tiles'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2, **b))       # k_tiles alone on a prepared scratch
     K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b)           # leave the scratch clean
@@ -324,11 +338,11 @@ def main():
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch)
         # over the HIP-event time of the launches that implement it, back to back alone on a stream -- for the route the
-        # timed region took at this size (bucket: k_project + k_tiles + the z-buffer / bucket reset riding in k_fill_holes;
+        # timed region took at this size (bucket: k_project + k_tiles, the tile launch clearing the other frame's z-buffer;
         # fused: k_frame), with the other route's figures beside it.
         route = kt.pop('route')
         scatter_bytes = 28 * n_points + 20 * HW
-        route_launches = {'fused': ['k_frame'], 'bucket': ['k_project', 'k_tiles', 'k_fill_holes']}
+        route_launches = {'fused': ['k_frame'], 'bucket': ['k_project', 'k_tiles']}
         # the committed PMC passes are of the default workload only
         per_kernel, traffic_src = measured_traffic() if (size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1) else ({}, None)
 

@@ -182,6 +182,15 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_FILL_PER_LANE 8
 #define KBE_STAGE_FILL_PER_HALFWAVE 16
 #define KBE_STAGE_FILL_BY_COUNT 32
+/* kbe_render_frame_stages: the scratch holds two z-buffers, A and B.  Without these flags a frame stands alone: it splats
+ * into A and its fill launch resets A and the bucket counters.  Consecutive frames of a video alternate instead:
+ * _ZBUF_A = splat into A, the TILE launch clears B (and the bucket counters); _ZBUF_B = splat into B, the tile launch
+ * clears A -- the reset then costs no launch and no pass over the z-buffer.  Rules: A must be empty when a stand-alone
+ * or _ZBUF_A frame starts (it is after kbe_frame_scratch_init, after a stand-alone frame and after a _ZBUF_B frame), B
+ * when a _ZBUF_B frame starts (it is after a _ZBUF_A frame); so a sequence is A, B, A, B, ... and must not END on
+ * _ZBUF_A (render the last frame stand-alone instead).  kbe_render_video does all of this itself. */
+#define KBE_STAGE_ZBUF_A 128
+#define KBE_STAGE_ZBUF_B 256
 /* kbe_render_frame_fused with parity -1 only: do not zero the hole counter first (bench.py times the scatter launch
  * alone, back to back; the frames of such a run are not valid) */
 #define KBE_STAGE_KEEP_HOLE_COUNT 64

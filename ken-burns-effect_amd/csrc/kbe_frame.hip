@@ -82,6 +82,7 @@ static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >
 
 struct Scratch {                            // carve-out of the caller's scratch allocation
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
+    uint32_t* zkeys_b;      // [H*W]  second z-buffer: consecutive frames of a video alternate, each clearing the other's in its tile launch
     int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
     int* hole_count;        // [1]
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
@@ -111,6 +112,7 @@ Scratch carve(void* base, int W, int H)
     s.holes = (int*) p;           p += align16(4 * hw);
     s.depth = (float*) p;         p += align16(4 * hw);
     s.mask = (uint32_t*) p;       p += align16(4 * (size_t) H * ((W + 31) / 32));
+    s.zkeys_b = (uint32_t*) p;    p += align16(4 * hw);
     s.buckets = (float4*) p;
     return s;
 }
@@ -120,14 +122,14 @@ size_t scratch_bytes(int W, int H)
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
-           align16(4 * (size_t) H * ((W + 31) / 32)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
+           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
 
-__global__ void k_scratch_init(uint32_t* zkeys, size_t hw, int* tile_count, int n_tiles, int* hole_count)
+__global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, int* tile_count, int n_tiles, int* hole_count)
 {
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t i = gtid; i < hw; i += stride) zkeys[i] = KBE_ZKEY_EMPTY;
+    for (size_t i = gtid; i < hw; i += stride) { zkeys[i] = KBE_ZKEY_EMPTY; if (zkeys_b) zkeys_b[i] = KBE_ZKEY_EMPTY; }
     for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
     if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; }
 }
@@ -349,6 +351,8 @@ struct TileArgs {
     const int* tile_count;
     const float4* buckets;
     int tiles_x, tiles_y;
+    uint32_t* zkeys_clear;  // optional: the OTHER z-buffer, whose pixels of this tile are reset here (and this tile's bucket counter)
+    int* tile_count_clear;
     uint8_t* frame;         // [H,W,3]
     float* depth;           // [H*W]
     uint32_t* mask;         // [H][ceil(W/32)]
@@ -802,6 +806,19 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
     }
 
     tile_epilogue(a, L, acc, tile, x0, y0);
+    // Consecutive frames of a video alternate between two z-buffers: this launch leaves the OTHER one empty for the next
+    // frame's projection (a tile's pixels of the buffer in use are still being read by its neighbours' halos, so a launch
+    // cannot clear its own), and its own bucket counter (nobody else reads it).  That takes the z-buffer / bucket reset
+    // -- a launch of its own riding in k_fill_holes for a frame rendered alone -- out of the scatter.
+    if (a.zkeys_clear) {
+        if (tid == 0) a.tile_count_clear[tile * CNT_STRIDE] = 0;
+#pragma unroll
+        for (int m = 0; m < PIX_PER_THREAD; m++) {
+            const int q = tid + m * TILE_THREADS;
+            const int ly = q / TW, lx = q - ly * TW;
+            if (x0 + lx < W && y0 + ly < H) a.zkeys_clear[__umul24((uint32_t) (y0 + ly), (uint32_t) W) + (uint32_t) (x0 + lx)] = KBE_ZKEY_EMPTY;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1930,7 +1947,7 @@ int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
 {
     KBE_REQUIRE(scratch && W > 0 && H > 0 && ((uintptr_t) scratch & 15) == 0, "kbe_frame_scratch_init: bad arguments");
     const Scratch sc = carve(scratch, W, H);
-    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, (hipStream_t) stream, sc.zkeys, (size_t) W * H, sc.tile_count,
+    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, (hipStream_t) stream, sc.zkeys, sc.zkeys_b, (size_t) W * H, sc.tile_count,
                        sc.tiles_x * sc.tiles_y, sc.hole_count);
     return launched("kbe_frame_scratch_init");
 }
@@ -1950,9 +1967,13 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     const int n_tiles = sc.tiles_x * sc.tiles_y;
     int rc = KBE_OK;
 
+    // which z-buffer this frame splats into, and whether its tile launch clears the other one (include/kbe.h)
+    const bool alternate = (stages & (KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B)) != 0;
+    uint32_t* const zk_use = (stages & KBE_STAGE_ZBUF_B) ? sc.zkeys_b : sc.zkeys;
+    uint32_t* const zk_other = (stages & KBE_STAGE_ZBUF_B) ? sc.zkeys : sc.zkeys_b;
     if (stages & KBE_STAGE_PROJECT) {
         ProjectArgs p;
-        p.points = points; p.N = N; p.cam = cam; p.zkeys = sc.zkeys; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
+        p.points = points; p.N = N; p.cam = cam; p.zkeys = zk_use; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
         p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
         p.raster_w = 0; p.raster_n = 0;
         p.dense = (size_t) N > 2 * (size_t) W * H;
@@ -1970,7 +1991,8 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         TileArgs a;
         a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
         if (N == 0) a.points = a.image = a.depth_in = (const float*) sc.zkeys;     // never dereferenced for a record, but never NULL
-        a.zkeys = sc.zkeys; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+        a.zkeys = zk_use; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+        a.zkeys_clear = alternate ? zk_other : nullptr; a.tile_count_clear = sc.tile_count;
         a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox; a.coarse = sc.coarse;
         a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
         hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
@@ -1985,7 +2007,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
                            (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y, 1, (int*) nullptr);
+                           sc.coarse, sc.tiles_x, sc.tiles_y, alternate ? 0 : 1, (int*) nullptr);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -2076,7 +2098,7 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
     hipLaunchKernelGGL(k_tiles_nc, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
     if ((rc = launched("kbe_render_pointcloud_tiled/tiles"))) return rc;
     // leave the scratch clean (z-buffer, bucket counters)
-    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, s, sc.zkeys, (size_t) W * H, sc.tile_count, n_tiles, sc.hole_count);
+    hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, s, sc.zkeys, (uint32_t*) nullptr, (size_t) W * H, sc.tile_count, n_tiles, sc.hole_count);
     return launched("kbe_render_pointcloud_tiled/reset");
 }
 
@@ -2172,10 +2194,17 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                                         (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
                                         KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags, crop ? rect : nullptr, lane_frames[l]++ & 1,
                                         (kbe_stream_t) ls[l]);
-        else
+        else {
+            // a lane's frames alternate between the two z-buffers (A, B, A, ...), each clearing the other's in its tile
+            // launch; a lane's LAST frame, if it falls on A, takes the stand-alone form (A cleared by its fill launch), so
+            // that every call leaves A empty -- B is always cleared before it is used
+            const int k = lane_frames[l]++;
+            const bool last_of_lane = i + lanes >= n_frames;
+            const int zflags = (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_lane ? 0 : KBE_STAGE_ZBUF_A);
             rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                         KBE_VIDEO_STAGES | fill_flags, crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
+                                         KBE_VIDEO_STAGES | fill_flags | zflags, crop ? rect : nullptr, raster_w, raster_n, (kbe_stream_t) ls[l]);
+        }
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
         return rc;
     };

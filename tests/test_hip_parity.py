@@ -333,6 +333,39 @@ def test_native_frame_loop_equals_per_frame_calls(K):
         assert np.array_equal(other, a), 'hand-off batch=%d' % batch
 
 
+@pytest.mark.parametrize('lanes', ['1', '2', '4'])
+@pytest.mark.parametrize('n_frames', [1, 2, 5, 8])
+def test_bucket_route_video_alternates_its_z_buffers(K, monkeypatch, lanes, n_frames):
+    """On the bucket route consecutive frames of a lane alternate between two z-buffers, each frame's tile launch
+    clearing the other's (no reset pass); whatever the number of frames and lanes, every frame must equal the frame
+    rendered on its own, and a stand-alone frame rendered AFTER the video must find its z-buffer empty."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '0')
+    monkeypatch.setenv('KBE_LANES', lanes)
+    settings, oc = _scene((160, 224), 8)
+    settings = dict(settings, dblSteps=[i / max(n_frames - 1, 1) for i in range(n_frames)])
+    cams = common.frame_cameras(settings, oc)
+    state = common._prepared_cloud(K, oc)
+    assert not state['fused']
+    alone = np.stack([K.render_frame(state, sh, f, oc['dblBaseline']).cpu().numpy() for f, sh in cams])
+    for _ in range(2):                                                      # twice: the second video starts from the first one's leftovers
+        video = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+        d = np.abs(video.astype(np.int32) - alone.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        again = K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy()
+        d = np.abs(again.astype(np.int32) - alone[0].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    # the flags by hand: A, B, A, B then a stand-alone frame
+    zp = torch.empty(160 * 224, device='cuda')
+    ref = torch.empty_like(zp)
+    K.render_frame(state, cams[-1][1], cams[-1][0], oc['dblBaseline'], zee_pre_f32=ref, stages=7)
+    for k in range(4):
+        K.render_frame(state, cams[-1][1], cams[-1][0], oc['dblBaseline'], zee_pre_f32=zp, stages=7 | (256 if k & 1 else 128))
+        assert torch.equal(zp.view(torch.int32), ref.view(torch.int32)), 'z-buffer of alternating frame %d' % k
+    K.render_frame(state, cams[-1][1], cams[-1][0], oc['dblBaseline'], zee_pre_f32=zp, stages=7)
+    assert torch.equal(zp.view(torch.int32), ref.view(torch.int32))
+
+
 @pytest.mark.parametrize('size', [(50, 37), (33, 64)])
 def test_frame_hand_off_with_unaligned_frame_sizes(K, size):
     """W*H*3 not a multiple of 16: the frames of a video start at unaligned host addresses (k_deliver's byte path)."""
