@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 3
+#define KBE_ABI_VERSION 4
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -182,6 +182,11 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_FILL_PER_LANE 8
 #define KBE_STAGE_FILL_PER_HALFWAVE 16
 #define KBE_STAGE_FILL_BY_COUNT 32
+/* with _PER_LANE or _BY_COUNT: frames with very many holes (>= ~49 k; no inpainting: a dolly zoom, a raw cloud) first get a
+ * per-pixel table of the Chebyshev distance to the nearest valid pixel (one more small launch, k_hole_dist; it returns at
+ * once when the frame has fewer holes), and a ray at distance D takes D - 1 steps at once -- the same positions are
+ * tested in the end, the result is identical */
+#define KBE_STAGE_FILL_DIST 512
 /* kbe_render_frame_stages: the scratch holds two z-buffers, A and B.  Without these flags a frame stands alone: it splats
  * into A and its fill launch resets A and the bucket counters.  Consecutive frames of a video alternate instead:
  * _ZBUF_A = splat into A, the TILE launch clears B (and the bucket counters); _ZBUF_B = splat into B, the tile launch
@@ -267,11 +272,12 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
 #define KBE_MAX_LANES 8
 KBE_API size_t kbe_video_scratch_stride(int W, int H);
 KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
+#define KBE_VIDEO_FILL_DIST 1        /* kbe_render_video flags: KBE_STAGE_FILL_DIST for every frame */
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
-                             int raster_w, int raster_n, const void* packed, double cloud_focal, kbe_stream_t stream,
-                             kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams);
+                             int raster_w, int raster_n, const void* packed, double cloud_focal, int flags,
+                             kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams);
 
 /* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where
  * point i of points[B,3,N] + shift[B,3] (a DEVICE array, the tensorShift of :690) owns the pixel its z-splat

@@ -24,7 +24,7 @@ SYMBOLS = (
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
@@ -327,12 +327,16 @@ class HipKernels:
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
+        # hole fill with the distance table (KBE_STAGE_FILL_DIST): for clouds without appended points (no inpainting: dolly,
+        # raw clouds), whose frames have tens to hundreds of thousands of holes; KBE_FILL_DIST=1 / 0 forces it on / off
+        mode = os.environ.get('KBE_FILL_DIST', 'auto')
+        flags = int(state['N'] <= W * H) if mode == 'auto' else int(mode != '0')
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
                                               _ptr(state['packed'], torch.uint8) if state.get('fused') else None, _d(state['cloud_focal']),
-                                              _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
+                                              _i(flags), _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
         return host_out
 
     def generate_mask_raw(self, points, shift, W, H, focal, baseline, want_tables=False):

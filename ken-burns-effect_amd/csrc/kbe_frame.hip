@@ -65,6 +65,9 @@ namespace {
 #define KBE_BUCKET_FACTOR 12
 #endif
 constexpr int TW = KBE_TILE_W, TH = KBE_TILE_H;     // target tile owned by one workgroup
+// strip tables of the hole fill (k_hole_dist): per fill direction, W + H + 8 lines of (lo, hi); built from the extents of
+// up to STRIP_TILES tile rows / columns
+constexpr int STRIP_TILES = 512;
 constexpr int KW = TW + 2, KH = TH + 2;             // tile + the 1-px halo whose z the degrid reads
 constexpr int BW = TW + 1, BH = TH + 1;             // bins: north-west corners x0-1 .. x0+TW-1, y0-1 .. y0+TH-1
 constexpr int TILE_THREADS = KBE_TILE_THREADS;
@@ -83,6 +86,9 @@ static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >
 struct Scratch {                            // carve-out of the caller's scratch allocation
     uint32_t* zkeys;        // [H*W]  z-buffer as order-preserving keys; KBE_ZKEY_EMPTY between frames
     uint32_t* zkeys_b;      // [H*W]  second z-buffer: consecutive frames of a video alternate, each clearing the other's in its tile launch
+    uint8_t* dist;          // [H*W]  Chebyshev distance to the nearest valid pixel, capped (frames with very many holes: k_hole_dist)
+    float2* strips;         // [16][W + H + 8]  per fill direction and line across the image: where along it valid pixels can be (k_hole_dist)
+    uint8_t* dist_blocks;   // [tiles_y * TH / 8][tiles_x * TW / 8]  the same distance between 8 x 8 blocks, in blocks
     int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
     int* hole_count;        // [1]
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
@@ -113,6 +119,9 @@ Scratch carve(void* base, int W, int H)
     s.depth = (float*) p;         p += align16(4 * hw);
     s.mask = (uint32_t*) p;       p += align16(4 * (size_t) H * ((W + 31) / 32));
     s.zkeys_b = (uint32_t*) p;    p += align16(4 * hw);
+    s.dist = (uint8_t*) p;        p += align16(hw);
+    s.strips = (float2*) p;       p += align16(8 * 16 * (size_t) (W + H + 8));
+    s.dist_blocks = (uint8_t*) p; p += align16(n_tiles * (TW / 8) * (TH / 8));
     s.buckets = (float4*) p;
     return s;
 }
@@ -122,7 +131,7 @@ size_t scratch_bytes(int W, int H)
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
-           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + n_tiles * BUCKET_STRIDE * sizeof(float4);
+           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + align16(hw) + align16(8 * 16 * (size_t) (W + H + 8)) + align16(n_tiles * (TW / 8) * (TH / 8)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
 
@@ -1656,6 +1665,323 @@ __device__ __forceinline__ void fill_hole_serial(int px, const float* __restrict
     if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + s];
 }
 
+// ---------------------------------------------------------------------------------------
+// Frames with very many holes (no inpainting: a dolly zoom, common.py:217, or a raw cloud): most of a ray's steps cross
+// empty space, and with the block-level skips the cost was in the last 8-16 single steps of every ray in front of the
+// rim (measured: 27 eight-step batches per hole).  k_hole_dist gives every pixel its Chebyshev distance D to the nearest
+// valid pixel (0 = valid, capped at DIST_CAP); a ray at a hole with distance D can take D - 1 steps at once and look
+// only at where it lands: a step moves at most 1 pixel per axis and rounding a position adds at most 1, so the first
+// D - 2 positions are holes for sure.  Same fp32 sums (:876-889), same positions tested in the end, no mask look-ups.
+// The table is D iterations of a 3 x 3 dilation of the validity bitmask in LDS (32 pixels per word), the distance =
+// the number of iterations a pixel's bit stayed clear, counted in bit planes.
+// ---------------------------------------------------------------------------------------
+constexpr int DIST_CAP = 31;
+constexpr int DT_W = 64, DT_H = 32;                 // interior of one workgroup: 2 words x 32 rows
+constexpr int DT_ROWS = DT_H + 2 * DIST_CAP, DT_WORDS = 4;      // + halo: 31 rows above / below, one word left / right
+static_assert(DIST_CAP <= 32 && DT_W == 64, "the halo is one 32-pixel word on each side");
+
+// Strip tables.  A ray of direction u through a hole p stays within 0.75 pixels of the line through p (positions are
+// rounded per axis; the fp32 sums drift by < 0.03 over 1000 steps), so the only valid pixels it can ever meet lie in the
+// strip of lines c in [b - 1, b + 2), b = floor(c(p)), c(q) = n . q the coordinate across the direction.  Per direction
+// and b, (lo, hi) bound the coordinate t(q) = u . q along the direction over every valid pixel of that strip -- or rather
+// over a superset of them: the x-extent of each tile row (the y-extent of each tile column for the flat directions), from
+// the tiles' boxes.  The end walking towards -u meets nothing once lo > t + 1, the end towards +u once hi < t - 1: the
+// direction is skipped (common.py:880-885, 891-896) without walking to the image border.  A zoomed-out frame is mostly
+// border around a convex patch of valid pixels; outside a convex patch NO direction has valid pixels on both sides.
+// Measured on the last frame of the dolly bench (266 k holes inside the box of valid pixels): 1.7 of a hole's 16 directions
+// complete, 4.5 pass this test; pixel steps per hole 6811 -> 560 (tools/strip_proto.c, against brute-force walks: no
+// direction that completes is ever skipped).
+constexpr float STRIP_MARGIN = 1.0f;
+__host__ __device__ __forceinline__ int strip_bins(int W, int H) { return W + H + 8; }
+// c(q) = -uy x + ux y over the image starts at -(max(0, uy W) + max(0, -ux H)); + 2 keeps b - 1 non-negative
+__device__ __forceinline__ int strip_offset(float ux, float uy, int W, int H)
+{
+    return (int) ceilf(fmaxf(0.0f, uy * (float) W) + fmaxf(0.0f, -ux * (float) H)) + 2;
+}
+
+__device__ void build_strips(const int4* __restrict__ bbox, int tiles_x, int tiles_y, int W, int H, float ux, float uy, int first_bin,
+                             float2* __restrict__ out)
+{
+    __shared__ int s_ext[4][STRIP_TILES];           // per tile row: min x, max x; per tile column: min y, max y
+    const int tid = threadIdx.x;
+    for (int i = tid; i < STRIP_TILES; i += blockDim.x) { s_ext[0][i] = 1 << 30; s_ext[1][i] = -1; s_ext[2][i] = 1 << 30; s_ext[3][i] = -1; }
+    __syncthreads();
+    for (int t = tid; t < tiles_x * tiles_y; t += blockDim.x) {
+        const int4 bb = bbox[t];
+        if (bb.z < bb.x) continue;                              // a tile without a valid pixel
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        atomicMin(&s_ext[0][ty], bb.x); atomicMax(&s_ext[1][ty], bb.z);
+        atomicMin(&s_ext[2][tx], bb.y); atomicMax(&s_ext[3][tx], bb.w);
+    }
+    __syncthreads();
+    const int b = first_bin + tid;
+    if (b >= strip_bins(W, H)) return;
+    const float c0 = (float) (b - strip_offset(ux, uy, W, H)) - STRIP_MARGIN, c1 = c0 + 1.0f + 2.0f * STRIP_MARGIN;
+    float lo = INFINITY, hi = -INFINITY;
+    const bool steep = fabsf(uy) >= fabsf(ux);                  // the line crosses every row once: walk the tile rows
+    const int n = steep ? tiles_y : tiles_x;
+    const float ua = steep ? ux : uy, ub = steep ? uy : ux;     // a = the coordinate along a row (column), b = across
+    const float inv = 1.0f / ub;
+    for (int i = 0; i < n; i++) {
+        const int e0 = s_ext[steep ? 0 : 2][i], e1 = s_ext[steep ? 1 : 3][i];
+        if (e1 < 0) continue;
+        const float b0 = (float) (i * (steep ? TH : TW)), b1 = b0 + (float) ((steep ? TH : TW) - 1);
+        // steep: c = -uy x + ux y  =>  x = (ux y - c) / uy;   flat: y = (c + uy x) / ux
+        const float v0 = steep ? (ua * b0 - c0) * inv : (c0 + ua * b0) * inv, v1 = steep ? (ua * b0 - c1) * inv : (c1 + ua * b0) * inv;
+        const float v2 = steep ? (ua * b1 - c0) * inv : (c0 + ua * b1) * inv, v3 = steep ? (ua * b1 - c1) * inv : (c1 + ua * b1) * inv;
+        float a0 = fminf(fminf(v0, v1), fminf(v2, v3)) - 0.01f, a1 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) + 0.01f;
+        a0 = fmaxf(a0, (float) e0); a1 = fminf(a1, (float) e1);
+        if (a0 > a1) continue;
+        // t = ux x + uy y = ua a + ub b over [a0, a1] x [b0, b1]
+        const float t0 = ua * a0 + ub * b0, t1 = ua * a0 + ub * b1, t2 = ua * a1 + ub * b0, t3 = ua * a1 + ub * b1;
+        lo = fminf(lo, fminf(fminf(t0, t1), fminf(t2, t3)));
+        hi = fmaxf(hi, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+    }
+    out[b] = make_float2(lo, hi);
+}
+
+// One workgroup's share of a distance table: the 64 x 32 bits at (64 bx, 32 by) of a bit grid given by load(row, word)
+// (0 outside the grid: nothing valid there), one byte per bit to out[row * pitch + col] for rows < n_rows, cols < n_cols.
+template <typename Load>
+__device__ __forceinline__ void dilate_distances(Load load, int bx, int by, int pitch, int n_rows, int n_cols, uint8_t* __restrict__ out)
+{
+    __shared__ uint32_t buf[2][DT_ROWS][DT_WORDS];
+    const int tid = threadIdx.x;
+    const int x0 = bx * DT_W, y0 = by * DT_H;
+    const int w0 = (x0 >> 5) - 1, r0 = y0 - DIST_CAP;
+    for (int i = tid; i < DT_ROWS * DT_WORDS; i += 256) {
+        const int r = i / DT_WORDS, w = i - r * DT_WORDS;
+        buf[0][r][w] = load(r0 + r, w0 + w);
+    }
+    // the owner of an interior word counts, in five bit planes, for how many iterations each of its 32 bits stayed clear
+    const bool owner = tid < DT_H * 2;
+    const int orow = DIST_CAP + (tid >> 1), ow = 1 + (tid & 1);
+    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+    __syncthreads();
+    int cur = 0;
+    for (int k = 0; k < DIST_CAP; k++) {
+        if (owner) {
+            uint32_t c = ~buf[cur][orow][ow], t;
+            t = p0 & c; p0 ^= c; c = t;
+            t = p1 & c; p1 ^= c; c = t;
+            t = p2 & c; p2 ^= c; c = t;
+            t = p3 & c; p3 ^= c; c = t;
+            p4 ^= c;
+        }
+        if (k + 1 < DIST_CAP) {
+            for (int i = tid; i < DT_ROWS * DT_WORDS; i += 256) {
+                const int r = i / DT_WORDS, w = i - r * DT_WORDS;
+                uint32_t v = 0;
+#pragma unroll
+                for (int dr = -1; dr <= 1; dr++) {
+                    const int rr = r + dr;
+                    if (rr < 0 || rr >= DT_ROWS) continue;
+                    const uint32_t m = buf[cur][rr][w];
+                    const uint32_t l = w > 0 ? buf[cur][rr][w - 1] : 0u, rt = w + 1 < DT_WORDS ? buf[cur][rr][w + 1] : 0u;
+                    v |= m | (m << 1) | (m >> 1) | (l >> 31) | (rt << 31);
+                }
+                buf[cur ^ 1][r][w] = v;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    if (owner) {
+        const int y = y0 + (tid >> 1), xb = x0 + (tid & 1) * 32;
+        if (y < n_rows && xb < n_cols) {
+            uint8_t* o = out + (size_t) y * pitch + xb;
+            const bool dwords = (pitch & 3) == 0 && xb + 32 <= n_cols;
+            for (int j = 0; j < 32; j += 4) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int bit = j + b;
+                    const uint32_t d = ((p0 >> bit) & 1u) | (((p1 >> bit) & 1u) << 1) | (((p2 >> bit) & 1u) << 2) | (((p3 >> bit) & 1u) << 3) | (((p4 >> bit) & 1u) << 4);
+                    packed |= d << (8 * b);
+                }
+                if (dwords) *(uint32_t*) (o + j) = packed;
+                else for (int b = 0; b < 4; b++) if (xb + j + b < n_cols) o[j + b] = (uint8_t) (packed >> (8 * b));
+            }
+        }
+    }
+}
+
+// grid: the 64 x 32-pixel blocks of the image, then -- in block rows of their own -- the blocks of the strip tables and
+// those of the coarse table (the same distance between 8 x 8-pixel blocks, from the tiles' `coarse` bits: where a
+// block is k >= 2 blocks from the nearest block with a valid pixel, every pixel of it is at least 8 (k - 1) + 1 pixels
+// from one -- jumps of up to 240 steps through empty space, looked up in LDS by the fill)
+__global__ void __launch_bounds__(256) k_hole_dist(const uint32_t* __restrict__ mask, int W, int H, uint8_t* __restrict__ dist,
+                                                   const int* __restrict__ hole_count, int min_holes,
+                                                   const int4* __restrict__ bbox, int tiles_x, int tiles_y, float2* __restrict__ strips, FillDirs dirs,
+                                                   const uint32_t* __restrict__ coarse, uint8_t* __restrict__ dist_blocks, int image_rows)
+{
+    if (*hole_count < min_holes) return;                        // few holes: the fill does not use the tables
+    if ((int) blockIdx.y >= image_rows) {
+        int si = ((int) blockIdx.y - image_rows) * (int) gridDim.x + (int) blockIdx.x;
+        const int bins = strip_bins(W, H), per_dir = (bins + 255) / 256;
+        if (si < 16 * per_dir) {
+            const int d = si / per_dir;
+            if (strips) build_strips(bbox, tiles_x, tiles_y, W, H, dirs.x[d], dirs.y[d], (si - d * per_dir) * 256, strips + (size_t) d * bins);
+            return;
+        }
+        si -= 16 * per_dir;
+        constexpr int CX = TW / 8, CY = TH / 8, TPW = 32 / CX;  // blocks per tile; tiles per 32-block word
+        const int cw = tiles_x * CX, ch = tiles_y * CY;
+        const int cgx = (cw + DT_W - 1) / DT_W, cgy = (ch + DT_H - 1) / DT_H;
+        if (si >= cgx * cgy) return;
+        const int cwpr = (cw + 31) >> 5;
+        dilate_distances([=](int r, int wi) -> uint32_t {
+            if (r < 0 || r >= ch || wi < 0 || wi >= cwpr) return 0u;
+            const int ty = r / CY, sub = r - ty * CY;
+            uint32_t word = 0;
+            for (int t = 0; t < TPW; t++) {
+                const int tx = wi * TPW + t;
+                if (tx < tiles_x) word |= ((coarse[ty * tiles_x + tx] >> (CX * sub)) & ((1u << CX) - 1u)) << (CX * t);
+            }
+            return word;
+        }, si % cgx, si / cgx, cw, ch, cw, dist_blocks);
+        return;
+    }
+    const int wpr = (W + 31) >> 5;
+    dilate_distances([=](int y, int wi) -> uint32_t { return (y >= 0 && y < H && wi >= 0 && wi < wpr) ? mask[(size_t) y * wpr + wi] : 0u; },
+                     (int) blockIdx.x, (int) blockIdx.y, W, H, W, dist);
+}
+
+// the extents the strip tables are built from: up to STRIP_TILES tile rows / columns
+inline bool strips_fit(const Scratch& sc) { return sc.tiles_x <= STRIP_TILES && sc.tiles_y <= STRIP_TILES; }
+
+void launch_hole_dist(hipStream_t s, const Scratch& sc, int W, int H, const int* hole_count, int min_holes, const FillDirs& dirs, const float2* strips)
+{
+    const int gx = (W + DT_W - 1) / DT_W, gy = (H + DT_H - 1) / DT_H;
+    const int cw = sc.tiles_x * (TW / 8), ch = sc.tiles_y * (TH / 8);
+    const int extra = 16 * ((strip_bins(W, H) + 255) / 256) + ((cw + DT_W - 1) / DT_W) * ((ch + DT_H - 1) / DT_H);
+    hipLaunchKernelGGL(k_hole_dist, dim3(gx, gy + (extra + gx - 1) / gx), dim3(256), 0, s, sc.mask, W, H, sc.dist, hole_count, min_holes,
+                       sc.bbox, sc.tiles_x, sc.tiles_y, (float2*) strips, dirs, sc.coarse, sc.dist_blocks, gy);
+}
+
+// m repeated fp32 additions a := a - u (or + u), exactly, in a few steps.  While a stays in one binade [2^e, 2^(e+1))
+// every value of the chain is a multiple of q = 2^(e-23), and each rounded sum moves a by the SAME amount R = u rounded to
+// a multiple of q: the exact sum lies between two neighbours of a's grid, and which one is nearer does not depend on a --
+// unless u sits exactly half-way between two multiples of q (a tie: round-to-even looks at a).  j such sums are a -/+ j R,
+// computed on the integer mantissa.  j is cut so that the chain, and one step beyond it on either side, stays inside the
+// binade (no sum is rounded on a finer or a coarser grid); across a binade boundary, for ties, below 1 and for the last
+// two steps the sums are added one at a time.  (tools/advance_check.c: against step-by-step sums, 24 M cases.)
+// `limit`: positions below -1 or above limit + 1 are outside the image for good (the ray is monotone), where the value
+// no longer matters: the direction is skipped (common.py:880-885).
+__device__ __forceinline__ float advance_exact(float a, float u, int m, bool subtract, float limit)
+{
+    if (u == 0.0f) return a;
+    while (m > 0) {
+        const uint32_t bits = __float_as_uint(a);
+        const int e = (int) (bits >> 23) - 127;
+        if (m >= 3 && a >= 1.0f && e <= 23) {
+            const float sc = ldexpf(u, 23 - e);                 // u / q, exact
+            const float r = rintf(sc);
+            if (fabsf(sc - r) != 0.5f) {
+                const int step = (int) r, mag = abs(step);
+                const int A = (int) ((bits & 0x7FFFFFu) | 0x800000u);       // a / q in [2^23, 2^24)
+                const bool down = subtract ? step > 0 : step < 0;
+                const int room_down = A - (1 << 23) - mag, room_up = (1 << 24) - 1 - mag - A;
+                const int room = down ? room_down : room_up, other = down ? room_up : room_down;
+                int j = (room > 0 && other >= 0 && mag > 0) ? (int) ((float) room / (float) mag) - 1 : 0;     // <= room / mag for sure
+                j = min(j, m);
+                if (j >= 1) {
+                    const int end = A + j * (down ? -mag : mag);
+                    a = __uint_as_float((bits & 0xFF800000u) | ((uint32_t) end & 0x7FFFFFu));
+                    m -= j;
+                    continue;
+                }
+            }
+        }
+        a = subtract ? a - u : a + u;
+        m--;
+        if (a < -1.0f || a > limit) break;
+    }
+    return a;
+}
+
+#if defined(KBE_FRAME_STATS)     // dev build only (tools/fill_stats.py)
+__device__ unsigned long long g_fill_stats[8];      // holes walked, directions walked, fine look-ups, coarse look-ups, -, directions cut by the bound, directions skipped, skipped before a step
+#define KBE_FILL_STAT(i, v) atomicAdd(&g_fill_stats[i], (unsigned long long) (v))
+#else
+#define KBE_FILL_STAT(i, v) ((void) 0)
+#endif
+
+// One coordinate of a ray end while it walks.  Fast mode (e >= 0): the coordinate is A 2^(e-23) with A in [2^23, 2^24),
+// and one fp32 addition of -/+ u moves A by `step` (advance_exact's argument, kept as state): m additions are one
+// multiply-add and one range test, the pixel a shift.  Invariant of the fast mode: A, and one step to either side of it,
+// inside the binade.  Slow mode (e < 0; A holds the float's bits): below 32, next to a binade boundary, or a tie --
+// single additions until the fast mode can be entered again.
+struct Axis { int A, step, e; };
+
+__device__ __forceinline__ bool axis_interior(int A, int mag) { return (unsigned) (A - (1 << 23) - mag) < (unsigned) ((1 << 23) - 2 * mag); }
+
+__device__ __forceinline__ Axis axis_enter(float f, float u, bool subtract)
+{
+    const uint32_t bits = __float_as_uint(f);
+    const int e = (int) (bits >> 23) - 127;
+    if (f >= 32.0f && e <= 22) {                                // |step| <= 2^18: m * step cannot overflow, 2 |step| < 2^23
+        const float sc = ldexpf(u, 23 - e);                     // u / q, exact
+        const float r = rintf(sc);
+        const int step = subtract ? -(int) r : (int) r;
+        const int A = (int) ((bits & 0x7FFFFFu) | 0x800000u);
+        if (fabsf(sc - r) != 0.5f && axis_interior(A, abs(step))) return Axis{ A, step, e };
+    }
+    return Axis{ (int) bits, 0, -1 };
+}
+
+__device__ __forceinline__ float axis_value(const Axis& ax)
+{
+    return ax.e >= 0 ? __uint_as_float(((uint32_t) (ax.e + 127) << 23) | ((uint32_t) ax.A & 0x7FFFFFu)) : __int_as_float(ax.A);
+}
+
+__device__ __forceinline__ int axis_pixel(const Axis& ax)      // (int) roundf(value): positive values round half up
+{
+    if (ax.e >= 0) { const int sh = 23 - ax.e; return (ax.A + (1 << (sh - 1))) >> sh; }
+    return (int) roundf(__int_as_float(ax.A));
+}
+
+// r pending additions, all at once if they end inside the binade (and the invariant holds at the end: everything in between
+// lies between two interior values)
+__device__ __forceinline__ void axis_jump(Axis& ax, int& r)
+{
+    if (ax.e >= 0) {
+        const int end = ax.A + r * ax.step;
+        if (axis_interior(end, abs(ax.step))) { ax.A = end; r = 0; }
+    }
+}
+
+// ... otherwise, typically in front of a binade boundary: as many as fit in front of it at once, four single additions in
+// fp32 (that is across), whatever mode the value is in then, and the rest at once if they fit now.  What is left stays
+// pending: the lane comes back in the next iteration of its loop.  Kept short on purpose -- in a wave of 64 some lane
+// is here in almost every iteration (9 % of the advances: an image has a binade boundary in its middle), and the wave
+// pays for its longest lane (a loop to completion here: 3/4 of the kernel's time).
+__device__ __forceinline__ void axis_catch_up(Axis& ax, int& r, float u, bool subtract, float limit)
+{
+    if (u == 0.0f) { r = 0; return; }                           // a + 0 = a
+    if (ax.e >= 0) {
+        const int mag = max(1, abs(ax.step));
+        const int room = ax.step < 0 ? ax.A - (1 << 23) - mag : (1 << 24) - 1 - mag - ax.A;
+        const int j = min(r, (int) ((float) room * __builtin_amdgcn_rcpf((float) mag)) - 1);
+        if (j >= 1 && axis_interior(ax.A + j * ax.step, mag)) { ax.A += j * ax.step; r -= j; }      // the test is what counts, j only a guess
+    }
+    float f = axis_value(ax);
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (r > 0) { f = subtract ? f - u : f + u; r--; }       // :876-877 / :887-888
+    if (f < -1.0f || f > limit) r = 0;                          // outside the image for good: the value no longer matters
+    ax = axis_enter(f, u, subtract);
+    if (r > 0) axis_jump(ax, r);
+}
+
+constexpr unsigned long long FILL_NO_ENTRY = ~0ull;
+constexpr int FILL_MAX_STEPS = (1 << 14) - 1;
+enum { END_IDLE = 0, END_WALK = 1, END_HIT = 2, END_DEAD = 3 };
+
+__device__ __forceinline__ int swap_with_neighbour(int v)       // lanes 2i and 2i + 1 exchange v (all lanes active)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1, 0, 3, 2]
+}
+
 #ifndef KBE_FILL_BLOCK
 #define KBE_FILL_BLOCK 256
 #endif
@@ -1668,7 +1994,9 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
                                                     const int4* __restrict__ bbox, int fill_mode, const uint32_t* __restrict__ coarse,
-                                                    int tiles_x, int tiles_y, int reset_scatter_scratch, int* __restrict__ next_hole_count)
+                                                    int tiles_x, int tiles_y, int reset_scatter_scratch, int* __restrict__ next_hole_count,
+                                                    const uint8_t* __restrict__ dist, const float2* __restrict__ strips,
+                                                    const uint8_t* __restrict__ dist_blocks)
 {
     // leave the scratch ready for the next frame.  Bucket path: empty z-buffer, empty buckets.  Fused path: it has
     // neither; its hole counters alternate between frames, and this launch zeroes the one the NEXT frame will count in
@@ -1709,7 +2037,197 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
         // position's block; if that neighbourhood has no valid pixel the eight steps cannot hit one and are taken at
         // once (16 additions, the same fp32 sums, no rounding of the positions in between, no mask look-ups).
         if ((int) (blockIdx.x * blockDim.x) >= n) return;       // no hole for this block in this schedule either
-        __shared__ uint32_t s_blk[COARSE_WORDS], s_near[COARSE_WORDS];
+        __shared__ uint32_t s_pool[2 * COARSE_WORDS];           // the coarse maps of either schedule
+        if (dist) {
+            // With the tables of k_hole_dist (launched in front of this kernel for frames expected to have very many holes).
+            // A workgroup takes 256 holes at a time.
+            // (1) One lane per hole: the strip test of its 16 directions; the directions that pass -- 4.5 of 16 on the
+            //     dolly bench -- are queued in LDS.
+            // (2) One lane per END of a queued (hole, direction), neighbouring lanes the two ends; ONE loop for everything:
+            //     an iteration is one advance (exactly the fp32 sums of :876-889, on the integer mantissa: struct Axis) and
+            //     one look-up -- the coarse table in LDS, and where that says "near" the fine table -- or, for lanes whose
+            //     direction is decided, waiting until enough lanes wait to fetch new work together.  A direction is
+            //     decided when one end leaves the image or its strip (skipped, :880-885 / :891-896), when both ends stand on
+            //     valid pixels (it enters the hole's contest, :898-900, with an LDS atomicMin: the fp32 length of the span in
+            //     the high word -- positive floats order like their bits -- then the direction: the reference keeps the
+            //     FIRST direction of the shortest length, `best > dd` is strict; then the step counts of the two ends),
+            //     or when its ends are already farther apart than a direction in the contest (they only move apart: it can
+            //     neither win nor tie).
+            // (3) One lane per hole: the winner's end points from its step counts, the fill.
+            // One lane per hole for everything left 3/4 of the lanes idle in every direction and chained ~100 dependent
+            // look-ups per lane (890 us per launch); loops nested per lane (per end, per jump) ran at ~20 % lane use.
+            constexpr int FB = KBE_FILL_BLOCK;
+            static_assert(FB % 64 == 0 && FB * 16 <= 65536, "queue entries are 16 bits");
+            __shared__ unsigned long long s_key[FB];
+            __shared__ uint16_t s_queue[FB * 16];
+            __shared__ int s_px[FB], s_wave_n[FB / 64], s_next;
+            __shared__ uint8_t s_m0[FB];
+            __shared__ float s_dir[2][16];
+            __shared__ int s_off[16];
+            const int cw = tiles_x * (TW / 8);
+            const int c_bytes = cw * tiles_y * (TH / 8);
+            const bool in_lds = c_bytes <= (int) sizeof(s_pool);
+            if (in_lds) for (int i = threadIdx.x; i < (c_bytes + 3) / 4; i += blockDim.x) s_pool[i] = ((const uint32_t*) dist_blocks)[i];
+            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+            if (tid < 16) { s_dir[0][tid] = dirs.x[tid]; s_dir[1][tid] = dirs.y[tid]; s_off[tid] = strip_offset(dirs.x[tid], dirs.y[tid], W, H); }
+            const int bins = strip_bins(W, H);
+            const size_t HW = (size_t) W * H;
+            const bool is_b = lane & 1;                         // the end walking towards +u
+            for (int base = blockIdx.x * FB; base < n; base += gridDim.x * FB) {
+                __syncthreads();                                // the tables are loaded / the previous batch is done with the LDS arrays
+                // (1)
+                const int h = base + tid;
+                int px = -1, x = 0, y = 0;
+                uint32_t pass = 0;
+                if (h < n) {
+                    px = holes[h];
+                    y = px / W; x = px - y * W;
+                    // outside the rectangle to be filled / outside the box of the valid pixels: every direction is skipped
+                    if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1 || x < bx0 || x > bx1 || y < by0 || y > by1) px = -1;
+                }
+                if (px >= 0) {
+                    KBE_FILL_STAT(0, 1);
+                    pass = 0xFFFFu;
+                    if (strips) {
+                        pass = 0;
+#pragma unroll
+                        for (int d = 0; d < 16; d++) {
+                            const float ddx = s_dir[0][d], ddy = s_dir[1][d];
+                            const float c = ddx * (float) y - ddy * (float) x, t = ddx * (float) x + ddy * (float) y;
+                            const float2 lh = strips[(size_t) d * bins + ((int) floorf(c) + s_off[d])];
+                            if (!(lh.x > t + STRIP_MARGIN || lh.y < t - STRIP_MARGIN)) pass |= 1u << d;     // valid pixels on both sides
+                        }
+                    }
+                    if (pass) {
+                        const int c_here = in_lds ? ((const uint8_t*) s_pool)[(y >> 3) * cw + (x >> 3)] : dist_blocks[(y >> 3) * cw + (x >> 3)];
+                        s_m0[tid] = (uint8_t) (c_here >= 2 ? 8 * (c_here - 1) : max(1, (int) dist[(uint32_t) px] - 1));
+                    }
+                }
+                s_px[tid] = px;
+                s_key[tid] = FILL_NO_ENTRY;
+                if (tid == 0) s_next = 0;
+                const int mine = __popc(pass);
+                int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                if (lane == 63) s_wave_n[wave] = incl;
+                __syncthreads();
+                int at = incl - mine, total = 0;
+                for (int w = 0; w < FB / 64; w++) { if (w < wave) at += s_wave_n[w]; total += s_wave_n[w]; }
+                for (uint32_t m = pass; m; m &= m - 1) s_queue[at++] = (uint16_t) ((tid << 4) | (__ffs(m) - 1));
+                __syncthreads();
+                // (2)
+                {
+                    int st = END_IDLE, rx = 0, ry = 0, k = 0, ix = 0, iy = 0, slot = 0, d = 0;
+                    float ux = 0.0f, uy = 0.0f, bound = 0.0f;
+                    Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
+                    for (;;) {
+                        // the two ends of a direction look at each other
+                        const int pst = swap_with_neighbour(st), pix = swap_with_neighbour(ix), piy = swap_with_neighbour(iy), pk = swap_with_neighbour(k);
+                        if (st != END_IDLE) {
+                            if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
+                            else {
+                                const float ex = (float) (ix - pix), ey = (float) (iy - piy);
+                                const float dd = sqrtf(ex * ex + ey * ey);                      // :898
+                                if (st == END_HIT && pst == END_HIT) {
+                                    const int ka = is_b ? pk : k, kb = is_b ? k : pk;
+                                    if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
+                                        atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
+                                                                ((unsigned long long) ka << 14) | (unsigned long long) kb);
+                                    st = END_IDLE;
+                                } else if (dd > __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1])) {       // no entry yet: NaN, never true
+                                    KBE_FILL_STAT(5, is_b ? 0 : 1);
+                                    st = END_IDLE;
+                                }
+                            }
+                        }
+                        // new work, for a quarter of the wave at a time (fetching runs at the pace of its slowest lane)
+                        const unsigned long long idle = __ballot(st == END_IDLE);
+                        if (idle) {
+                            const int next = *(const volatile int*) &s_next;
+                            if (next >= total) { if (idle == ~0ull) break; }
+                            else if (__popcll(idle) >= 16 || idle == ~0ull) {
+                                const int n_pairs = __popcll(idle) >> 1;
+                                int first = 0;
+                                if (lane == (int) __ffsll((long long) idle) - 1) first = atomicAdd(&s_next, n_pairs);
+                                first = __shfl(first, (int) __ffsll((long long) idle) - 1);
+                                const int q = first + (__popcll(idle & ((1ull << lane) - 1ull)) >> 1);
+                                if (st == END_IDLE && q < total) {
+                                    const int e = s_queue[q];
+                                    slot = e >> 4; d = e & 15;
+                                    const int qpx = s_px[slot];
+                                    iy = qpx / W; ix = qpx - iy * W;
+                                    ux = s_dir[0][d]; uy = s_dir[1][d];
+                                    bound = is_b ? INFINITY : -INFINITY;
+                                    if (strips) {
+                                        const float2 lh = strips[(size_t) d * bins + ((int) floorf(ux * (float) iy - uy * (float) ix) + s_off[d])];
+                                        bound = is_b ? lh.y : lh.x;
+                                    }
+                                    X = axis_enter((float) ix, ux, !is_b);
+                                    Y = axis_enter((float) iy, uy, !is_b);
+                                    rx = ry = k = s_m0[slot];
+                                    st = END_WALK;
+                                    KBE_FILL_STAT(1, is_b ? 0 : 1);
+                                }
+                            }
+                        }
+#if defined(KBE_FRAME_STATS)
+                        { const unsigned long long w = __ballot(st == END_WALK); if (lane == 0) { KBE_FILL_STAT(6, 1); KBE_FILL_STAT(7, __popcll(w)); } }
+#endif
+                        // one advance, one look-up
+                        if (st == END_WALK) {
+                            axis_jump(X, rx);
+                            axis_jump(Y, ry);
+                            if (rx | ry) {                      // one of them did not get there: one catch-up, for one axis
+                                const bool on_x = rx > 0;
+                                Axis a = on_x ? X : Y;
+                                int r = on_x ? rx : ry;
+                                KBE_FILL_STAT(4, 1);
+                                axis_catch_up(a, r, on_x ? ux : uy, !is_b, on_x ? (float) W : (float) H);
+                                if (on_x) { X = a; rx = r; } else { Y = a; ry = r; }
+                            }
+                            if ((rx | ry) == 0) {
+                                ix = axis_pixel(X); iy = axis_pixel(Y);
+                                const float t = ux * (float) ix + uy * (float) iy;
+                                int m = 0;
+                                if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
+                                else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
+                                else {
+                                    const int ci = (iy >> 3) * cw + (ix >> 3);
+                                    const int c = in_lds ? ((const uint8_t*) s_pool)[ci] : dist_blocks[ci];
+                                    KBE_FILL_STAT(3, 1);
+                                    if (c >= 2) m = 8 * (c - 1);            // a hole, and so are the next 8 (c - 1) - 1 positions
+                                    else {
+                                        const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
+                                        KBE_FILL_STAT(2, 1);
+                                        if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
+                                        else m = max(1, dn - 1);
+                                    }
+                                }
+                                rx = ry = m;
+                                k += m;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                // (3)
+                const unsigned long long key = s_key[tid];
+                if (px >= 0 && key != FILL_NO_ENTRY) {
+                    const int d = (int) (key >> 28) & 15, ka = (int) (key >> 14) & FILL_MAX_STEPS, kb = (int) key & FILL_MAX_STEPS;
+                    const float ddx = s_dir[0][d], ddy = s_dir[1][d];
+                    const int sax = (int) roundf(advance_exact((float) x, ddx, ka, true, INFINITY)), say = (int) roundf(advance_exact((float) y, ddy, ka, true, INFINITY));
+                    const int sbx = (int) roundf(advance_exact((float) x, ddx, kb, false, INFINITY)), sby = (int) roundf(advance_exact((float) y, ddy, kb, false, INFINITY));
+                    int sx = sax, sy = say;
+                    if (depth[(size_t) say * W + sax] < depth[(size_t) sby * W + sbx]) { sx = sbx; sy = sby; }     // :904 the farther (background) end
+                    const size_t src = (size_t) sy * W + sx, o = (size_t) px;
+                    frame[o * 3] = frame[src * 3]; frame[o * 3 + 1] = frame[src * 3 + 1]; frame[o * 3 + 2] = frame[src * 3 + 2];
+                    if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + src];
+                }
+            }
+            return;
+        }
+        uint32_t* s_blk = s_pool, *s_near = s_pool + COARSE_WORDS;
         constexpr int CX = TW / 8, CY = TH / 8;                 // coarse blocks per tile
         const int c_rows = tiles_y * CY, c_wpr = (tiles_x * CX + 31) >> 5;
         const bool skip_ok = c_rows * c_wpr <= COARSE_WORDS;
@@ -2004,10 +2522,17 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        const uint8_t* dist = nullptr;
+        const float2* strips = nullptr;
+        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT))) {
+            strips = strips_fit(sc) ? sc.strips : nullptr;
+            launch_hole_dist(s, sc, W, H, sc.hole_count, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
+            dist = sc.dist;
+        }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
                            (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y, alternate ? 0 : 1, (int*) nullptr);
+                           sc.coarse, sc.tiles_x, sc.tiles_y, alternate ? 0 : 1, (int*) nullptr, dist, strips, sc.dist_blocks);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -2058,16 +2583,29 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
         const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        const uint8_t* dist = nullptr;
+        const float2* strips = nullptr;
+        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT))) {
+            strips = strips_fit(sc) ? sc.strips : nullptr;
+            launch_hole_dist(s, sc, W, H, count_now, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
+            dist = sc.dist;
+        }
         hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, count_now, sc.depth, sc.mask, W, H, dirs, rect,
                            frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
                            (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y, 0, parity >= 0 ? count_next : (int*) nullptr);
+                           sc.coarse, sc.tiles_x, sc.tiles_y, 0, parity >= 0 ? count_next : (int*) nullptr, dist, strips, sc.dist_blocks);
         rc = launched("kbe_render_frame_fused/fill");
     }
     return rc;
 }
 
 #if defined(KBE_FRAME_STATS)
+extern "C" __attribute__((visibility("default"))) int kbe_debug_fill_stats(unsigned long long* out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fill_stats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_fill_stats), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int kbe_debug_frame_stats(unsigned long long* out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_frame_stats), 8 * sizeof(unsigned long long));
@@ -2106,7 +2644,8 @@ constexpr int KBE_VIDEO_STAGES = KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, const void* packed,
-                     double cloud_focal, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams)
+                     double cloud_focal, int flags, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
+                     const kbe_stream_t* lane_streams)
 {
     KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64 && (!packed || cloud_focal > 0.0),
                 "kbe_render_video: bad arguments");
@@ -2187,7 +2726,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     int lane_frames[KBE_MAX_LANES] = {};
     auto render = [&](int i, int l, uint8_t* out) {
         uint8_t* raw = stage + (size_t) l * fb;
-        const int fill_flags = lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0;
+        const int fill_flags = lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? (KBE_STAGE_FILL_BY_COUNT | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0)) : 0;
         int rc;
         if (packed)         // the fused scatter on the packed cloud; a lane's frames alternate between its two hole counters
             rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i,

@@ -644,6 +644,66 @@ def test_denser_than_raster_cloud_matches_oracle(K, oracle):
     assert d.max() <= 1 and (d > 0).mean() < 2e-3
 
 
+@pytest.mark.parametrize('size,dolly,kind', [((512, 512), True, 'smooth'), ((200, 312), False, 'noise'), ((1024, 1024), True, 'smooth')])
+def test_hole_fill_schedules_on_the_same_unfilled_frame_are_byte_identical(K, size, dolly, kind):
+    """The three hole-fill schedules (one half-wave per hole; one lane per hole with block skips; one lane per hole with the
+    distance table of k_hole_dist) run on the SAME un-filled frame: a fill never reads a hole, so it can be repeated on
+    copies, and the copies must agree byte for byte -- the search is the reference's (:838-924) in all three."""
+    from ken_burns_effect_amd import common
+    settings, oc = _scene(size, 5, kind, dolly)
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], size[1], size[0])
+    n_holes = 0
+    for focal, shift3 in common.frame_cameras(settings, oc):
+        unfilled = K.render_frame(state, shift3, focal, oc['dblBaseline'], stages=3, fused=False).clone()
+        results = []
+        for mode in (16, 8, 8 | 512, 32 | 512):                     # half-wave, lane, lane + distance table, by count + distance table
+            buf = unfilled.clone()
+            K.render_frame(state, shift3, focal, oc['dblBaseline'], out=buf, stages=4 | mode, fused=False)
+            results.append(buf)
+        n_holes += int((results[0] != unfilled).any(dim=2).sum())
+        for r in results[1:]:
+            assert torch.equal(r, results[0])
+    assert n_holes > 1000
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_hole_fill_schedules_agree_between_islands_of_valid_pixels(K, seed):
+    """The tables of the distance-table fill (strips of lines per direction, distances between pixels and between 8 x 8
+    blocks) on frames whose valid pixels are islands -- discs, bars and single pixels, image borders included -- with empty
+    space and other islands between them: rays that pass islands, graze them, leave the image.  Every hole, every schedule:
+    byte-identical to the half-wave search, which has no tables."""
+    from ken_burns_effect_amd import synthetic
+    H, W = 600, 840
+    rng = np.random.default_rng(seed)
+    image, disp = synthetic.make_rgbd(H, W, seed, 'smooth')
+    depth = ((512.0 * 120) / (disp + 1e-7)).cuda()
+    yy, xx = np.mgrid[0:H, 0:W]
+    keep = np.zeros((H, W), bool)
+    for _ in range(14):                                             # discs
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(6, 90)
+        keep |= (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
+    for _ in range(6):                                              # thin bars, some touching the border
+        x0, y0 = int(rng.uniform(0, W - 200)), int(rng.uniform(0, H - 8))
+        keep[y0:y0 + int(rng.uniform(1, 6)), x0:x0 + int(rng.uniform(20, 200))] = True
+    keep |= rng.random((H, W)) < 0.0005                             # specks
+    keep[:, :3] |= rng.random((H, 3)) < 0.3
+    idx = torch.from_numpy(np.flatnonzero(keep)).cuda()
+    pts = K.depth_to_points(depth, 512.0).view(1, 3, -1)[:, :, idx].contiguous()
+    img = image.cuda().reshape(1, 3, -1)[:, :, idx].contiguous()
+    dep = depth.reshape(1, 1, -1)[:, :, idx].contiguous()
+    state = K.prepare_cloud(pts, img, dep, W, H, 512.0)
+    for shift3, focal in (([0.0, 0.0, 0.0], 512.0), ([30.0, -12.0, -60.0], 400.0)):
+        unfilled = K.render_frame(state, shift3, focal, 120, stages=3, fused=False).clone()
+        results = []
+        for mode in (16, 8, 8 | 512):
+            buf = unfilled.clone()
+            K.render_frame(state, shift3, focal, 120, out=buf, stages=4 | mode, fused=False)
+            results.append(buf)
+        assert int((results[0] != unfilled).any(dim=2).sum()) > 20000
+        for r in results[1:]:
+            assert torch.equal(r, results[0])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_generate_mask_against_reference_vectors(K, tag):
@@ -691,7 +751,7 @@ def test_both_hole_fill_schedules_give_identical_frames(K, size, dolly, kind):
     n_filled = 0
     for focal, shift3 in common.frame_cameras(settings, oc):
         outs = []
-        for mode in (8, 16):                                        # KBE_STAGE_FILL_PER_LANE, KBE_STAGE_FILL_PER_HALFWAVE
+        for mode in (8, 16, 8 | 512):                               # KBE_STAGE_FILL_PER_LANE, _PER_HALFWAVE, _PER_LANE with the distance table
             rf = torch.zeros(4, size[0], size[1], device='cuda')
             frame = K.render_frame(state, shift3, focal, oc['dblBaseline'], render_f32=rf, stages=7 | mode).clone()
             outs.append((c(frame), c(rf)))
@@ -700,9 +760,9 @@ def test_both_hole_fill_schedules_give_identical_frames(K, size, dolly, kind):
         K.render_frame(state, shift3, focal, oc['dblBaseline'], stages=4, fill_rect=(1, 1, 0, 0))      # reset the scratch
         # the un-filled renders of the two runs can differ in the last bit (summation order), so compare what the
         # fill decides: the set of pixels whose float render changed and, where the inputs agree, the values
-        a, b = outs
-        assert np.array_equal(a[0], b[0]) or (np.abs(a[0].astype(np.int32) - b[0].astype(np.int32)).max() <= 1
-                                              and (a[0] != b[0]).mean() < 1e-3)
+        for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+            assert np.array_equal(a[0], b[0]) or (np.abs(a[0].astype(np.int32) - b[0].astype(np.int32)).max() <= 1
+                                                  and (a[0] != b[0]).mean() < 1e-3)
         n_filled += int((c(unfilled)[3] == 0).sum())
     assert n_filled > 100
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""What the distance-table hole fill does per frame of a dolly zoom (dev aid): holes walked, table look-ups per hole,
+directions cut by the bound.  Builds a -DKBE_FRAME_STATS variant library under /tmp, like tools/frame_stats.py."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = '/tmp/libkbe_stats.so'
+src = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
+subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared',
+                       '-fvisibility=hidden', '-DKBE_FRAME_STATS', '-I' + os.path.join(ROOT, 'include'), '-I' + src,
+                       os.path.join(src, 'kbe_hip.hip'), os.path.join(src, 'kbe_frame.hip'), os.path.join(src, 'kbe_cloud.hip'), '-o', so])
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
+
+_native._lib, _native._kernels, _native.LIB_PATH = None, None, so
+size = int(os.environ.get('SIZE', '1024'))
+ofrom, oto = synthetic.default_windows(size, size, True)
+settings = {'dblSteps': [i / 8 for i in range(9)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': True}
+oc = bench.build_scene(size, torch.device('cuda:0'), False, settings, 1)
+K = _native.kernels()
+state = common._prepared_cloud(K, oc)
+out = (ctypes.c_ulonglong * 8)()
+ex = torch.empty(size * size, device='cuda')
+for focal, shift3 in common.frame_cameras(settings, oc):
+    torch.cuda.synchronize()
+    K.lib.kbe_debug_fill_stats(out, 1)
+    K.render_frame(state, shift3, focal, oc['dblBaseline'], existing_f32=ex, stages=7 | 8 | 512, fused=False)
+    torch.cuda.synchronize()
+    K.lib.kbe_debug_fill_stats(out, 0)
+    holes = int((ex <= 0).sum())
+    h = max(1, out[0])
+    print('holes %d, inside the box of valid pixels %d; per hole: directions walked %.1f (cut by the bound %.1f); fine look-ups %.1f, coarse look-ups %.1f; '
+          'slow advances %.2f per look-up; wave iterations %d, lanes walking per iteration %.1f of 64'
+          % (holes, out[0], out[1] / h, out[5] / h, out[2] / h, out[3] / h, out[4] / max(1, out[3]), out[6], out[7] / max(1, out[6])))
