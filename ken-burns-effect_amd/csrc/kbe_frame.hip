@@ -1973,6 +1973,12 @@ __device__ __forceinline__ void axis_catch_up(Axis& ax, int& r, float u, bool su
     if (r > 0) axis_jump(ax, r);
 }
 
+#ifndef KBE_FILL_REFILL_MIN
+#define KBE_FILL_REFILL_MIN 16          // lanes of a wave that must be waiting before new work is fetched
+#endif
+#ifndef KBE_FILL_FINE_BELOW
+#define KBE_FILL_FINE_BELOW 2           // coarse distances below this ask the fine table as well (longer jumps, one more load)
+#endif
 constexpr unsigned long long FILL_NO_ENTRY = ~0ull;
 constexpr int FILL_MAX_STEPS = (1 << 14) - 1;
 enum { END_IDLE = 0, END_WALK = 1, END_HIT = 2, END_DEAD = 3 };
@@ -2119,7 +2125,7 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                 // (2)
                 {
                     int st = END_IDLE, rx = 0, ry = 0, k = 0, ix = 0, iy = 0, slot = 0, d = 0;
-                    float ux = 0.0f, uy = 0.0f, bound = 0.0f;
+                    float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
                     Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
                     for (;;) {
                         // the two ends of a direction look at each other
@@ -2128,14 +2134,18 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                             if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
                             else {
                                 const float ex = (float) (ix - pix), ey = (float) (iy - piy);
-                                const float dd = sqrtf(ex * ex + ey * ey);                      // :898
+                                const float ssq = ex * ex + ey * ey;                            // exact: small integers
+                                // the best length in the contest, squared and rounded up a little: a span whose square is
+                                // above that has a longer fp32 length (sqrtf is monotone and correctly rounded)
+                                const float best = __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1]);          // no entry yet: NaN
                                 if (st == END_HIT && pst == END_HIT) {
                                     const int ka = is_b ? pk : k, kb = is_b ? k : pk;
+                                    const float dd = sqrtf(ssq);                                // :898
                                     if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
                                         atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
                                                                 ((unsigned long long) ka << 14) | (unsigned long long) kb);
                                     st = END_IDLE;
-                                } else if (dd > __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1])) {       // no entry yet: NaN, never true
+                                } else if (ssq > best * best * 1.000001f) {                     // NaN: never true
                                     KBE_FILL_STAT(5, is_b ? 0 : 1);
                                     st = END_IDLE;
                                 }
@@ -2146,7 +2156,7 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                         if (idle) {
                             const int next = *(const volatile int*) &s_next;
                             if (next >= total) { if (idle == ~0ull) break; }
-                            else if (__popcll(idle) >= 16 || idle == ~0ull) {
+                            else if (__popcll(idle) >= KBE_FILL_REFILL_MIN || idle == ~0ull) {
                                 const int n_pairs = __popcll(idle) >> 1;
                                 int first = 0;
                                 if (lane == (int) __ffsll((long long) idle) - 1) first = atomicAdd(&s_next, n_pairs);
@@ -2158,6 +2168,7 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                     const int qpx = s_px[slot];
                                     iy = qpx / W; ix = qpx - iy * W;
                                     ux = s_dir[0][d]; uy = s_dir[1][d];
+                                    inv_umax = 0.999999f / fmaxf(fabsf(ux), fabsf(uy));
                                     bound = is_b ? INFINITY : -INFINITY;
                                     if (strips) {
                                         const float2 lh = strips[(size_t) d * bins + ((int) floorf(ux * (float) iy - uy * (float) ix) + s_off[d])];
@@ -2196,12 +2207,16 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                     const int ci = (iy >> 3) * cw + (ix >> 3);
                                     const int c = in_lds ? ((const uint8_t*) s_pool)[ci] : dist_blocks[ci];
                                     KBE_FILL_STAT(3, 1);
-                                    if (c >= 2) m = 8 * (c - 1);            // a hole, and so are the next 8 (c - 1) - 1 positions
+                                    // With the nearest valid pixel D away (Chebyshev) from this one, the pixel j steps
+                                    // on is at most j max(|ux|, |uy|) + 1 away from this one (the steps; the rounding of
+                                    // both positions; < 0.03 of drift): a hole for sure while j umax + 1.03 < D.  The first
+                                    // position to look at is step ceil((D - 1.03) / umax).
+                                    if (c >= KBE_FILL_FINE_BELOW) m = (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f);   // D >= 8 (c - 1) + 1
                                     else {
                                         const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
                                         KBE_FILL_STAT(2, 1);
                                         if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
-                                        else m = max(1, dn - 1);
+                                        else m = max(c >= 2 ? (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f) : 1, (int) ceilf(((float) dn - 1.03f) * inv_umax));
                                     }
                                 }
                                 rx = ry = m;

@@ -34,7 +34,8 @@ for focal, shift3 in common.frame_cameras(settings, oc):
     torch.cuda.synchronize()
     K.lib.kbe_debug_fill_stats(out, 0)
     holes = int((ex <= 0).sum())
+    hit_wait, out[0] = out[0] >> 32, out[0] & 0xFFFFFFFF
     h = max(1, out[0])
     print('holes %d, inside the box of valid pixels %d; per hole: directions walked %.1f (cut by the bound %.1f); fine look-ups %.1f, coarse look-ups %.1f; '
-          'slow advances %.2f per look-up; wave iterations %d, lanes walking per iteration %.1f of 64'
-          % (holes, out[0], out[1] / h, out[5] / h, out[2] / h, out[3] / h, out[4] / max(1, out[3]), out[6], out[7] / max(1, out[6])))
+          'slow advances %.2f per look-up; wave iterations %d, lanes walking per iteration %.1f of 64, waiting for the other end %.1f'
+          % (holes, out[0], out[1] / h, out[5] / h, out[2] / h, out[3] / h, out[4] / max(1, out[3]), out[6], out[7] / max(1, out[6]), hit_wait / max(1, out[6])))
