@@ -2062,6 +2062,12 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
             // (3) One lane per hole: the winner's end points from its step counts, the fill.
             // One lane per hole for everything left 3/4 of the lanes idle in every direction and chained ~100 dependent
             // look-ups per lane (890 us per launch); loops nested per lane (per end, per jump) ran at ~20 % lane use.
+            // Where the time still goes (tools/fill_stats.py, late dolly frames): while the queue has work 49 of 64 lanes
+            // walk; after it has run dry the waves walk their last rays to the barrier with 6 lanes -- more than half of
+            // all loop iterations, whatever the batch size: rays through speckled regions live 100+ iterations.  Tried
+            // against that and slower: the queue in HBM with persistent waves (a look-up per iteration at the
+            // hole's key in L2 instead of LDS), batches of up to 1024 slots claimed from a cursor (3 instead of 5 workgroups
+            // per CU), waves working on their own without any barrier (119 registers, 46 KB: occupancy 3).
             constexpr int FB = KBE_FILL_BLOCK;
             static_assert(FB % 64 == 0 && FB * 16 <= 65536, "queue entries are 16 bits");
             __shared__ unsigned long long s_key[FB];
@@ -2183,7 +2189,10 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                             }
                         }
 #if defined(KBE_FRAME_STATS)
-                        { const unsigned long long w = __ballot(st == END_WALK); if (lane == 0) { KBE_FILL_STAT(6, 1); KBE_FILL_STAT(7, __popcll(w)); } }
+                        { const unsigned long long w = __ballot(st == END_WALK), hw = __ballot(st == END_HIT);
+                          const bool empty = *(const volatile int*) &s_next >= total;
+                          if (lane == 0) { KBE_FILL_STAT(6, 1ull | (empty ? 1ull << 32 : 0ull)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | (empty ? (unsigned long long) __popcll(w) << 32 : 0ull));
+                                           KBE_FILL_STAT(0, (unsigned long long) __popcll(hw) << 32); } }
 #endif
                         // one advance, one look-up
                         if (st == END_WALK) {

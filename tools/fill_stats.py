@@ -36,6 +36,9 @@ for focal, shift3 in common.frame_cameras(settings, oc):
     holes = int((ex <= 0).sum())
     hit_wait, out[0] = out[0] >> 32, out[0] & 0xFFFFFFFF
     h = max(1, out[0])
+    it, it_drain = out[6] & 0xFFFFFFFF, out[6] >> 32
+    walking, walking_drain = out[7] & 0xFFFFFFFF, out[7] >> 32
     print('holes %d, inside the box of valid pixels %d; per hole: directions walked %.1f (cut by the bound %.1f); fine look-ups %.1f, coarse look-ups %.1f; '
-          'slow advances %.2f per look-up; wave iterations %d, lanes walking per iteration %.1f of 64, waiting for the other end %.1f'
-          % (holes, out[0], out[1] / h, out[5] / h, out[2] / h, out[3] / h, out[4] / max(1, out[3]), out[6], out[7] / max(1, out[6]), hit_wait / max(1, out[6])))
+          'catch-ups %.2f per look-up; wave iterations %d (%d with the queue empty), lanes walking per iteration %.1f of 64 (%.1f while the queue has work, %.1f after), waiting for the other end %.1f'
+          % (holes, out[0], out[1] / h, out[5] / h, out[2] / h, out[3] / h, out[4] / max(1, out[3]), it, it_drain, walking / max(1, it),
+             (walking - walking_drain) / max(1, it - it_drain), walking_drain / max(1, it_drain), hit_wait / max(1, it)))
