@@ -332,7 +332,7 @@ def main():
     if rank == 0:
         from ken_burns_effect_amd import _native
         lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
-        host_lanes = min(lanes, max(1, int(os.environ.get('KBE_HOST_LANES', _native.DEFAULT_HOST_LANES))))
+        host_lanes = _native.host_lanes(lanes, n_points, size, size, 3 * size * size)
         kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]))
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +

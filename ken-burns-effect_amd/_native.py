@@ -28,7 +28,25 @@ ABI_VERSION = 4
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
-DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory (env KBE_HOST_LANES)
+DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
+
+
+def host_lanes(lanes, n_points, W, H, frame_bytes):
+    """Lanes of the frame loop when the frames go to pinned host memory (env KBE_HOST_LANES overrides).  Where the PCIe
+    link binds, two lanes ping-pong best (one renders its next group while the other's leaves: 59.1 us per 1024^2 frame of
+    the bench against 60.7 with four and 84.8 with three); where the rendering binds every lane helps (measured, 2 -> 4
+    lanes: 512^2 25.5 -> 18.8 us, dolly 260 -> 155, raw cloud 64 -> 61, 2048^2 raw 305 -> 276, 2048^2 from 16.8 M points
+    427 -> 386).  Which it is, from what is known before the first frame: the link needs frame_bytes / 53 GB/s per frame; a
+    frame of an inpainted cloud (more points than pixels: few holes to fill) renders in about 13.5 us per million points
+    + 12 us per megapixel with four lanes, and never in less than the ~14 us its four launches take; a cloud without
+    appended points leaves holes whose fill dominates (rendering binds).  The link binds when it needs 1.5 x longer."""
+    env = os.environ.get('KBE_HOST_LANES')
+    if env:
+        return min(lanes, max(1, int(env)))
+    link_us = frame_bytes / 53.0e3
+    render_us = max(14.0, 13.5e-6 * n_points + 12.0e-6 * W * H)
+    link_bound = n_points > W * H and link_us > 1.5 * render_us
+    return min(lanes, DEFAULT_HOST_LANES) if link_bound else lanes
 _lib = None
 
 
@@ -310,9 +328,7 @@ class HipKernels:
                 raise KbeError('render_video: host_out must be pinned host memory (or a device tensor)')
             # The hand-off (include/kbe.h): < 0 = groups of -batch frames per lane, one hipMemcpyAsync each, the lanes
             # taking turns on the link (default); 0 = per frame by a copy kernel; > 0 = round 1's staged ring.
-            # Two lanes ping-pong best (one renders its next group while the other's leaves: 59 us per 1024^2 frame;
-            # 3-4 lanes 60-61): the link, not the rendering, bounds this mode.
-            lanes = min(lanes, max(1, int(os.environ.get('KBE_HOST_LANES', DEFAULT_HOST_LANES))))
+            lanes = host_lanes(lanes, state['N'], W, H, 3 * W * H)      # a cropped frame is resized back to W x H (common.py:257)
             if batch is None:
                 batch = int(os.environ.get('KBE_DELIVERY_BATCH', '0')) or -max(1, min(8, n // (4 * lanes)))
         batch = max(-64, int(batch))

@@ -201,3 +201,17 @@ def test_fp32_image_position_and_cull_equal_the_fp64_forms(tmp_path):
     out = subprocess.run([exe, '1021'], capture_output=True, text=True)
     n, bad = (int(v) for v in out.stdout.split()[-2:])
     assert out.returncode == 0 and bad == 0 and n > 70_000_000
+
+
+def test_host_lanes_two_where_the_link_binds_all_where_the_rendering_does(monkeypatch):
+    """_native.host_lanes: the lanes of the frame loop when frames go to pinned host memory (measured table in its docstring)."""
+    from ken_burns_effect_amd import _native
+    monkeypatch.delenv('KBE_HOST_LANES', raising=False)
+    cases = {'bench default (inpainted, 1024^2)': (1137109, 1024, 2), '512^2 inpainted (launch-bound)': (284000, 512, 4),
+             'dolly / raw cloud (holes)': (1048576, 1024, 4), 'configs[4]: 16.8 M points': (16777216, 2048, 4),
+             '2048^2 inpainted': (4550000, 2048, 2)}
+    for name, (n, size, want) in cases.items():
+        assert _native.host_lanes(4, n, size, size, 3 * size * size) == want, name
+    assert _native.host_lanes(1, 1137109, 1024, 1024, 3 << 20) == 1
+    monkeypatch.setenv('KBE_HOST_LANES', '3')
+    assert _native.host_lanes(4, 1137109, 1024, 1024, 3 << 20) == 3

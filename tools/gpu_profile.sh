@@ -36,8 +36,13 @@ python $R/tools/pmc_report.py /tmp/pm_FETCH_SIZE/c_counter_collection.csv /tmp/p
 for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPSAMPLE=2 CLOUD=raw"; do
   for fused in 0 1; do
     echo "== $env KBE_FUSED=$fused"
-    env $env KBE_FUSED=$fused FRAMES=128 REPS=3 python $R/tools/throughput.py 2>/dev/null | tail -1
+    env $env KBE_FUSED=$fused FRAMES=128 REPS=3 timeout 300 python $R/tools/throughput.py 2>/dev/null | tail -1
   done
 done
 ) > $OUT/other_workloads.txt
+# 5. the dolly zoom (frames with very many holes: the distance-table fill): per-kernel stats of its frame loop, and what the fill does
+rm -rf /tmp/kd
+DOLLY=1 REPS=2 FRAMES=128 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kd -o b --output-format csv -- python $R/tools/throughput.py > $OUT/dolly_under_rocprof.txt 2>/dev/null
+if [ -f /tmp/kd/b_kernel_stats.csv ]; then cp /tmp/kd/b_kernel_stats.csv $OUT/dolly_kernel_stats.csv; fi
+timeout 600 python $R/tools/fill_stats.py 2>/dev/null | grep "^holes" > $OUT/dolly_fill_stats.txt
 ls -la $OUT; cat $OUT/bench.json; grep -E 'k_tiles|k_project|k_frame|k_fill_holes|k_crop|copy|Copy' $OUT/bench_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv $OUT/bench_fused_lanes1_kernel_stats.csv | cut -c1-220; cat $OUT/hbm_traffic.json; cat $OUT/other_workloads.txt
