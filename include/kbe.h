@@ -182,10 +182,13 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 #define KBE_STAGE_FILL_PER_LANE 8
 #define KBE_STAGE_FILL_PER_HALFWAVE 16
 #define KBE_STAGE_FILL_BY_COUNT 32
-/* with _PER_LANE or _BY_COUNT: frames with very many holes (>= ~49 k; no inpainting: a dolly zoom, a raw cloud) first get a
- * per-pixel table of the Chebyshev distance to the nearest valid pixel (one more small launch, k_hole_dist; it returns at
- * once when the frame has fewer holes), and a ray at distance D takes D - 1 steps at once -- the same positions are
- * tested in the end, the result is identical */
+/* with _PER_LANE or _BY_COUNT: frames with very many holes (>= ~49 k; no inpainting: a dolly zoom, a raw cloud) first get
+ * tables (one more launch, k_hole_dist; it returns at once when the frame has fewer holes): the Chebyshev distance of
+ * every pixel, and of every 8 x 8 block, to the nearest valid one -- a ray at distance D takes ~D - 1 steps at once, the
+ * reference's fp32 sums taken on the integer mantissa -- and per direction and line across the image where along the
+ * line valid pixels can be -- a direction with nothing on one side of the hole is skipped without walking to the image
+ * border.  The same positions are tested in the end, the result is identical.  Frames with a side above 11 000 pixels
+ * ignore the flag. */
 #define KBE_STAGE_FILL_DIST 512
 /* kbe_render_frame_stages: the scratch holds two z-buffers, A and B.  Without these flags a frame stands alone: it splats
  * into A and its fill launch resets A and the bucket counters.  Consecutive frames of a video alternate instead:

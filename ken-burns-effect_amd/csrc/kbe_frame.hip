@@ -1847,6 +1847,10 @@ __global__ void __launch_bounds__(256) k_hole_dist(const uint32_t* __restrict__ 
                      (int) blockIdx.x, (int) blockIdx.y, W, H, W, dist);
 }
 
+// the contest's key holds an end's step count in 14 bits: a ray takes at most max(W, H) / 0.707 steps (larger frames
+// fill with the other schedules)
+inline bool fill_tables_fit(int W, int H) { return W <= 11000 && H <= 11000; }
+
 // the extents the strip tables are built from: up to STRIP_TILES tile rows / columns
 inline bool strips_fit(const Scratch& sc) { return sc.tiles_x <= STRIP_TILES && sc.tiles_y <= STRIP_TILES; }
 
@@ -2548,7 +2552,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         const uint8_t* dist = nullptr;
         const float2* strips = nullptr;
-        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT))) {
+        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
             strips = strips_fit(sc) ? sc.strips : nullptr;
             launch_hole_dist(s, sc, W, H, sc.hole_count, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
             dist = sc.dist;
@@ -2609,7 +2613,7 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
         const uint8_t* dist = nullptr;
         const float2* strips = nullptr;
-        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT))) {
+        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
             strips = strips_fit(sc) ? sc.strips : nullptr;
             launch_hole_dist(s, sc, W, H, count_now, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
             dist = sc.dist;

@@ -80,10 +80,12 @@ def test_config4_2048_frame_from_16m_points(K, oracle, dense_cloud, fused, monke
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, float(np.abs(b).max())), 'channel %d' % ch
     zref = oracle.degrid(oracle.zsplat(sp, size, size, focal, Bl)[0], 'jacobi').numpy()[0, 0]
     assert_bits_equal(c(zd).reshape(size, size)[win], zref[win], 'degridded z-buffer in the window')
-    # (3) the two hole-fill schedules give the same frame
-    frames = [c(K.render_frame(state, shift3, focal, Bl, stages=7 | mode, fused=fused)) for mode in (8, 16)]
-    d = np.abs(frames[0].astype(np.int32) - frames[1].astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    # (3) the hole-fill schedules give the same frame: half-wave, lane, lane with the tables of k_hole_dist (at this size the
+    # block-distance table is read from memory, not from LDS)
+    frames = [c(K.render_frame(state, shift3, focal, Bl, stages=7 | mode, fused=fused)) for mode in (8, 16, 8 | 512)]
+    for other in frames[1:]:
+        d = np.abs(frames[0].astype(np.int32) - other.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
     assert int((c(ex) <= 0).sum()) > 0, 'the frame has holes to fill'
 
 
@@ -111,4 +113,12 @@ def test_rasters_beyond_4096_tile_renderers_against_the_atomic_kernels(K, size, 
         assert torch.equal(ex.view(size, size) > 0, existing[0, 0] > 0), 'validity masks (fused=%s)' % fused
         assert float((rf - filled[0]).abs().max()) <= 1e-4 * max(1.0, float(filled.abs().max()))
         assert int((frame.int() - want_u8.int()).abs().max()) <= 1
-        del rf, ex
+        # the fill with the tables of k_hole_dist on the same un-filled frame: byte-identical to the per-lane schedule
+        unfilled = K.render_frame(state, shift3, synthetic.FOCAL, synthetic.BASELINE, stages=3, fused=fused).clone()
+        filled_by = []
+        for mode in (8, 8 | 512):
+            buf = unfilled.clone()
+            K.render_frame(state, shift3, synthetic.FOCAL, synthetic.BASELINE, out=buf, stages=4 | mode, fused=fused)
+            filled_by.append(buf)
+        assert torch.equal(filled_by[0], filled_by[1]), 'table-driven fill at %d^2 (fused=%s)' % (size, fused)
+        del rf, ex, unfilled, filled_by
