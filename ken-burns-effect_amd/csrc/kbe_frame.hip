@@ -1907,8 +1907,12 @@ __device__ __forceinline__ float advance_exact(float a, float u, int m, bool sub
 #if defined(KBE_FRAME_STATS)     // dev build only (tools/fill_stats.py)
 __device__ unsigned long long g_fill_stats[8];      // holes walked, directions walked, fine look-ups, coarse look-ups, -, directions cut by the bound, directions skipped, skipped before a step
 #define KBE_FILL_STAT(i, v) atomicAdd(&g_fill_stats[i], (unsigned long long) (v))
+__device__ unsigned long long g_fill_hist[16];       // ray ends by the loop iterations they lived: [0] < 4, [1] < 8, ... doubling; [12] = the longest, [13] = steps of rays living >= 128 iterations, [14] = their iterations
+#define KBE_FILL_RAY_DONE(iters, steps) do { int b_ = 0; while ((4 << b_) <= (iters) && b_ < 11) b_++; atomicAdd(&g_fill_hist[b_], 1ull); atomicMax(&g_fill_hist[12], (unsigned long long) (iters)); \
+    if ((iters) >= 128) { atomicAdd(&g_fill_hist[13], (unsigned long long) (steps)); atomicAdd(&g_fill_hist[14], (unsigned long long) (iters)); } } while (0)
 #else
 #define KBE_FILL_STAT(i, v) ((void) 0)
+#define KBE_FILL_RAY_DONE(iters, steps) ((void) 0)
 #endif
 
 // One coordinate of a ray end while it walks.  Fast mode (e >= 0): the coordinate is A 2^(e-23) with A in [2^23, 2^24),
@@ -2068,10 +2072,13 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
             // look-ups per lane (890 us per launch); loops nested per lane (per end, per jump) ran at ~20 % lane use.
             // Where the time still goes (tools/fill_stats.py, late dolly frames): while the queue has work 49 of 64 lanes
             // walk; after it has run dry the waves walk their last rays to the barrier with 6 lanes -- more than half of
-            // all loop iterations, whatever the batch size: rays through speckled regions live 100+ iterations.  Tried
-            // against that and slower: the queue in HBM with persistent waves (a look-up per iteration at the
-            // hole's key in L2 instead of LDS), batches of up to 1024 slots claimed from a cursor (3 instead of 5 workgroups
-            // per CU), waves working on their own without any barrier (119 registers, 46 KB: occupancy 3).
+            // all loop iterations, whatever the batch size: of 1.9 M ray ends 1.1 M live < 4 iterations and ~1 700 live
+            // 128-335 (rays creeping through speckled regions at 1.3-1.9 steps per iteration).  Tried against that and
+            // slower: the queue in HBM with persistent waves (a look-up per iteration at the hole's key in
+            // L2 instead of LDS), batches of up to 1024 slots claimed from a cursor (3 instead of 5 workgroups per CU),
+            // waves working on their own without any barrier (119 registers, 46 KB: occupancy 3), creeping rays taking 8
+            // steps per iteration in sparse waves (the longest launch 894 -> 724 us, the average 385 -> 405), creeping
+            // rays first in the queue, 6-8 waves per SIMD with the block table read from memory (no change).
             constexpr int FB = KBE_FILL_BLOCK;
             static_assert(FB % 64 == 0 && FB * 16 <= 65536, "queue entries are 16 bits");
             __shared__ unsigned long long s_key[FB];
@@ -2135,6 +2142,9 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                 // (2)
                 {
                     int st = END_IDLE, rx = 0, ry = 0, k = 0, ix = 0, iy = 0, slot = 0, d = 0;
+#if defined(KBE_FRAME_STATS)
+                    int iters = 0;
+#endif
                     float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
                     Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
                     for (;;) {
@@ -2161,6 +2171,10 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                 }
                             }
                         }
+#if defined(KBE_FRAME_STATS)
+                        if (st == END_IDLE && iters > 0) { KBE_FILL_RAY_DONE(iters, k); iters = 0; }
+                        if (st == END_WALK) iters++;
+#endif
                         // new work, for a quarter of the wave at a time (fetching runs at the pace of its slowest lane)
                         const unsigned long long idle = __ballot(st == END_IDLE);
                         if (idle) {
@@ -2628,6 +2642,12 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
 }
 
 #if defined(KBE_FRAME_STATS)
+extern "C" __attribute__((visibility("default"))) int kbe_debug_fill_hist(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fill_hist), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[16] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_fill_hist), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int kbe_debug_fill_stats(unsigned long long* out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fill_stats), 8 * sizeof(unsigned long long));

@@ -26,14 +26,19 @@ oc = bench.build_scene(size, torch.device('cuda:0'), False, settings, 1)
 K = _native.kernels()
 state = common._prepared_cloud(K, oc)
 out = (ctypes.c_ulonglong * 8)()
+hist = (ctypes.c_ulonglong * 16)()
 ex = torch.empty(size * size, device='cuda')
 for focal, shift3 in common.frame_cameras(settings, oc):
     torch.cuda.synchronize()
     K.lib.kbe_debug_fill_stats(out, 1)
+    K.lib.kbe_debug_fill_hist(hist, 1)
     K.render_frame(state, shift3, focal, oc['dblBaseline'], existing_f32=ex, stages=7 | 8 | 512, fused=False)
     torch.cuda.synchronize()
     K.lib.kbe_debug_fill_stats(out, 0)
     holes = int((ex <= 0).sum())
+    K.lib.kbe_debug_fill_hist(hist, 0)
+    print('   ray ends by loop iterations lived (< 4, < 8, < 16, ...): %s; the longest %d; rays of >= 128 iterations take %.2f steps per iteration'
+          % (' '.join(str(hist[i]) for i in range(12)), hist[12], hist[13] / max(1, hist[14])))
     hit_wait, out[0] = out[0] >> 32, out[0] & 0xFFFFFFFF
     h = max(1, out[0])
     it, it_drain = out[6] & 0xFFFFFFFF, out[6] >> 32
