@@ -644,7 +644,8 @@ def test_denser_than_raster_cloud_matches_oracle(K, oracle):
     assert d.max() <= 1 and (d > 0).mean() < 2e-3
 
 
-@pytest.mark.parametrize('size,dolly,kind', [((512, 512), True, 'smooth'), ((200, 312), False, 'noise'), ((1024, 1024), True, 'smooth')])
+@pytest.mark.parametrize('size,dolly,kind', [((512, 512), True, 'smooth'), ((200, 312), False, 'noise'), ((1024, 1024), True, 'smooth'),
+                                             ((37, 50), True, 'noise'), ((9, 70), False, 'noise'), ((130, 33), True, 'smooth'), ((257, 1031), True, 'smooth')])
 def test_hole_fill_schedules_on_the_same_unfilled_frame_are_byte_identical(K, size, dolly, kind):
     """The three hole-fill schedules (one half-wave per hole; one lane per hole with block skips; one lane per hole with the
     distance table of k_hole_dist) run on the SAME un-filled frame: a fill never reads a hole, so it can be repeated on
@@ -663,7 +664,7 @@ def test_hole_fill_schedules_on_the_same_unfilled_frame_are_byte_identical(K, si
         n_holes += int((results[0] != unfilled).any(dim=2).sum())
         for r in results[1:]:
             assert torch.equal(r, results[0])
-    assert n_holes > 1000
+    assert n_holes > (1000 if size[0] * size[1] > 50000 else 20)
 
 
 @pytest.mark.parametrize('seed', [1, 2, 3])
