@@ -2008,6 +2008,269 @@ __device__ __forceinline__ int swap_with_neighbour(int v)       // lanes 2i and 
     return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1, 0, 3, 2]
 }
 
+// the box of all valid pixels from the tiles' boxes (every thread of the block gets it; s_bb: one int[4] per wave)
+__device__ __forceinline__ void valid_box(const int4* __restrict__ bbox, int n_tiles, int W, int H, int (*s_bb)[4], int& bx0, int& by0, int& bx1, int& by1)
+{
+    bx0 = W; by0 = H; bx1 = -1; by1 = -1;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int4 bb = bbox[t];
+        bx0 = min(bx0, bb.x); by0 = min(by0, bb.y); bx1 = max(bx1, bb.z); by1 = max(by1, bb.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
+        bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_bb[threadIdx.x >> 6][0] = bx0; s_bb[threadIdx.x >> 6][1] = by0; s_bb[threadIdx.x >> 6][2] = bx1; s_bb[threadIdx.x >> 6][3] = by1; }
+    __syncthreads();
+    for (int w = 0; w < (int) (blockDim.x >> 6); w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
+}
+
+// The fill of a frame with very many holes, with the tables of k_hole_dist (launched in front of it; a kernel of its own so
+// that its loop gets its own register allocation and code: inside k_fill_holes, next to the other two schedules, the same
+// loop ran 20 % slower whenever code was added anywhere in that kernel).  `min_holes`: frames with fewer holes are left
+// to k_fill_holes, which is launched behind this kernel in any case (housekeeping) and skips the frames filled here.
+__global__ void __launch_bounds__(256) k_fill_tables(const int* __restrict__ holes, const int* __restrict__ hole_count, int min_holes,
+                                                     const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
+                                                     uint8_t* __restrict__ frame, float* __restrict__ render, int n_tiles,
+                                                     const int4* __restrict__ bbox, int tiles_x, int tiles_y,
+                                                     const uint8_t* __restrict__ dist, const float2* __restrict__ strips,
+                                                     const uint8_t* __restrict__ dist_blocks)
+{
+    const int n = min(*hole_count, W * H);
+    if (n < min_holes || (int) (blockIdx.x * blockDim.x) >= n) return;
+    __shared__ int s_bb[4][4];
+    // the block-distance table, two entries per byte (they are <= 15), if it fits: 8 KB hold a 1024 x 1024 frame's, and with
+    // the queue and the slots a workgroup then needs < 20 KB, so that 8 of them share a CU
+    static_assert(KBE_DIST_CAP_BLOCKS <= 15, "block distances are stored in 4 bits");
+    __shared__ uint32_t s_pool[COARSE_WORDS];
+    int bx0, by0, bx1, by1;
+    valid_box(bbox, n_tiles, W, H, s_bb, bx0, by0, bx1, by1);
+    // With the tables of k_hole_dist (launched in front of this kernel for frames expected to have very many holes).
+    // A workgroup takes 256 holes at a time.
+    // (1) One lane per hole: the strip test of its 16 directions; the directions that pass -- 4.5 of 16 on the
+    //     dolly bench -- are queued in LDS.
+    // (2) One lane per END of a queued (hole, direction), neighbouring lanes the two ends; ONE loop for everything:
+    //     an iteration is one advance (exactly the fp32 sums of :876-889, on the integer mantissa: struct Axis) and
+    //     one look-up -- the coarse table in LDS, and where that says "near" the fine table -- or, for lanes whose
+    //     direction is decided, waiting until enough lanes wait to fetch new work together.  A direction is
+    //     decided when one end leaves the image or its strip (skipped, :880-885 / :891-896), when both ends stand on
+    //     valid pixels (it enters the hole's contest, :898-900, with an LDS atomicMin: the fp32 length of the span in
+    //     the high word -- positive floats order like their bits -- then the direction: the reference keeps the
+    //     FIRST direction of the shortest length, `best > dd` is strict; then the step counts of the two ends),
+    //     or when its ends are already farther apart than a direction in the contest (they only move apart: it can
+    //     neither win nor tie).
+    // (3) One lane per hole: the winner's end points from its step counts, the fill.
+    // One lane per hole for everything left 3/4 of the lanes idle in every direction and chained ~100 dependent
+    // look-ups per lane (890 us per launch); loops nested per lane (per end, per jump) ran at ~20 % lane use.
+    // Where the time still goes (tools/fill_stats.py, late dolly frames): while the queue has work 49 of 64 lanes
+    // walk; after it has run dry the waves walk their last rays to the barrier with 6 lanes -- more than half of
+    // all loop iterations, whatever the batch size: of 1.9 M ray ends 1.1 M live < 4 iterations and ~1 700 live
+    // 128-335 (rays creeping through speckled regions at 1.3-1.9 steps per iteration).  Tried against that and
+    // slower: the queue in HBM with persistent waves (a look-up per iteration at the hole's key in
+    // L2 instead of LDS), batches of up to 1024 slots claimed from a cursor (3 instead of 5 workgroups per CU),
+    // waves working on their own without any barrier (119 registers, 46 KB: occupancy 3), creeping rays taking 8
+    // steps per iteration in sparse waves (the longest launch 894 -> 724 us, the average 385 -> 405), creeping
+    // rays first in the queue, 6-8 waves per SIMD with the block table read from memory (no change).
+    constexpr int FB = 256;
+    static_assert(FB % 64 == 0 && FB * 16 <= 65536, "queue entries are 16 bits");
+    __shared__ unsigned long long s_key[FB];
+    __shared__ uint16_t s_queue[FB * 16];
+    __shared__ int s_px[FB], s_wave_n[FB / 64], s_next;
+    __shared__ uint8_t s_m0[FB];
+    __shared__ float s_dir[2][16];
+    __shared__ int s_off[16];
+    const int cw = tiles_x * (TW / 8);
+    const int c_bytes = cw * tiles_y * (TH / 8);
+    const bool in_lds = c_bytes <= 2 * (int) sizeof(s_pool);
+    if (in_lds)
+        for (int i = threadIdx.x; i < (c_bytes + 7) / 8; i += blockDim.x) {
+            const uint32_t lo = ((const uint32_t*) dist_blocks)[2 * i], hi = 8 * i + 4 < c_bytes ? ((const uint32_t*) dist_blocks)[2 * i + 1] : 0u;
+            // bytes b0..b7 -> nibbles: entry 2j in the low half of byte j
+            s_pool[i] = (lo & 0xFu) | ((lo >> 4) & 0xF0u) | ((lo >> 8) & 0xF00u) | ((lo >> 12) & 0xF000u) |
+                        ((hi & 0xFu) << 16) | (((hi >> 4) & 0xF0u) << 16) | (((hi >> 8) & 0xF00u) << 16) | (((hi >> 12) & 0xF000u) << 16);
+        }
+    const auto block_distance = [&](int ci) -> int {           // blocks to the nearest block with a valid pixel
+        return in_lds ? (((const uint8_t*) s_pool)[ci >> 1] >> ((ci & 1) << 2)) & 15 : (int) dist_blocks[ci];
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 16) { s_dir[0][tid] = dirs.x[tid]; s_dir[1][tid] = dirs.y[tid]; s_off[tid] = strip_offset(dirs.x[tid], dirs.y[tid], W, H); }
+    const int bins = strip_bins(W, H);
+    const size_t HW = (size_t) W * H;
+    const bool is_b = lane & 1;                         // the end walking towards +u
+    for (int base = blockIdx.x * FB; base < n; base += gridDim.x * FB) {
+        __syncthreads();                                // the tables are loaded / the previous batch is done with the LDS arrays
+        // (1)
+        const int h = base + tid;
+        int px = -1, x = 0, y = 0;
+        uint32_t pass = 0;
+        if (h < n) {
+            px = holes[h];
+            y = px / W; x = px - y * W;
+            // outside the rectangle to be filled / outside the box of the valid pixels: every direction is skipped
+            if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1 || x < bx0 || x > bx1 || y < by0 || y > by1) px = -1;
+        }
+        if (px >= 0) {
+            KBE_FILL_STAT(0, 1);
+            pass = 0xFFFFu;
+            if (strips) {
+                pass = 0;
+#pragma unroll
+                for (int d = 0; d < 16; d++) {
+                    const float ddx = s_dir[0][d], ddy = s_dir[1][d];
+                    const float c = ddx * (float) y - ddy * (float) x, t = ddx * (float) x + ddy * (float) y;
+                    const float2 lh = strips[(size_t) d * bins + ((int) floorf(c) + s_off[d])];
+                    if (!(lh.x > t + STRIP_MARGIN || lh.y < t - STRIP_MARGIN)) pass |= 1u << d;     // valid pixels on both sides
+                }
+            }
+            if (pass) {
+                const int c_here = block_distance((y >> 3) * cw + (x >> 3));
+                s_m0[tid] = (uint8_t) (c_here >= 2 ? 8 * (c_here - 1) : max(1, (int) dist[(uint32_t) px] - 1));
+            }
+        }
+        s_px[tid] = px;
+        s_key[tid] = FILL_NO_ENTRY;
+        if (tid == 0) s_next = 0;
+        const int mine = __popc(pass);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) s_wave_n[wave] = incl;
+        __syncthreads();
+        int at = incl - mine, total = 0;
+        for (int w = 0; w < FB / 64; w++) { if (w < wave) at += s_wave_n[w]; total += s_wave_n[w]; }
+        for (uint32_t m = pass; m; m &= m - 1) s_queue[at++] = (uint16_t) ((tid << 4) | (__ffs(m) - 1));
+        __syncthreads();
+        // (2)
+        {
+            int st = END_IDLE, rx = 0, ry = 0, k = 0, ix = 0, iy = 0, slot = 0, d = 0;
+#if defined(KBE_FRAME_STATS)
+            int iters = 0;
+#endif
+            float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
+            Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
+            for (;;) {
+                // the two ends of a direction look at each other
+                const int pst = swap_with_neighbour(st), pix = swap_with_neighbour(ix), piy = swap_with_neighbour(iy), pk = swap_with_neighbour(k);
+                if (st != END_IDLE) {
+                    if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
+                    else {
+                        const float ex = (float) (ix - pix), ey = (float) (iy - piy);
+                        const float ssq = ex * ex + ey * ey;                            // exact: small integers
+                        // the best length in the contest, squared and rounded up a little: a span whose square is
+                        // above that has a longer fp32 length (sqrtf is monotone and correctly rounded)
+                        const float best = __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1]);          // no entry yet: NaN
+                        if (st == END_HIT && pst == END_HIT) {
+                            const int ka = is_b ? pk : k, kb = is_b ? k : pk;
+                            const float dd = sqrtf(ssq);                                // :898
+                            if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
+                                atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
+                                                        ((unsigned long long) ka << 14) | (unsigned long long) kb);
+                            st = END_IDLE;
+                        } else if (ssq > best * best * 1.000001f) {                     // NaN: never true
+                            KBE_FILL_STAT(5, is_b ? 0 : 1);
+                            st = END_IDLE;
+                        }
+                    }
+                }
+#if defined(KBE_FRAME_STATS)
+                if (st == END_IDLE && iters > 0) { KBE_FILL_RAY_DONE(iters, k); iters = 0; }
+                if (st == END_WALK) iters++;
+#endif
+                // new work, for a quarter of the wave at a time (fetching runs at the pace of its slowest lane)
+                const unsigned long long idle = __ballot(st == END_IDLE);
+                if (idle) {
+                    const int next = *(const volatile int*) &s_next;
+                    if (next >= total) { if (idle == ~0ull) break; }
+                    else if (__popcll(idle) >= KBE_FILL_REFILL_MIN || idle == ~0ull) {
+                        const int n_pairs = __popcll(idle) >> 1;
+                        int first = 0;
+                        if (lane == (int) __ffsll((long long) idle) - 1) first = atomicAdd(&s_next, n_pairs);
+                        first = __shfl(first, (int) __ffsll((long long) idle) - 1);
+                        const int q = first + (__popcll(idle & ((1ull << lane) - 1ull)) >> 1);
+                        if (st == END_IDLE && q < total) {
+                            const int e = s_queue[q];
+                            slot = e >> 4; d = e & 15;
+                            const int qpx = s_px[slot];
+                            iy = qpx / W; ix = qpx - iy * W;
+                            ux = s_dir[0][d]; uy = s_dir[1][d];
+                            inv_umax = 0.999999f / fmaxf(fabsf(ux), fabsf(uy));
+                            bound = is_b ? INFINITY : -INFINITY;
+                            if (strips) {
+                                const float2 lh = strips[(size_t) d * bins + ((int) floorf(ux * (float) iy - uy * (float) ix) + s_off[d])];
+                                bound = is_b ? lh.y : lh.x;
+                            }
+                            X = axis_enter((float) ix, ux, !is_b);
+                            Y = axis_enter((float) iy, uy, !is_b);
+                            rx = ry = k = s_m0[slot];
+                            st = END_WALK;
+                            KBE_FILL_STAT(1, is_b ? 0 : 1);
+                        }
+                    }
+                }
+#if defined(KBE_FRAME_STATS)
+                { const unsigned long long w = __ballot(st == END_WALK), hw = __ballot(st == END_HIT);
+                  const bool empty = *(const volatile int*) &s_next >= total;
+                  if (lane == 0) { KBE_FILL_STAT(6, 1ull | (empty ? 1ull << 32 : 0ull)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | (empty ? (unsigned long long) __popcll(w) << 32 : 0ull));
+                                   KBE_FILL_STAT(0, (unsigned long long) __popcll(hw) << 32); } }
+#endif
+                // one advance, one look-up
+                if (st == END_WALK) {
+                    axis_jump(X, rx);
+                    axis_jump(Y, ry);
+                    if (rx | ry) {                      // one of them did not get there: one catch-up, for one axis
+                        const bool on_x = rx > 0;
+                        Axis a = on_x ? X : Y;
+                        int r = on_x ? rx : ry;
+                        KBE_FILL_STAT(4, 1);
+                        axis_catch_up(a, r, on_x ? ux : uy, !is_b, on_x ? (float) W : (float) H);
+                        if (on_x) { X = a; rx = r; } else { Y = a; ry = r; }
+                    }
+                    if ((rx | ry) == 0) {
+                        ix = axis_pixel(X); iy = axis_pixel(Y);
+                        const float t = ux * (float) ix + uy * (float) iy;
+                        int m = 0;
+                        if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
+                        else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
+                        else {
+                            const int ci = (iy >> 3) * cw + (ix >> 3);
+                            const int c = block_distance(ci);
+                            KBE_FILL_STAT(3, 1);
+                            // With the nearest valid pixel D away (Chebyshev) from this one, the pixel j steps
+                            // on is at most j max(|ux|, |uy|) + 1 away from this one (the steps; the rounding of
+                            // both positions; < 0.03 of drift): a hole for sure while j umax + 1.03 < D.  The first
+                            // position to look at is step ceil((D - 1.03) / umax).
+                            if (c >= KBE_FILL_FINE_BELOW) m = (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f);   // D >= 8 (c - 1) + 1
+                            else {
+                                const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
+                                KBE_FILL_STAT(2, 1);
+                                if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
+                                else m = max(c >= 2 ? (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f) : 1, (int) ceilf(((float) dn - 1.03f) * inv_umax));
+                            }
+                        }
+                        rx = ry = m;
+                        k += m;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // (3)
+        const unsigned long long key = s_key[tid];
+        if (px >= 0 && key != FILL_NO_ENTRY) {
+            const int d = (int) (key >> 28) & 15, ka = (int) (key >> 14) & FILL_MAX_STEPS, kb = (int) key & FILL_MAX_STEPS;
+            const float ddx = s_dir[0][d], ddy = s_dir[1][d];
+            const int sax = (int) roundf(advance_exact((float) x, ddx, ka, true, INFINITY)), say = (int) roundf(advance_exact((float) y, ddy, ka, true, INFINITY));
+            const int sbx = (int) roundf(advance_exact((float) x, ddx, kb, false, INFINITY)), sby = (int) roundf(advance_exact((float) y, ddy, kb, false, INFINITY));
+            int sx = sax, sy = say;
+            if (depth[(size_t) say * W + sax] < depth[(size_t) sby * W + sbx]) { sx = sbx; sy = sby; }     // :904 the farther (background) end
+            const size_t src = (size_t) sy * W + sx, o = (size_t) px;
+            frame[o * 3] = frame[src * 3]; frame[o * 3 + 1] = frame[src * 3 + 1]; frame[o * 3 + 2] = frame[src * 3 + 2];
+            if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + src];
+        }
+    }
+}
+
 #ifndef KBE_FILL_BLOCK
 #define KBE_FILL_BLOCK 256
 #endif
@@ -2021,8 +2284,7 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
                                                     uint32_t* __restrict__ zkeys, int* __restrict__ tile_count, int n_tiles,
                                                     const int4* __restrict__ bbox, int fill_mode, const uint32_t* __restrict__ coarse,
                                                     int tiles_x, int tiles_y, int reset_scatter_scratch, int* __restrict__ next_hole_count,
-                                                    const uint8_t* __restrict__ dist, const float2* __restrict__ strips,
-                                                    const uint8_t* __restrict__ dist_blocks)
+                                                    int tables)
 {
     // leave the scratch ready for the next frame.  Bucket path: empty z-buffer, empty buckets.  Fused path: it has
     // neither; its hole counters alternate between frames, and this launch zeroes the one the NEXT frame will count in
@@ -2034,25 +2296,15 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
     }
     if (next_hole_count && blockIdx.x == 0 && threadIdx.x == 0) *next_hole_count = 0;
     const int n = min(*hole_count, W * H);
+    if (tables && n >= tables - 1) return;                      // k_fill_tables, launched in front of this kernel, filled this frame
     // A ray is a straight line, monotone in x and in y.  Once it is outside the bounding box of the valid
     // pixels on a side it is not moving back from, it can never meet one: its outcome is "left the image"
     // (common.py:880-885) without walking there.  Exact, and it is what makes a zoomed-out (dolly) frame,
     // where most of the image is empty border, cheap.
     __shared__ int s_bb[KBE_FILL_BLOCK / 64][4];
-    int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
     if ((int) (blockIdx.x * (blockDim.x >> 5)) >= n) return;    // no hole for this block (whole block: uniform)
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-        const int4 bb = bbox[t];
-        bx0 = min(bx0, bb.x); by0 = min(by0, bb.y); bx1 = max(bx1, bb.z); by1 = max(by1, bb.w);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
-        bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
-    }
-    if ((threadIdx.x & 63) == 0) { s_bb[threadIdx.x >> 6][0] = bx0; s_bb[threadIdx.x >> 6][1] = by0; s_bb[threadIdx.x >> 6][2] = bx1; s_bb[threadIdx.x >> 6][3] = by1; }
-    __syncthreads();
-    for (int w = 0; w < KBE_FILL_BLOCK / 64; w++) { bx0 = min(bx0, s_bb[w][0]); by0 = min(by0, s_bb[w][1]); bx1 = max(bx1, s_bb[w][2]); by1 = max(by1, s_bb[w][3]); }
+    int bx0, by0, bx1, by1;
+    valid_box(bbox, n_tiles, W, H, s_bb, bx0, by0, bx1, by1);
     const int wpr = (W + 31) >> 5;              // mask words per row
     // fill_mode: 0 = by hole count (the multi-lane frame loop: the per-lane schedule does less work but has long
     // dependent chains, which only pays when other frames' kernels fill the chip meanwhile), 1 = one lane per hole,
@@ -2064,223 +2316,6 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
         // once (16 additions, the same fp32 sums, no rounding of the positions in between, no mask look-ups).
         if ((int) (blockIdx.x * blockDim.x) >= n) return;       // no hole for this block in this schedule either
         __shared__ uint32_t s_pool[2 * COARSE_WORDS];           // the coarse maps of either schedule
-        if (dist) {
-            // With the tables of k_hole_dist (launched in front of this kernel for frames expected to have very many holes).
-            // A workgroup takes 256 holes at a time.
-            // (1) One lane per hole: the strip test of its 16 directions; the directions that pass -- 4.5 of 16 on the
-            //     dolly bench -- are queued in LDS.
-            // (2) One lane per END of a queued (hole, direction), neighbouring lanes the two ends; ONE loop for everything:
-            //     an iteration is one advance (exactly the fp32 sums of :876-889, on the integer mantissa: struct Axis) and
-            //     one look-up -- the coarse table in LDS, and where that says "near" the fine table -- or, for lanes whose
-            //     direction is decided, waiting until enough lanes wait to fetch new work together.  A direction is
-            //     decided when one end leaves the image or its strip (skipped, :880-885 / :891-896), when both ends stand on
-            //     valid pixels (it enters the hole's contest, :898-900, with an LDS atomicMin: the fp32 length of the span in
-            //     the high word -- positive floats order like their bits -- then the direction: the reference keeps the
-            //     FIRST direction of the shortest length, `best > dd` is strict; then the step counts of the two ends),
-            //     or when its ends are already farther apart than a direction in the contest (they only move apart: it can
-            //     neither win nor tie).
-            // (3) One lane per hole: the winner's end points from its step counts, the fill.
-            // One lane per hole for everything left 3/4 of the lanes idle in every direction and chained ~100 dependent
-            // look-ups per lane (890 us per launch); loops nested per lane (per end, per jump) ran at ~20 % lane use.
-            // Where the time still goes (tools/fill_stats.py, late dolly frames): while the queue has work 49 of 64 lanes
-            // walk; after it has run dry the waves walk their last rays to the barrier with 6 lanes -- more than half of
-            // all loop iterations, whatever the batch size: of 1.9 M ray ends 1.1 M live < 4 iterations and ~1 700 live
-            // 128-335 (rays creeping through speckled regions at 1.3-1.9 steps per iteration).  Tried against that and
-            // slower: the queue in HBM with persistent waves (a look-up per iteration at the hole's key in
-            // L2 instead of LDS), batches of up to 1024 slots claimed from a cursor (3 instead of 5 workgroups per CU),
-            // waves working on their own without any barrier (119 registers, 46 KB: occupancy 3), creeping rays taking 8
-            // steps per iteration in sparse waves (the longest launch 894 -> 724 us, the average 385 -> 405), creeping
-            // rays first in the queue, 6-8 waves per SIMD with the block table read from memory (no change).
-            constexpr int FB = KBE_FILL_BLOCK;
-            static_assert(FB % 64 == 0 && FB * 16 <= 65536, "queue entries are 16 bits");
-            __shared__ unsigned long long s_key[FB];
-            __shared__ uint16_t s_queue[FB * 16];
-            __shared__ int s_px[FB], s_wave_n[FB / 64], s_next;
-            __shared__ uint8_t s_m0[FB];
-            __shared__ float s_dir[2][16];
-            __shared__ int s_off[16];
-            const int cw = tiles_x * (TW / 8);
-            const int c_bytes = cw * tiles_y * (TH / 8);
-            const bool in_lds = c_bytes <= (int) sizeof(s_pool);
-            if (in_lds) for (int i = threadIdx.x; i < (c_bytes + 3) / 4; i += blockDim.x) s_pool[i] = ((const uint32_t*) dist_blocks)[i];
-            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-            if (tid < 16) { s_dir[0][tid] = dirs.x[tid]; s_dir[1][tid] = dirs.y[tid]; s_off[tid] = strip_offset(dirs.x[tid], dirs.y[tid], W, H); }
-            const int bins = strip_bins(W, H);
-            const size_t HW = (size_t) W * H;
-            const bool is_b = lane & 1;                         // the end walking towards +u
-            for (int base = blockIdx.x * FB; base < n; base += gridDim.x * FB) {
-                __syncthreads();                                // the tables are loaded / the previous batch is done with the LDS arrays
-                // (1)
-                const int h = base + tid;
-                int px = -1, x = 0, y = 0;
-                uint32_t pass = 0;
-                if (h < n) {
-                    px = holes[h];
-                    y = px / W; x = px - y * W;
-                    // outside the rectangle to be filled / outside the box of the valid pixels: every direction is skipped
-                    if (x < rect.x0 || x > rect.x1 || y < rect.y0 || y > rect.y1 || x < bx0 || x > bx1 || y < by0 || y > by1) px = -1;
-                }
-                if (px >= 0) {
-                    KBE_FILL_STAT(0, 1);
-                    pass = 0xFFFFu;
-                    if (strips) {
-                        pass = 0;
-#pragma unroll
-                        for (int d = 0; d < 16; d++) {
-                            const float ddx = s_dir[0][d], ddy = s_dir[1][d];
-                            const float c = ddx * (float) y - ddy * (float) x, t = ddx * (float) x + ddy * (float) y;
-                            const float2 lh = strips[(size_t) d * bins + ((int) floorf(c) + s_off[d])];
-                            if (!(lh.x > t + STRIP_MARGIN || lh.y < t - STRIP_MARGIN)) pass |= 1u << d;     // valid pixels on both sides
-                        }
-                    }
-                    if (pass) {
-                        const int c_here = in_lds ? ((const uint8_t*) s_pool)[(y >> 3) * cw + (x >> 3)] : dist_blocks[(y >> 3) * cw + (x >> 3)];
-                        s_m0[tid] = (uint8_t) (c_here >= 2 ? 8 * (c_here - 1) : max(1, (int) dist[(uint32_t) px] - 1));
-                    }
-                }
-                s_px[tid] = px;
-                s_key[tid] = FILL_NO_ENTRY;
-                if (tid == 0) s_next = 0;
-                const int mine = __popc(pass);
-                int incl = mine;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-                if (lane == 63) s_wave_n[wave] = incl;
-                __syncthreads();
-                int at = incl - mine, total = 0;
-                for (int w = 0; w < FB / 64; w++) { if (w < wave) at += s_wave_n[w]; total += s_wave_n[w]; }
-                for (uint32_t m = pass; m; m &= m - 1) s_queue[at++] = (uint16_t) ((tid << 4) | (__ffs(m) - 1));
-                __syncthreads();
-                // (2)
-                {
-                    int st = END_IDLE, rx = 0, ry = 0, k = 0, ix = 0, iy = 0, slot = 0, d = 0;
-#if defined(KBE_FRAME_STATS)
-                    int iters = 0;
-#endif
-                    float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
-                    Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
-                    for (;;) {
-                        // the two ends of a direction look at each other
-                        const int pst = swap_with_neighbour(st), pix = swap_with_neighbour(ix), piy = swap_with_neighbour(iy), pk = swap_with_neighbour(k);
-                        if (st != END_IDLE) {
-                            if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
-                            else {
-                                const float ex = (float) (ix - pix), ey = (float) (iy - piy);
-                                const float ssq = ex * ex + ey * ey;                            // exact: small integers
-                                // the best length in the contest, squared and rounded up a little: a span whose square is
-                                // above that has a longer fp32 length (sqrtf is monotone and correctly rounded)
-                                const float best = __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1]);          // no entry yet: NaN
-                                if (st == END_HIT && pst == END_HIT) {
-                                    const int ka = is_b ? pk : k, kb = is_b ? k : pk;
-                                    const float dd = sqrtf(ssq);                                // :898
-                                    if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
-                                        atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
-                                                                ((unsigned long long) ka << 14) | (unsigned long long) kb);
-                                    st = END_IDLE;
-                                } else if (ssq > best * best * 1.000001f) {                     // NaN: never true
-                                    KBE_FILL_STAT(5, is_b ? 0 : 1);
-                                    st = END_IDLE;
-                                }
-                            }
-                        }
-#if defined(KBE_FRAME_STATS)
-                        if (st == END_IDLE && iters > 0) { KBE_FILL_RAY_DONE(iters, k); iters = 0; }
-                        if (st == END_WALK) iters++;
-#endif
-                        // new work, for a quarter of the wave at a time (fetching runs at the pace of its slowest lane)
-                        const unsigned long long idle = __ballot(st == END_IDLE);
-                        if (idle) {
-                            const int next = *(const volatile int*) &s_next;
-                            if (next >= total) { if (idle == ~0ull) break; }
-                            else if (__popcll(idle) >= KBE_FILL_REFILL_MIN || idle == ~0ull) {
-                                const int n_pairs = __popcll(idle) >> 1;
-                                int first = 0;
-                                if (lane == (int) __ffsll((long long) idle) - 1) first = atomicAdd(&s_next, n_pairs);
-                                first = __shfl(first, (int) __ffsll((long long) idle) - 1);
-                                const int q = first + (__popcll(idle & ((1ull << lane) - 1ull)) >> 1);
-                                if (st == END_IDLE && q < total) {
-                                    const int e = s_queue[q];
-                                    slot = e >> 4; d = e & 15;
-                                    const int qpx = s_px[slot];
-                                    iy = qpx / W; ix = qpx - iy * W;
-                                    ux = s_dir[0][d]; uy = s_dir[1][d];
-                                    inv_umax = 0.999999f / fmaxf(fabsf(ux), fabsf(uy));
-                                    bound = is_b ? INFINITY : -INFINITY;
-                                    if (strips) {
-                                        const float2 lh = strips[(size_t) d * bins + ((int) floorf(ux * (float) iy - uy * (float) ix) + s_off[d])];
-                                        bound = is_b ? lh.y : lh.x;
-                                    }
-                                    X = axis_enter((float) ix, ux, !is_b);
-                                    Y = axis_enter((float) iy, uy, !is_b);
-                                    rx = ry = k = s_m0[slot];
-                                    st = END_WALK;
-                                    KBE_FILL_STAT(1, is_b ? 0 : 1);
-                                }
-                            }
-                        }
-#if defined(KBE_FRAME_STATS)
-                        { const unsigned long long w = __ballot(st == END_WALK), hw = __ballot(st == END_HIT);
-                          const bool empty = *(const volatile int*) &s_next >= total;
-                          if (lane == 0) { KBE_FILL_STAT(6, 1ull | (empty ? 1ull << 32 : 0ull)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | (empty ? (unsigned long long) __popcll(w) << 32 : 0ull));
-                                           KBE_FILL_STAT(0, (unsigned long long) __popcll(hw) << 32); } }
-#endif
-                        // one advance, one look-up
-                        if (st == END_WALK) {
-                            axis_jump(X, rx);
-                            axis_jump(Y, ry);
-                            if (rx | ry) {                      // one of them did not get there: one catch-up, for one axis
-                                const bool on_x = rx > 0;
-                                Axis a = on_x ? X : Y;
-                                int r = on_x ? rx : ry;
-                                KBE_FILL_STAT(4, 1);
-                                axis_catch_up(a, r, on_x ? ux : uy, !is_b, on_x ? (float) W : (float) H);
-                                if (on_x) { X = a; rx = r; } else { Y = a; ry = r; }
-                            }
-                            if ((rx | ry) == 0) {
-                                ix = axis_pixel(X); iy = axis_pixel(Y);
-                                const float t = ux * (float) ix + uy * (float) iy;
-                                int m = 0;
-                                if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
-                                else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
-                                else {
-                                    const int ci = (iy >> 3) * cw + (ix >> 3);
-                                    const int c = in_lds ? ((const uint8_t*) s_pool)[ci] : dist_blocks[ci];
-                                    KBE_FILL_STAT(3, 1);
-                                    // With the nearest valid pixel D away (Chebyshev) from this one, the pixel j steps
-                                    // on is at most j max(|ux|, |uy|) + 1 away from this one (the steps; the rounding of
-                                    // both positions; < 0.03 of drift): a hole for sure while j umax + 1.03 < D.  The first
-                                    // position to look at is step ceil((D - 1.03) / umax).
-                                    if (c >= KBE_FILL_FINE_BELOW) m = (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f);   // D >= 8 (c - 1) + 1
-                                    else {
-                                        const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
-                                        KBE_FILL_STAT(2, 1);
-                                        if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
-                                        else m = max(c >= 2 ? (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f) : 1, (int) ceilf(((float) dn - 1.03f) * inv_umax));
-                                    }
-                                }
-                                rx = ry = m;
-                                k += m;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                // (3)
-                const unsigned long long key = s_key[tid];
-                if (px >= 0 && key != FILL_NO_ENTRY) {
-                    const int d = (int) (key >> 28) & 15, ka = (int) (key >> 14) & FILL_MAX_STEPS, kb = (int) key & FILL_MAX_STEPS;
-                    const float ddx = s_dir[0][d], ddy = s_dir[1][d];
-                    const int sax = (int) roundf(advance_exact((float) x, ddx, ka, true, INFINITY)), say = (int) roundf(advance_exact((float) y, ddy, ka, true, INFINITY));
-                    const int sbx = (int) roundf(advance_exact((float) x, ddx, kb, false, INFINITY)), sby = (int) roundf(advance_exact((float) y, ddy, kb, false, INFINITY));
-                    int sx = sax, sy = say;
-                    if (depth[(size_t) say * W + sax] < depth[(size_t) sby * W + sbx]) { sx = sbx; sy = sby; }     // :904 the farther (background) end
-                    const size_t src = (size_t) sy * W + sx, o = (size_t) px;
-                    frame[o * 3] = frame[src * 3]; frame[o * 3 + 1] = frame[src * 3 + 1]; frame[o * 3 + 2] = frame[src * 3 + 2];
-                    if (render) for (int c = 0; c < 4; c++) render[c * HW + o] = render[c * HW + src];
-                }
-            }
-            return;
-        }
         uint32_t* s_blk = s_pool, *s_near = s_pool + COARSE_WORDS;
         constexpr int CX = TW / 8, CY = TH / 8;                 // coarse blocks per tile
         const int c_rows = tiles_y * CY, c_wpr = (tiles_x * CX + 31) >> 5;
@@ -2487,6 +2522,28 @@ __global__ void __launch_bounds__(DELIVER_THREADS) k_deliver(const uint8_t* __re
     }
 }
 
+// the hole fill of one frame: with KBE_STAGE_FILL_DIST the tables and the table-driven fill in front of k_fill_holes (each of
+// them returns at once when the frame has fewer holes than the schedule asks for)
+void launch_fill(hipStream_t s, const Scratch& sc, int W, int H, const int* hole_count, int stages, const FillDirs& dirs, const FillRect& rect,
+                 unsigned fill_blocks, uint8_t* frame_u8, float* render_f32, int n_tiles, int reset_scatter_scratch, int* next_hole_count)
+{
+    int tables = 0;
+    const int fill_mode = (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0);
+    if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
+        const int min_holes = (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN;
+        const float2* strips = strips_fit(sc) ? sc.strips : nullptr;
+        launch_hole_dist(s, sc, W, H, hole_count, min_holes, dirs, strips);
+        const size_t hw = (size_t) W * H;
+        const unsigned blocks = (unsigned) ((hw + 255) / 256 < KBE_FILL_MAX_BLOCKS ? (hw + 255) / 256 : KBE_FILL_MAX_BLOCKS);
+        hipLaunchKernelGGL(k_fill_tables, dim3(blocks), dim3(256), 0, s, sc.holes, hole_count, min_holes, sc.depth, W, H, dirs, rect, frame_u8, render_f32,
+                           n_tiles, sc.bbox, sc.tiles_x, sc.tiles_y, sc.dist, strips, sc.dist_blocks);
+        tables = 1 + min_holes;                                 // k_fill_holes: the frame is done if it has >= tables - 1 holes
+    }
+    hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, hole_count, sc.depth, sc.mask, W, H, dirs, rect,
+                       frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox, fill_mode,
+                       sc.coarse, sc.tiles_x, sc.tiles_y, reset_scatter_scratch, next_hole_count, tables);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2576,17 +2633,7 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
         const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        const uint8_t* dist = nullptr;
-        const float2* strips = nullptr;
-        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
-            strips = strips_fit(sc) ? sc.strips : nullptr;
-            launch_hole_dist(s, sc, W, H, sc.hole_count, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
-            dist = sc.dist;
-        }
-        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, sc.hole_count, sc.depth, sc.mask, W, H, dirs, rect,
-                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
-                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y, alternate ? 0 : 1, (int*) nullptr, dist, strips, sc.dist_blocks);
+        launch_fill(s, sc, W, H, sc.hole_count, stages, dirs, rect, fill_blocks, frame_u8, render_f32, n_tiles, alternate ? 0 : 1, (int*) nullptr);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -2637,17 +2684,7 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
         const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        const uint8_t* dist = nullptr;
-        const float2* strips = nullptr;
-        if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
-            strips = strips_fit(sc) ? sc.strips : nullptr;
-            launch_hole_dist(s, sc, W, H, count_now, (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN, dirs, strips);
-            dist = sc.dist;
-        }
-        hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, count_now, sc.depth, sc.mask, W, H, dirs, rect,
-                           frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox,
-                           (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0),
-                           sc.coarse, sc.tiles_x, sc.tiles_y, 0, parity >= 0 ? count_next : (int*) nullptr, dist, strips, sc.dist_blocks);
+        launch_fill(s, sc, W, H, count_now, stages, dirs, rect, fill_blocks, frame_u8, render_f32, n_tiles, 0, parity >= 0 ? count_next : (int*) nullptr);
         rc = launched("kbe_render_frame_fused/fill");
     }
     return rc;
