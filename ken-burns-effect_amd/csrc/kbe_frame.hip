@@ -1993,6 +1993,12 @@ __device__ __forceinline__ void axis_catch_up(Axis& ax, int& r, float u, bool su
     if (r > 0) axis_jump(ax, r);
 }
 
+#ifndef KBE_FILL_BURST
+#define KBE_FILL_BURST 8                // steps a creeping ray takes together ...
+#endif
+#ifndef KBE_FILL_BURST_LANES
+#define KBE_FILL_BURST_LANES 16         // ... in a wave whose queue has run dry and of which no more lanes than this still walk
+#endif
 #ifndef KBE_FILL_REFILL_MIN
 #define KBE_FILL_REFILL_MIN 16          // lanes of a wave that must be waiting before new work is fetched
 #endif
@@ -2149,30 +2155,116 @@ __global__ void __launch_bounds__(256) k_fill_tables(const int* __restrict__ hol
 #endif
             float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
             Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
-            for (;;) {
-                // the two ends of a direction look at each other
-                const int pst = swap_with_neighbour(st), pix = swap_with_neighbour(ix), piy = swap_with_neighbour(iy), pk = swap_with_neighbour(k);
-                if (st != END_IDLE) {
-                    if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
-                    else {
-                        const float ex = (float) (ix - pix), ey = (float) (iy - piy);
-                        const float ssq = ex * ex + ey * ey;                            // exact: small integers
-                        // the best length in the contest, squared and rounded up a little: a span whose square is
-                        // above that has a longer fp32 length (sqrtf is monotone and correctly rounded)
-                        const float best = __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1]);          // no entry yet: NaN
-                        if (st == END_HIT && pst == END_HIT) {
-                            const int ka = is_b ? pk : k, kb = is_b ? k : pk;
-                            const float dd = sqrtf(ssq);                                // :898
-                            if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
-                                atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
-                                                        ((unsigned long long) ka << 14) | (unsigned long long) kb);
-                            st = END_IDLE;
-                        } else if (ssq > best * best * 1.000001f) {                     // NaN: never true
-                            KBE_FILL_STAT(5, is_b ? 0 : 1);
-                            st = END_IDLE;
+            // the two ends of a direction look at each other
+            const auto look = [&]() {
+                    const int pst = swap_with_neighbour(st), pix = swap_with_neighbour(ix), piy = swap_with_neighbour(iy), pk = swap_with_neighbour(k);
+                    if (st != END_IDLE) {
+                        if (st == END_DEAD || pst == END_DEAD) st = END_IDLE;
+                        else {
+                            const float ex = (float) (ix - pix), ey = (float) (iy - piy);
+                            const float ssq = ex * ex + ey * ey;                            // exact: small integers
+                            // the best length in the contest, squared and rounded up a little: a span whose square is
+                            // above that has a longer fp32 length (sqrtf is monotone and correctly rounded)
+                            const float best = __uint_as_float(((const volatile uint32_t*) &s_key[slot])[1]);          // no entry yet: NaN
+                            if (st == END_HIT && pst == END_HIT) {
+                                const int ka = is_b ? pk : k, kb = is_b ? k : pk;
+                                const float dd = sqrtf(ssq);                                // :898
+                                if (!is_b && 1000000.0f > dd && ka <= FILL_MAX_STEPS && kb <= FILL_MAX_STEPS)      // :854, :900
+                                    atomicMin(&s_key[slot], ((unsigned long long) __float_as_uint(dd) << 32) | ((unsigned long long) d << 28) |
+                                                            ((unsigned long long) ka << 14) | (unsigned long long) kb);
+                                st = END_IDLE;
+                            } else if (ssq > best * best * 1.000001f) {                     // NaN: never true
+                                KBE_FILL_STAT(5, is_b ? 0 : 1);
+                                st = END_IDLE;
+                            }
                         }
                     }
+            };
+            const auto step = [&]() {
+                    // one advance, one look-up
+                    if (st == END_WALK) {
+                        axis_jump(X, rx);
+                        axis_jump(Y, ry);
+                        if (rx | ry) {                      // one of them did not get there: one catch-up, for one axis
+                            const bool on_x = rx > 0;
+                            Axis a = on_x ? X : Y;
+                            int r = on_x ? rx : ry;
+                            KBE_FILL_STAT(4, 1);
+                            axis_catch_up(a, r, on_x ? ux : uy, !is_b, on_x ? (float) W : (float) H);
+                            if (on_x) { X = a; rx = r; } else { Y = a; ry = r; }
+                        }
+                        if ((rx | ry) == 0) {
+                            ix = axis_pixel(X); iy = axis_pixel(Y);
+                            const float t = ux * (float) ix + uy * (float) iy;
+                            int m = 0;
+                            if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
+                            else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
+                            else {
+                                const int ci = (iy >> 3) * cw + (ix >> 3);
+                                const int c = block_distance(ci);
+                                KBE_FILL_STAT(3, 1);
+                                // With the nearest valid pixel D away (Chebyshev) from this one, the pixel j steps
+                                // on is at most j max(|ux|, |uy|) + 1 away from this one (the steps; the rounding of
+                                // both positions; < 0.03 of drift): a hole for sure while j umax + 1.03 < D.  The first
+                                // position to look at is step ceil((D - 1.03) / umax).
+                                if (c >= KBE_FILL_FINE_BELOW) m = (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f);   // D >= 8 (c - 1) + 1
+                                else {
+                                    const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
+                                    KBE_FILL_STAT(2, 1);
+                                    if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
+                                    else m = max(c >= 2 ? (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f) : 1, (int) ceilf(((float) dn - 1.03f) * inv_umax));
+                                }
+                            }
+                            rx = ry = m;
+                            k += m;
+                        }
+                    }
+            };
+            // A ray creeping through a speckled region (a valid pixel next to every position, none on the ray) takes one
+            // step per look-up for a hundred iterations and more -- ~1 700 of the 1.9 M ray ends of a late dolly frame live
+            // 128-335 iterations -- and its workgroup waits for it.  Once the queue has run dry and few lanes of the wave still
+            // walk, such a ray takes its next KBE_FILL_BURST steps together: the positions do not depend on what is found
+            // there, so their look-ups go out at once, and the first that ends the ray (a valid pixel, the image border, the
+            // end of its strip) counts.  In a loop of its own: the same code inside the main loop made that one 18 % slower
+            // without ever running.
+            const auto creep = [&]() -> bool {
+                if (!(st == END_WALK && rx == ry && rx >= 1 && rx <= 2)) return false;
+                constexpr int B = KBE_FILL_BURST;
+                float fx = axis_value(X), fy = axis_value(Y);
+                int bpx[B], bpy[B], bdn[B];
+                bool bstop[B];
+#pragma unroll
+                for (int j = 0; j < B; j++) {
+                    fx = is_b ? fx + ux : fx - ux;                      // :876-877 / :887-888
+                    fy = is_b ? fy + uy : fy - uy;
+                    bpx[j] = (int) roundf(fx); bpy[j] = (int) roundf(fy);
+                    const bool inb = ((unsigned) bpx[j] < (unsigned) W) & ((unsigned) bpy[j] < (unsigned) H);
+                    const float t = ux * (float) bpx[j] + uy * (float) bpy[j];
+                    bstop[j] = !inb || (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN);
+                    bdn[j] = dist[inb ? (uint32_t) bpy[j] * (uint32_t) W + (uint32_t) bpx[j] : 0u];
                 }
+                KBE_FILL_STAT(2, B);
+                k -= rx;                                                // the pending steps are among these
+                bool decided = false;
+#pragma unroll
+                for (int j = 0; j < B; j++) {
+                    if (decided) continue;
+                    if (bstop[j]) { st = END_DEAD; decided = true; }
+                    else if (bdn[j] == 0) { st = END_HIT; ix = bpx[j]; iy = bpy[j]; k += j + 1; decided = true; }
+                }
+                if (!decided) {
+                    ix = bpx[B - 1]; iy = bpy[B - 1];
+                    X = axis_enter(fx, ux, !is_b);
+                    Y = axis_enter(fy, uy, !is_b);
+                    const int m = max(1, (int) ceilf(((float) bdn[B - 1] - 1.03f) * inv_umax));
+                    rx = ry = m;
+                    k += B + m;
+                }
+                return true;
+            };
+            bool stragglers = false;
+            for (;;) {
+                look();
 #if defined(KBE_FRAME_STATS)
                 if (st == END_IDLE && iters > 0) { KBE_FILL_RAY_DONE(iters, k); iters = 0; }
                 if (st == END_WALK) iters++;
@@ -2181,7 +2273,10 @@ __global__ void __launch_bounds__(256) k_fill_tables(const int* __restrict__ hol
                 const unsigned long long idle = __ballot(st == END_IDLE);
                 if (idle) {
                     const int next = *(const volatile int*) &s_next;
-                    if (next >= total) { if (idle == ~0ull) break; }
+                    if (next >= total) {
+                        if (idle == ~0ull) break;
+                        if (64 - __popcll(idle) <= KBE_FILL_BURST_LANES) { stragglers = true; break; }
+                    }
                     else if (__popcll(idle) >= KBE_FILL_REFILL_MIN || idle == ~0ull) {
                         const int n_pairs = __popcll(idle) >> 1;
                         int first = 0;
@@ -2214,45 +2309,20 @@ __global__ void __launch_bounds__(256) k_fill_tables(const int* __restrict__ hol
                   if (lane == 0) { KBE_FILL_STAT(6, 1ull | (empty ? 1ull << 32 : 0ull)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | (empty ? (unsigned long long) __popcll(w) << 32 : 0ull));
                                    KBE_FILL_STAT(0, (unsigned long long) __popcll(hw) << 32); } }
 #endif
-                // one advance, one look-up
-                if (st == END_WALK) {
-                    axis_jump(X, rx);
-                    axis_jump(Y, ry);
-                    if (rx | ry) {                      // one of them did not get there: one catch-up, for one axis
-                        const bool on_x = rx > 0;
-                        Axis a = on_x ? X : Y;
-                        int r = on_x ? rx : ry;
-                        KBE_FILL_STAT(4, 1);
-                        axis_catch_up(a, r, on_x ? ux : uy, !is_b, on_x ? (float) W : (float) H);
-                        if (on_x) { X = a; rx = r; } else { Y = a; ry = r; }
-                    }
-                    if ((rx | ry) == 0) {
-                        ix = axis_pixel(X); iy = axis_pixel(Y);
-                        const float t = ux * (float) ix + uy * (float) iy;
-                        int m = 0;
-                        if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
-                        else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
-                        else {
-                            const int ci = (iy >> 3) * cw + (ix >> 3);
-                            const int c = block_distance(ci);
-                            KBE_FILL_STAT(3, 1);
-                            // With the nearest valid pixel D away (Chebyshev) from this one, the pixel j steps
-                            // on is at most j max(|ux|, |uy|) + 1 away from this one (the steps; the rounding of
-                            // both positions; < 0.03 of drift): a hole for sure while j umax + 1.03 < D.  The first
-                            // position to look at is step ceil((D - 1.03) / umax).
-                            if (c >= KBE_FILL_FINE_BELOW) m = (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f);   // D >= 8 (c - 1) + 1
-                            else {
-                                const int dn = dist[(uint32_t) iy * (uint32_t) W + (uint32_t) ix];
-                                KBE_FILL_STAT(2, 1);
-                                if (dn == 0) st = END_HIT;          // depth > 0 (:882 / :893)
-                                else m = max(c >= 2 ? (int) ceilf((float) (8 * (c - 1)) * inv_umax - 0.03f) : 1, (int) ceilf(((float) dn - 1.03f) * inv_umax));
-                            }
-                        }
-                        rx = ry = m;
-                        k += m;
-                    }
-                }
+                step();
             }
+            // the wave's last rays (the queue has run dry, <= KBE_FILL_BURST_LANES lanes still walk): creeping ones in bursts
+            if (stragglers)
+                for (;;) {
+                    look();
+                    if (__ballot(st != END_IDLE) == 0ull) break;
+#if defined(KBE_FRAME_STATS)
+                    if (st == END_IDLE && iters > 0) { KBE_FILL_RAY_DONE(iters, k); iters = 0; }
+                    if (st == END_WALK) iters++;
+                    { const unsigned long long w = __ballot(st == END_WALK); if (lane == 0) { KBE_FILL_STAT(6, 1ull | (1ull << 32)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | ((unsigned long long) __popcll(w) << 32)); } }
+#endif
+                    if (!creep()) step();
+                }
         }
         __syncthreads();
         // (3)
