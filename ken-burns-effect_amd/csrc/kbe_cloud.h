@@ -1,5 +1,5 @@
 // kbe_cloud.h -- the packed point cloud of the fused frame kernel: layout shared by kbe_cloud.hip (which builds it)
-// and kbe_frame.hip (which renders from it).
+// and kbe_fused.hip (which renders from it).
 //
 // The reference keeps the cloud as three tensors in whatever order process_inpaint appended the points
 // (common.py:176-179, :76-80) and scatters every point into the target raster with global atomics.  The fused

@@ -1,4 +1,4 @@
-"""CPU checks behind the table-driven hole fill of ken-burns-effect_amd/csrc/kbe_frame.hip (k_hole_dist, struct Axis), as C
+"""CPU checks behind the table-driven hole fill of ken-burns-effect_amd/csrc/kbe_holes.hip (k_hole_dist, struct Axis), as C
 restatements of its arithmetic against brute force (no GPU, no oracle):
   * tools/advance_check.c -- m fp32 additions of a fill direction taken on the integer mantissa (axis_jump,
     axis_catch_up, advance_exact) against the additions one at a time (common.py:876-889): bits and pixels identical;

@@ -178,7 +178,7 @@ def test_get_masks_plumbing_with_the_oracle_kernel_set(oracle):
 
 
 def test_shared_reciprocal_division_is_the_correctly_rounded_division(tmp_path):
-    """kbe_frame.hip resolve: four numerators over one denominator = one IEEE reciprocal + a Markstein step each."""
+    """kbe_tiles.h tile_epilogue (resolve): four numerators over one denominator = one IEEE reciprocal + a Markstein step each."""
     import os
     import subprocess
     exe = str(tmp_path / 'markstein_div_check')

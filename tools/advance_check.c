@@ -1,5 +1,5 @@
 // CPU check of the integer-mantissa walk of the hole fill (struct Axis, axis_jump, axis_catch_up and advance_exact in
-// ken-burns-effect_amd/csrc/kbe_frame.hip, restated here in C): sequences of m fp32 additions taken as the kernel takes
+// ken-burns-effect_amd/csrc/kbe_holes.hip, restated here in C): sequences of m fp32 additions taken as the kernel takes
 // them against the additions one at a time -- the 16 fill directions, both axes, both senses, starts 0..9000,
 // m up to 250 (dev aid).
 //   gcc -O2 -ffp-contract=off -o /tmp/advance_check tools/advance_check.c -lm && /tmp/advance_check

@@ -10,9 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = '/tmp/libkbe_stats.so'
 src = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
-subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared',
-                       '-fvisibility=hidden', '-DKBE_FRAME_STATS', '-I' + os.path.join(ROOT, 'include'), '-I' + src,
-                       os.path.join(src, 'kbe_hip.hip'), os.path.join(src, 'kbe_frame.hip'), os.path.join(src, 'kbe_cloud.hip'), '-o', so])
+subprocess.check_call(['make', '-s', '-B', '-C', src, 'EXTRA=-DKBE_FRAME_STATS', 'OUT=' + so])
 import torch  # noqa: E402
 
 import bench  # noqa: E402

@@ -7,8 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for flags in "$@"; do
   so=/tmp/libkbe_case_$i.so
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -I$R/include -I$R/ken-burns-effect_amd/csrc $flags \
-      $R/ken-burns-effect_amd/csrc/kbe_hip.hip $R/ken-burns-effect_amd/csrc/kbe_frame.hip $R/ken-burns-effect_amd/csrc/kbe_cloud.hip -o $so || exit 1
+  make -s -B -C $R/ken-burns-effect_amd/csrc EXTRA="$flags" OUT=$so || exit 1
   echo "==== variant: ${flags:-(default)}"
   for c in ${CASES:-"CLOUD=inpaint,DOLLY=0" "CLOUD=raw,DOLLY=0" "CLOUD=raw,DOLLY=1"}; do
     echo "== $c"

@@ -8,8 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for flags in "$@"; do
   so=/tmp/libkbe_var_$i.so
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -I$R/include -I$R/ken-burns-effect_amd/csrc $flags \
-      $R/ken-burns-effect_amd/csrc/kbe_hip.hip $R/ken-burns-effect_amd/csrc/kbe_frame.hip $R/ken-burns-effect_amd/csrc/kbe_cloud.hip -o $so || exit 1
+  make -s -B -C $R/ken-burns-effect_amd/csrc EXTRA="$flags" OUT=$so || exit 1
   rm -rf /tmp/v$i
   KBE_LIB_PATH=$so FRAMES=9 timeout 600 rocprofv3 --pmc $PMC -d /tmp/v$i -o c --output-format csv -- python $R/tools/frame_once.py > /tmp/v$i.log 2>&1 || tail -5 /tmp/v$i.log
   echo "== variant: ${flags:-(default)}"

@@ -1,4 +1,4 @@
-// Prototype of the strip tables of the hole fill (ken-burns-effect_amd/csrc/kbe_frame.hip, build_strips): how many
+// Prototype of the strip tables of the hole fill (ken-burns-effect_amd/csrc/kbe_holes.hip, build_strips): how many
 // (hole, direction) pairs pass the test, and is it conservative -- does any direction that completes in a brute-force
 // walk get skipped?  (dev aid)   Input: the validity mask of a 1024 x 1024 frame, one byte per pixel (existing > 0).
 //   gcc -O2 -ffp-contract=off -o /tmp/strip_proto tools/strip_proto.c -lm && /tmp/strip_proto mask.u8
