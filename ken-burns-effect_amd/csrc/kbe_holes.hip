@@ -536,7 +536,12 @@ __device__ __forceinline__ void valid_box(const int4* __restrict__ bbox, int n_t
 // that its loop gets its own register allocation and code: inside k_fill_holes, next to the other two schedules, the same
 // loop ran 20 % slower whenever code was added anywhere in that kernel).  `min_holes`: frames with fewer holes are left
 // to k_fill_holes, which is launched behind this kernel in any case (housekeeping) and skips the frames filled here.
-__global__ void __launch_bounds__(256) k_fill_tables(const int* __restrict__ holes, const int* __restrict__ hole_count, int min_holes,
+#if defined(KBE_FILL_TABLES_WAVES)
+#define KBE_FILL_TABLES_ATTR __attribute__((amdgpu_waves_per_eu(KBE_FILL_TABLES_WAVES, KBE_FILL_TABLES_WAVES)))
+#else
+#define KBE_FILL_TABLES_ATTR
+#endif
+__global__ void __launch_bounds__(256) KBE_FILL_TABLES_ATTR k_fill_tables(const int* __restrict__ holes, const int* __restrict__ hole_count, int min_holes,
                                                      const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
                                                      uint8_t* __restrict__ frame, float* __restrict__ render, int n_tiles,
                                                      const int4* __restrict__ bbox, int tiles_x, int tiles_y,
