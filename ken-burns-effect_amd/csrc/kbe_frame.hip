@@ -800,7 +800,8 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     if (stages & KBE_STAGE_FILL) {
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        launch_fill(s, sc, W, H, sc.hole_count, stages, dirs, rect, frame_u8, render_f32, n_tiles, alternate ? 0 : 1, (int*) nullptr);
+        const FillTarget target = { sc, sc.hole_count, frame_u8, render_f32, alternate ? 0 : 1, nullptr };
+        launch_fill(s, 1, &target, W, H, stages, dirs, rect, n_tiles);
         rc = launched("kbe_render_frame/fill");
     }
     return rc;
@@ -842,7 +843,8 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     if (stages & KBE_STAGE_FILL) {
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        launch_fill(s, sc, W, H, count_now, stages, dirs, rect, frame_u8, render_f32, n_tiles, 0, parity >= 0 ? count_next : (int*) nullptr);
+        const FillTarget target = { sc, count_now, frame_u8, render_f32, 0, parity >= 0 ? count_next : nullptr };
+        launch_fill(s, 1, &target, W, H, stages, dirs, rect, n_tiles);
         rc = launched("kbe_render_frame_fused/fill");
     }
     return rc;

@@ -322,7 +322,7 @@ __device__ __forceinline__ void dilate_distances(Load load, int bx, int by, int 
 // those of the coarse table (the same distance between 8 x 8-pixel blocks, from the tiles' `coarse` bits: where a
 // block is k >= 2 blocks from the nearest block with a valid pixel, every pixel of it is at least 8 (k - 1) + 1 pixels
 // from one -- jumps of up to 240 steps through empty space, looked up in LDS by the fill)
-__global__ void __launch_bounds__(256) k_hole_dist(const uint32_t* __restrict__ mask, int W, int H, uint8_t* __restrict__ dist,
+__device__ __forceinline__ void hole_dist_body(const uint32_t* __restrict__ mask, int W, int H, uint8_t* __restrict__ dist,
                                                    const int* __restrict__ hole_count, int min_holes,
                                                    const int4* __restrict__ bbox, int tiles_x, int tiles_y, float2* __restrict__ strips, FillDirs dirs,
                                                    const uint32_t* __restrict__ coarse, uint8_t* __restrict__ dist_blocks, int image_rows)
@@ -365,15 +365,6 @@ inline bool fill_tables_fit(int W, int H) { return W <= 11000 && H <= 11000; }
 
 // the extents the strip tables are built from: up to STRIP_TILES tile rows / columns
 inline bool strips_fit(const Scratch& sc) { return sc.tiles_x <= STRIP_TILES && sc.tiles_y <= STRIP_TILES; }
-
-void launch_hole_dist(hipStream_t s, const Scratch& sc, int W, int H, const int* hole_count, int min_holes, const FillDirs& dirs, const float2* strips)
-{
-    const int gx = (W + DT_W - 1) / DT_W, gy = (H + DT_H - 1) / DT_H;
-    const int cw = sc.tiles_x * (TW / 8), ch = sc.tiles_y * (TH / 8);
-    const int extra = 16 * ((strip_bins(W, H) + 255) / 256) + ((cw + DT_W - 1) / DT_W) * ((ch + DT_H - 1) / DT_H);
-    hipLaunchKernelGGL(k_hole_dist, dim3(gx, gy + (extra + gx - 1) / gx), dim3(256), 0, s, sc.mask, W, H, sc.dist, hole_count, min_holes,
-                       sc.bbox, sc.tiles_x, sc.tiles_y, (float2*) strips, dirs, sc.coarse, sc.dist_blocks, gy);
-}
 
 // m repeated fp32 additions a := a - u (or + u), exactly, in a few steps.  While a stays in one binade [2^e, 2^(e+1))
 // every value of the chain is a multiple of q = 2^(e-23), and each rounded sum moves a by the SAME amount R = u rounded to
@@ -541,7 +532,7 @@ __device__ __forceinline__ void valid_box(const int4* __restrict__ bbox, int n_t
 #else
 #define KBE_FILL_TABLES_ATTR
 #endif
-__global__ void __launch_bounds__(256) KBE_FILL_TABLES_ATTR k_fill_tables(const int* __restrict__ holes, const int* __restrict__ hole_count, int min_holes,
+__device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, const int* __restrict__ hole_count, int min_holes,
                                                      const float* __restrict__ depth, int W, int H, FillDirs dirs, FillRect rect,
                                                      uint8_t* __restrict__ frame, float* __restrict__ render, int n_tiles,
                                                      const int4* __restrict__ bbox, int tiles_x, int tiles_y,
@@ -852,7 +843,7 @@ __global__ void __launch_bounds__(256) KBE_FILL_TABLES_ATTR k_fill_tables(const 
 #ifndef KBE_FILL_MAX_BLOCKS
 #define KBE_FILL_MAX_BLOCKS 2048
 #endif
-__global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __restrict__ holes, const int* __restrict__ hole_count,
+__device__ __forceinline__ void fill_holes_body(const int* __restrict__ holes, const int* __restrict__ hole_count,
                                                     const float* __restrict__ depth, const uint32_t* __restrict__ mask, int W, int H,
                                                     FillDirs dirs, FillRect rect,
                                                     uint8_t* __restrict__ frame, float* __restrict__ render,
@@ -1020,29 +1011,67 @@ __global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(const int* __rest
 
 }  // namespace
 
-namespace kbe {
-// the hole fill of one frame: with KBE_STAGE_FILL_DIST the tables and the table-driven fill in front of k_fill_holes (each of
-// them returns at once when the frame has fewer holes than the schedule asks for)
-void launch_fill(hipStream_t s, const Scratch& sc, int W, int H, const int* hole_count, int stages, const FillDirs& dirs, const FillRect& rect,
-                 uint8_t* frame_u8, float* render_f32, int n_tiles, int reset_scatter_scratch, int* next_hole_count)
+namespace {
+
+// The kernels of a fill take up to KBE_FILL_JOBS frames per launch (blockIdx.z / .y = the frame): a lane of the video loop
+// whose frames fill with the tables renders two frames and fills them TOGETHER -- the table-driven fill is bound by its
+// own chain of dependent look-ups (272 us alone on the chip, 352 us with four of them overlapping), so two frames per
+// launch take little longer than one.
+__global__ void __launch_bounds__(256) k_hole_dist(FillJobs jobs, int W, int H, int min_holes, int tiles_x, int tiles_y, FillDirs dirs, int image_rows, int use_strips)
 {
+    const FillJob& J = jobs.j[blockIdx.z];
+    hole_dist_body(J.mask, W, H, J.dist, J.hole_count, min_holes, J.bbox, tiles_x, tiles_y, use_strips ? J.strips : nullptr, dirs, J.coarse, J.dist_blocks, image_rows);
+}
+
+__global__ void __launch_bounds__(256) KBE_FILL_TABLES_ATTR k_fill_tables(FillJobs jobs, int min_holes, int W, int H, FillDirs dirs, FillRect rect, int n_tiles,
+                                                                         int tiles_x, int tiles_y, int use_strips)
+{
+    const FillJob& J = jobs.j[blockIdx.y];
+    fill_tables_body(J.holes, J.hole_count, min_holes, J.depth, W, H, dirs, rect, J.frame, J.render, n_tiles, J.bbox, tiles_x, tiles_y, J.dist,
+                     use_strips ? J.strips : nullptr, J.dist_blocks);
+}
+
+__global__ void __launch_bounds__(KBE_FILL_BLOCK) k_fill_holes(FillJobs jobs, int W, int H, FillDirs dirs, FillRect rect, int n_tiles, int fill_mode,
+                                                               int tiles_x, int tiles_y, int tables)
+{
+    const FillJob& J = jobs.j[blockIdx.y];
+    fill_holes_body(J.holes, J.hole_count, J.depth, J.mask, W, H, dirs, rect, J.frame, J.render, J.zkeys, J.tile_count, n_tiles, J.bbox, fill_mode, J.coarse,
+                    tiles_x, tiles_y, J.reset_scatter_scratch, J.next_hole_count, tables);
+}
+
+}  // namespace
+
+namespace kbe {
+// the hole fill of `n_jobs` frames of the same size (1 or 2): with KBE_STAGE_FILL_DIST the tables and the table-driven fill in
+// front of k_fill_holes (each of them returns at once when a frame has fewer holes than the schedule asks for)
+void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, int H, int stages, const FillDirs& dirs, const FillRect& rect, int n_tiles)
+{
+    FillJobs jobs;
+    const Scratch& sc0 = targets[0].sc;
+    for (int k = 0; k < KBE_FILL_JOBS; k++) {
+        const FillTarget& t = targets[k < n_jobs ? k : 0];
+        FillJob& j = jobs.j[k];
+        j.holes = t.sc.holes; j.hole_count = t.hole_count; j.depth = t.sc.depth; j.mask = t.sc.mask; j.frame = t.frame_u8; j.render = t.render_f32;
+        j.zkeys = t.sc.zkeys; j.tile_count = t.sc.tile_count; j.bbox = t.sc.bbox; j.coarse = t.sc.coarse; j.dist = t.sc.dist; j.strips = t.sc.strips;
+        j.dist_blocks = t.sc.dist_blocks; j.reset_scatter_scratch = t.reset_scatter_scratch; j.next_hole_count = t.next_hole_count;
+    }
     const size_t want_fill = (size_t) W * H / 64, max_fill = (size_t) KBE_FILL_MAX_BLOCKS * 256 / KBE_FILL_BLOCK;       // the same number of threads
     const unsigned fill_blocks = (unsigned) (want_fill < max_fill ? (want_fill > 0 ? want_fill : 1) : max_fill);
     int tables = 0;
     const int fill_mode = (stages & KBE_STAGE_FILL_PER_LANE) ? 1 : ((stages & KBE_STAGE_FILL_PER_HALFWAVE) || !(stages & KBE_STAGE_FILL_BY_COUNT) ? 2 : 0);
     if ((stages & KBE_STAGE_FILL_DIST) && (stages & (KBE_STAGE_FILL_PER_LANE | KBE_STAGE_FILL_BY_COUNT)) && fill_tables_fit(W, H)) {
         const int min_holes = (stages & KBE_STAGE_FILL_PER_LANE) ? 0 : KBE_FILL_SERIAL_MIN;
-        const float2* strips = strips_fit(sc) ? sc.strips : nullptr;
-        launch_hole_dist(s, sc, W, H, hole_count, min_holes, dirs, strips);
+        const int use_strips = strips_fit(sc0) ? 1 : 0;
+        const int gx = (W + DT_W - 1) / DT_W, gy = (H + DT_H - 1) / DT_H;
+        const int cw = sc0.tiles_x * (TW / 8), ch = sc0.tiles_y * (TH / 8);
+        const int extra = 16 * ((strip_bins(W, H) + 255) / 256) + ((cw + DT_W - 1) / DT_W) * ((ch + DT_H - 1) / DT_H);
+        hipLaunchKernelGGL(k_hole_dist, dim3(gx, gy + (extra + gx - 1) / gx, n_jobs), dim3(256), 0, s, jobs, W, H, min_holes, sc0.tiles_x, sc0.tiles_y, dirs, gy, use_strips);
         const size_t hw = (size_t) W * H;
         const unsigned blocks = (unsigned) ((hw + 255) / 256 < KBE_FILL_MAX_BLOCKS ? (hw + 255) / 256 : KBE_FILL_MAX_BLOCKS);
-        hipLaunchKernelGGL(k_fill_tables, dim3(blocks), dim3(256), 0, s, sc.holes, hole_count, min_holes, sc.depth, W, H, dirs, rect, frame_u8, render_f32,
-                           n_tiles, sc.bbox, sc.tiles_x, sc.tiles_y, sc.dist, strips, sc.dist_blocks);
-        tables = 1 + min_holes;                                 // k_fill_holes: the frame is done if it has >= tables - 1 holes
+        hipLaunchKernelGGL(k_fill_tables, dim3(blocks, n_jobs), dim3(256), 0, s, jobs, min_holes, W, H, dirs, rect, n_tiles, sc0.tiles_x, sc0.tiles_y, use_strips);
+        tables = 1 + min_holes;                                 // k_fill_holes: a frame is done if it has >= tables - 1 holes
     }
-    hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks), dim3(KBE_FILL_BLOCK), 0, s, sc.holes, hole_count, sc.depth, sc.mask, W, H, dirs, rect,
-                       frame_u8, render_f32, sc.zkeys, sc.tile_count, n_tiles, sc.bbox, fill_mode,
-                       sc.coarse, sc.tiles_x, sc.tiles_y, reset_scatter_scratch, next_hole_count, tables);
+    hipLaunchKernelGGL(k_fill_holes, dim3(fill_blocks, n_jobs), dim3(KBE_FILL_BLOCK), 0, s, jobs, W, H, dirs, rect, n_tiles, fill_mode, sc0.tiles_x, sc0.tiles_y, tables);
 }
 
 }  // namespace kbe

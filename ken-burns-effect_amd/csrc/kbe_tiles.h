@@ -109,10 +109,25 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 #define KBE_FILL_BY_COUNT_MIN_LANES 2       // frames in flight from which the video loop lets the fill pick its schedule by the hole count
 #endif
 
-// kbe_holes.hip: the hole fill of one frame -- with KBE_STAGE_FILL_DIST the tables (k_hole_dist) and the table-driven fill
-// (k_fill_tables) in front of k_fill_holes; each returns at once when the frame has fewer holes than its schedule asks for
-void launch_fill(hipStream_t s, const Scratch& sc, int W, int H, const int* hole_count, int stages, const FillDirs& dirs, const FillRect& rect,
-                 uint8_t* frame_u8, float* render_f32, int n_tiles, int reset_scatter_scratch, int* next_hole_count);
+// kbe_holes.hip: the hole fill of one frame, or of two frames of the same size in the same launches -- with
+// KBE_STAGE_FILL_DIST the tables (k_hole_dist) and the table-driven fill (k_fill_tables) in front of k_fill_holes; each
+// returns at once when a frame has fewer holes than its schedule asks for
+constexpr int KBE_FILL_JOBS = 2;
+struct FillTarget {                 // a frame to be filled, on the host
+    Scratch sc;
+    const int* hole_count;
+    uint8_t* frame_u8;
+    float* render_f32;
+    int reset_scatter_scratch;      // stand-alone frames of the bucket route: the fill launch empties z-buffer A and the bucket counters
+    int* next_hole_count;           // fused route: the hole counter the NEXT frame counts in, zeroed here
+};
+struct FillJob {                    // ... and as the kernels see it
+    const int* holes; const int* hole_count; const float* depth; const uint32_t* mask; uint8_t* frame; float* render;
+    uint32_t* zkeys; int* tile_count; const int4* bbox; const uint32_t* coarse; uint8_t* dist; float2* strips; uint8_t* dist_blocks;
+    int reset_scatter_scratch; int* next_hole_count;
+};
+struct FillJobs { FillJob j[KBE_FILL_JOBS]; };
+void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, int H, int stages, const FillDirs& dirs, const FillRect& rect, int n_tiles);
 // kbe_fused.hip: the one-launch scatter of a frame from the packed cloud (k_frame)
 void launch_frame_fused(hipStream_t s, unsigned n_tiles, const void* packed, int N, double cloud_focal, const Camera& cam, const Scratch& sc, int* hole_count,
                         uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32, float* zee_pre_f32);
