@@ -268,14 +268,20 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  *   batch > 0: round 1's scheme, kept for comparison and for host memory the device cannot address: frames are
  *       staged on the device in two halves of `batch` frames and leave with one hipMemcpyAsync per half on
  *       copy_stream (NULL: on `stream`), cross-stream events per half.
- *   scratch: lanes * kbe_video_scratch_stride(W, H) bytes, each lane's part initialised with
- *            kbe_frame_scratch_init;
+ *   scratch: lanes * kbe_video_scratch_stride(W, H) bytes (n times that with KBE_VIDEO_FILL_GROUP(n)), each lane's part
+ *            initialised with kbe_frame_scratch_init;
  *   stage:   DEVICE buffer, 256-byte aligned, of kbe_video_stage_bytes(W, H, lanes, batch) bytes.
  * The call creates and destroys its HIP events. */
 #define KBE_MAX_LANES 8
 KBE_API size_t kbe_video_scratch_stride(int W, int H);
 KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 #define KBE_VIDEO_FILL_DIST 1        /* kbe_render_video flags: KBE_STAGE_FILL_DIST for every frame */
+/* with KBE_VIDEO_FILL_DIST, batch <= 0 and two or more lanes: a lane renders n = 2..4 frames, each into a scratch set of its
+ * own, and fills them in the same launches (the table-driven fill is bound by its chain of dependent look-ups, not by the
+ * chip: n frames per launch take much less than n times as long).  `scratch` must then hold n * lanes sets
+ * (n * lanes * kbe_video_scratch_stride bytes, every set initialised with kbe_frame_scratch_init); same frames. */
+#define KBE_VIDEO_FILL_GROUP(n) (((n) - 1) << 1)
+#define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,

@@ -28,6 +28,7 @@ ABI_VERSION = 4
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
+DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
 
@@ -351,9 +352,23 @@ class HipKernels:
         mode = os.environ.get('KBE_FILL_DIST', 'auto')
         zooms_out = n > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
+        scratch = state['scratch']
+        group = max(1, min(4, int(os.environ.get('KBE_FILL_GROUP', DEFAULT_FILL_GROUP))))
+        if flags and lanes >= 2 and batch <= 0 and group > 1:
+            # KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets and fills them in the same launches
+            # (dolly bench, us per frame: see DESIGN.md); n * lanes sets, allocated on first use
+            flags |= (group - 1) << 1
+            stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H)))
+            sets = group * state['lanes']
+            if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
+                state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=dev)
+                for l in range(sets):
+                    self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch_groups'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
+                                'kbe_frame_scratch_init')
+            scratch = state['scratch_groups']
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
-                                              _ptr(state['scratch'], torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
+                                              _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
                                               _ptr(state['packed'], torch.uint8) if state.get('fused') else None, _d(state['cloud_focal']),
                                               _i(flags), _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')

@@ -733,7 +733,7 @@ static inline size_t stage_fin_per_lane(int batch) { return batch < -2 ? (size_t
 static inline size_t stage_ctl_offset(int W, int H, int lanes, int batch)
 {
     const size_t fb = (size_t) W * H * 3;
-    return (((size_t) lanes * (1 + stage_fin_per_lane(batch)) + 2 * (size_t) (batch > 0 ? batch : 0)) * fb + 255) & ~(size_t) 255;
+    return (((size_t) lanes * (KBE_FILL_JOBS + stage_fin_per_lane(batch)) + 2 * (size_t) (batch > 0 ? batch : 0)) * fb + 255) & ~(size_t) 255;
 }
 
 size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch)
@@ -892,16 +892,23 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     const size_t fb = (size_t) W * H * 3;
     const size_t sb = (scratch_bytes(W, H) + 255) & ~(size_t) 255;      // == kbe_frame_scratch_bytes rounded: lane stride
     const bool crop = crop_w > 0;
+    // KBE_VIDEO_FILL_PAIRS (with _FILL_DIST; `scratch` then holds 2 * lanes sets): a lane renders TWO frames, each into a
+    // scratch set of its own, and fills them in the same launches.  The table-driven fill is bound by its own chain of
+    // dependent look-ups, not by the chip (272 us alone, 352 us with four of them overlapping), and more than four
+    // streams do not overlap any better (the hardware queues): two frames per launch are the way to have eight in flight.
+    const int group = ((flags & KBE_VIDEO_FILL_DIST) && lanes >= KBE_FILL_BY_COUNT_MIN_LANES && batch <= 0) ? ((flags >> 1) & 3) + 1 : 1;    // KBE_VIDEO_FILL_GROUP(n)
+    KBE_REQUIRE(group <= KBE_FILL_JOBS, "kbe_render_video: KBE_VIDEO_FILL_GROUP beyond the library's KBE_FILL_JOBS");
+    const bool pairs = group > 1;
     // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
     // frame: the fixed cost of a kernel boundary on this chip (launch ramp, tail, and the L2 write-back between
     // dependent kernels) is then paid while another frame's kernels run.
-    // stage = [lanes raw frames][2 * lanes finished frames][ring half 0: batch frames][ring half 1: batch frames].
+    // stage = [KBE_FILL_JOBS * lanes raw frames][lanes * fin finished frames][ring half 0: batch frames][ring half 1: batch frames].
     hipStream_t ls[KBE_MAX_LANES], ds[1];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? cs : (hipStream_t) lane_streams[l];
     ds[0] = copy_stream ? (hipStream_t) copy_stream : cs;        // only the staged ring (batch > 0) uses it
     const int fin = (int) stage_fin_per_lane(batch);                    // finished-frame buffers per lane
     const int slots = fin * lanes;
-    uint8_t* const finished = stage + (size_t) lanes * fb;
+    uint8_t* const finished = stage + (size_t) KBE_FILL_JOBS * lanes * fb;
     uint8_t* ring[2] = { finished + (size_t) slots * fb, finished + ((size_t) slots + (size_t) (batch > 0 ? batch : 0)) * fb };
     // where do the frames go?  (a pointer the runtime does not know is taken for device memory, as before)
     uint8_t* host_dev = nullptr;                // host_out as the device sees it, when it is pinned host memory
@@ -948,7 +955,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     }
     if (packed) {
         // every lane starts the call on hole counter 0: both of its counters are zeroed here, on `stream`, before the lanes start
-        for (int l = 0; l < lanes; l++) {
+        for (int l = 0; l < group * lanes; l++) {
             const hipError_t e = hipMemsetAsync(carve((char*) scratch + (size_t) l * sb, W, H).hole_count, 0, 2 * sizeof(int), cs);
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
         }
@@ -984,6 +991,44 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         if (rc == KBE_OK && crop) rc = kbe_crop_resize_u8(raw, W, H, crop_w, crop_h, out, (kbe_stream_t) ls[l]);
         return rc;
     };
+    // up to `group` frames of lane l: each scattered into a scratch set of its own, filled together, cropped
+    static const FillDirs fill_dirs = make_fill_dirs();
+    int set_frames[KBE_MAX_LANES][KBE_FILL_JOBS] = {}, set_total[KBE_MAX_LANES][KBE_FILL_JOBS] = {};
+    bool counting = false;
+    auto render_group = [&](int l, int count, const int* idx, uint8_t* const* outs) {
+        if (counting) { for (int j = 0; j < count; j++) set_total[l][j]++; return (int) KBE_OK; }
+        FillTarget targets[KBE_FILL_JOBS];
+        uint8_t* raws[KBE_FILL_JOBS];
+        int rc = KBE_OK;
+        for (int j = 0; j < count && rc == KBE_OK; j++) {
+            const int i = idx[j];
+            char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
+            uint8_t* const raw = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
+            uint8_t* const target = crop ? raw : outs[j];
+            const Scratch sc = carve(scr, W, H);
+            const int k = set_frames[l][j]++;
+            if (packed) {
+                rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scr, target, nullptr, nullptr,
+                                            nullptr, nullptr, KBE_STAGE_TILES, crop ? rect : nullptr, k & 1, (kbe_stream_t) ls[l]);
+                targets[j] = FillTarget{ sc, sc.hole_count + (k & 1), target, nullptr, 0, sc.hole_count + ((k & 1) ^ 1) };
+            } else {
+                const bool last_of_set = k + 1 == set_total[l][j];
+                const int zflags = (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_set ? 0 : KBE_STAGE_ZBUF_A);
+                rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scr, target, nullptr, nullptr,
+                                             nullptr, nullptr, KBE_STAGE_PROJECT | KBE_STAGE_TILES | zflags, crop ? rect : nullptr, raster_w, raster_n,
+                                             (kbe_stream_t) ls[l]);
+                targets[j] = FillTarget{ sc, sc.hole_count, target, nullptr, zflags ? 0 : 1, nullptr };
+            }
+            raws[j] = raw;
+        }
+        if (rc != KBE_OK || count == 0) return rc;
+        FillRect fr = { 0, 0, W - 1, H - 1 };
+        if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
+        launch_fill(ls[l], count, targets, W, H, KBE_STAGE_FILL | KBE_STAGE_FILL_BY_COUNT | KBE_STAGE_FILL_DIST, fill_dirs, fr, targets[0].sc.tiles_x * targets[0].sc.tiles_y);
+        if ((rc = launched("kbe_render_video/fill")) != KBE_OK) return rc;
+        for (int j = 0; j < count && rc == KBE_OK && crop; j++) rc = kbe_crop_resize_u8(raws[j], W, H, crop_w, crop_h, outs[j], (kbe_stream_t) ls[l]);
+        return rc;
+    };
     // whoever synchronises `stream` afterwards also sees every frame delivered and every other stream idle
     auto join = [&]() {
         for (int l = 1; l < lanes && ok; l++) { hipEvent_t e = make(); if (e) { (void) hipEventRecord(e, ls[l]); (void) hipStreamWaitEvent(cs, e, 0); } }
@@ -992,6 +1037,23 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     int rc = KBE_OK;
     if (!ringed && !per_frame) {
         // host_out is device memory: the last kernel of every frame stores straight into it (the frames stay in HBM)
+        if (pairs) {
+            // lane l takes frames l, l + lanes, l + 2 lanes, ... `group` at a time (a first pass counts the frames of every
+            // scratch set: the bucket route must know a set's last frame)
+            for (int pass = 0; pass < 2 && rc == KBE_OK; pass++) {
+                counting = pass == 0;
+                for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes)
+                    for (int l = 0; l < lanes && rc == KBE_OK; l++) {
+                        int idx[KBE_FILL_JOBS], count = 0;
+                        uint8_t* outs[KBE_FILL_JOBS];
+                        for (int m = 0; m < group; m++) {
+                            const int i = base + m * lanes + l;
+                            if (i < n_frames) { idx[count] = i; outs[count++] = host_out + (size_t) i * fb; }
+                        }
+                        if (count) rc = render_group(l, count, idx, outs);
+                    }
+            }
+        } else
         for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = render(i, i % lanes, host_out + (size_t) i * fb);
     } else if (!ringed) {
         // Hand-off to pinned host memory in the lane's own stream (no event), the lanes taking turns:
@@ -1012,10 +1074,24 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
         } else {
             const int G = -batch;
+            if (pairs) {                                                // the frames of every scratch set, counted first
+                counting = true;
+                for (int i0 = 0, g = 0; i0 < n_frames; i0 += G, g++) {
+                    const int l = g % lanes, nb = n_frames - i0 < G ? n_frames - i0 : G;
+                    for (int k = 0; k < nb; k += group) (void) render_group(l, nb - k < group ? nb - k : group, nullptr, nullptr);
+                }
+                counting = false;
+            }
             for (int i0 = 0, g = 0; i0 < n_frames && rc == KBE_OK; i0 += G, g++) {
                 const int l = g % lanes, nb = n_frames - i0 < G ? n_frames - i0 : G;
                 uint8_t* base = finished + (size_t) l * fin * fb;
-                for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
+                if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
+                    int idx[KBE_FILL_JOBS], count = 0;
+                    uint8_t* outs[KBE_FILL_JOBS];
+                    for (int m = 0; m < group && k + m < nb; m++) { idx[count] = i0 + k + m; outs[count++] = base + (size_t) (k + m) * fb; }
+                    rc = render_group(l, count, idx, outs);
+                }
+                else for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
                 if (rc != KBE_OK) break;
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, (uint32_t) g, 0);
                 const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);

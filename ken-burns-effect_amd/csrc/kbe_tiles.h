@@ -112,7 +112,7 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 // kbe_holes.hip: the hole fill of one frame, or of two frames of the same size in the same launches -- with
 // KBE_STAGE_FILL_DIST the tables (k_hole_dist) and the table-driven fill (k_fill_tables) in front of k_fill_holes; each
 // returns at once when a frame has fewer holes than its schedule asks for
-constexpr int KBE_FILL_JOBS = 2;
+constexpr int KBE_FILL_JOBS = 4;
 struct FillTarget {                 // a frame to be filled, on the host
     Scratch sc;
     const int* hole_count;

@@ -366,6 +366,45 @@ def test_bucket_route_video_alternates_its_z_buffers(K, monkeypatch, lanes, n_fr
     assert torch.equal(zp.view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize('fused', ['0', '1'])
+@pytest.mark.parametrize('group,n_frames,lanes', [('2', 7, '4'), ('3', 13, '2'), ('4', 16, '4'), ('4', 5, '3'), ('2', 1, '2')])
+def test_video_that_fills_several_frames_per_launch_equals_frames_on_their_own(K, monkeypatch, fused, group, n_frames, lanes):
+    """KBE_VIDEO_FILL_GROUP(n): a lane scatters n frames into n scratch sets and fills them in the same launches (dolly
+    zooms with the table-driven fill).  Every frame must equal the frame rendered on its own (within the accumulation order) -- whole groups, ragged last
+    groups, a single frame; both scatter routes (the bucket route's sets alternate their z-buffers separately, the fused
+    route's their hole counters); frames left in HBM and delivered to host memory, cropped and not; twice in a row."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', fused)
+    monkeypatch.setenv('KBE_LANES', lanes)
+    monkeypatch.setenv('KBE_FILL_DIST', '1')
+    monkeypatch.setenv('KBE_FILL_GROUP', group)
+    size = (384, 416)
+    settings, oc = _scene(size, 11, 'smooth', True)
+    settings = dict(settings, dblSteps=[i / max(n_frames - 1, 1) for i in range(n_frames)])
+    cams = common.frame_cameras(settings, oc)
+    crop = common.crop_size(settings)
+    state = common._prepared_cloud(K, oc)
+    assert state['fused'] == (fused == '1')
+    def same(a, b, what=''):
+        # the colour sums depend on the order records reach a bucket (last ulp): a uint8 value on an integer boundary may flip
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, '%s: max %d, %.2e of the values differ' % (what, d.max(), (d > 0).mean())
+
+    alone = np.stack([K.render_frame(state, sh, f, oc['dblBaseline']).cpu().numpy() for f, sh in cams])
+    assert n_frames < 5 or int((alone[-1] == 0).all(axis=2).sum()) > 49152, 'late frames have enough holes for the table-driven schedule'
+    for _ in range(2):
+        video = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+        same(video, alone, 'frames left in HBM')
+        same(common.render_frames(cams, oc, None), alone, 'delivered to host memory')
+    rect = common.crop_window(size[1], size[0], crop[0], crop[1])
+    cropped = np.stack([K.crop_resize_u8(K.render_frame(state, sh, f, oc['dblBaseline'], fill_rect=rect), crop[0], crop[1]).cpu().numpy() for f, sh in cams])
+    same(common.render_frames(cams, oc, crop), cropped, 'cropped')
+    monkeypatch.setenv('KBE_FILL_GROUP', '1')
+    same(common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy(), alone, 'one frame per launch')
+    again = K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy()       # the scratch of lane 0 is as a video leaves it
+    same(again, alone[0], 'a frame on its own after the videos')
+
+
 @pytest.mark.parametrize('size', [(50, 37), (33, 64)])
 def test_frame_hand_off_with_unaligned_frame_sizes(K, size):
     """W*H*3 not a multiple of 16: the frames of a video start at unaligned host addresses (k_deliver's byte path)."""
