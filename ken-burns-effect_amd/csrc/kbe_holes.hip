@@ -484,8 +484,11 @@ __device__ __forceinline__ void axis_catch_up(Axis& ax, int& r, float u, bool su
     if (r > 0) axis_jump(ax, r);
 }
 
+#ifndef KBE_FILL_TABLES_BLOCKS
+#define KBE_FILL_TABLES_BLOCKS 768      // workgroups of k_fill_tables per frame (3 per CU; with four frames per launch and four lanes: 96.5 us per dolly frame, 2048: 99.5)
+#endif
 #ifndef KBE_FILL_BURST
-#define KBE_FILL_BURST 8                // steps a creeping ray takes together ...
+#define KBE_FILL_BURST 4                // steps a creeping ray takes together (8: 102 us per dolly frame, 4: 99, with four frames per launch) ...
 #endif
 #ifndef KBE_FILL_BURST_LANES
 #define KBE_FILL_BURST_LANES 16         // ... in a wave whose queue has run dry and of which no more lanes than this still walk
@@ -1067,7 +1070,7 @@ void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, in
         const int extra = 16 * ((strip_bins(W, H) + 255) / 256) + ((cw + DT_W - 1) / DT_W) * ((ch + DT_H - 1) / DT_H);
         hipLaunchKernelGGL(k_hole_dist, dim3(gx, gy + (extra + gx - 1) / gx, n_jobs), dim3(256), 0, s, jobs, W, H, min_holes, sc0.tiles_x, sc0.tiles_y, dirs, gy, use_strips);
         const size_t hw = (size_t) W * H;
-        const unsigned blocks = (unsigned) ((hw + 255) / 256 < KBE_FILL_MAX_BLOCKS ? (hw + 255) / 256 : KBE_FILL_MAX_BLOCKS);
+        const unsigned blocks = (unsigned) ((hw + 255) / 256 < KBE_FILL_TABLES_BLOCKS ? (hw + 255) / 256 : KBE_FILL_TABLES_BLOCKS);
         hipLaunchKernelGGL(k_fill_tables, dim3(blocks, n_jobs), dim3(256), 0, s, jobs, min_holes, W, H, dirs, rect, n_tiles, sc0.tiles_x, sc0.tiles_y, use_strips);
         tables = 1 + min_holes;                                 // k_fill_holes: a frame is done if it has >= tables - 1 holes
     }
