@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 4
+#define KBE_ABI_VERSION 5
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -207,6 +207,16 @@ KBE_API int kbe_render_frame_stages(const float* points, const float* image, con
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
                                     float* zee_pre_f32, int stages, const int* fill_rect, int raster_w, int raster_n,
                                     kbe_stream_t stream);
+/* The same launches for a GROUP of 1..4 frames of the same cloud and size: every launch (projection, tiles, fill) takes all
+ * the frames of the group (one grid dimension is the frame).  Frames are independent, and a launch on its own is bound by
+ * its ramp and its latencies rather than by the chip, so several frames per launch cost much less than as many launches
+ * (what kbe_render_video does with KBE_VIDEO_FILL_GROUP).  focals [n], shifts [3 n]; scratch [n]: one initialised scratch
+ * set PER FRAME (kbe_frame_scratch_bytes each); frames_u8 [n]; zbuf_flags [n] or NULL: KBE_STAGE_ZBUF_A / _B / 0 per frame
+ * (each scratch set follows the A, B, A ... rule of kbe_render_frame_stages on its own); `stages` as there. */
+KBE_API int kbe_render_frame_group(const float* points, const float* image, const float* depth, int N, int W, int H,
+                                   double baseline, int n_frames, const double* focals, const float* shifts,
+                                   void* const* scratch, uint8_t* const* frames_u8, const int* zbuf_flags, int stages,
+                                   const int* fill_rect, int raster_w, int raster_n, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * The same frame from the PACKED cloud, with the whole of render_pointcloud in ONE launch (the default route of the

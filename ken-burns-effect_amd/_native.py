@@ -20,11 +20,11 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
@@ -310,6 +310,33 @@ class HipKernels:
                     'kbe_render_frame')
         return frame
 
+    def group_scratch(self, state, sets):
+        """`sets` initialised scratch sets for launches that take several frames (kbe_render_frame_group, KBE_VIDEO_FILL_GROUP),
+        allocated on first use: (tensor, stride in bytes)."""
+        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H'])))
+        if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
+            state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=state['points'].device)
+            for l in range(sets):
+                self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch_groups'].data_ptr() + l * stride), _i(state['W']), _i(state['H']),
+                                                            _stream()), 'kbe_frame_scratch_init')
+        return state['scratch_groups'], stride
+
+    def render_frame_group(self, state, cameras, baseline, out, stages=7, zbuf_flags=None, fill_rect=None):
+        """kbe_render_frame_group: the launches of 1..4 frames [(focal, shift3)] of the bucket route, every launch taking all of
+        them; out: uint8 [n,H,W,3] on the device.  Each frame uses a scratch set of its own (state['scratch_groups'])."""
+        n = len(cameras)
+        scratch, stride = self.group_scratch(state, max(n, 4))
+        focals = (ctypes.c_double * n)(*[float(c[0]) for c in cameras])
+        shifts = (ctypes.c_float * (3 * n))(*[float(v) for c in cameras for v in c[1]])
+        sets = (ctypes.c_void_p * n)(*[scratch.data_ptr() + k * stride for k in range(n)])
+        frames = (ctypes.c_void_p * n)(*[out[k].data_ptr() for k in range(n)])
+        zf = None if zbuf_flags is None else (ctypes.c_int * n)(*[int(v) for v in zbuf_flags])
+        rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
+        self._check(self.lib.kbe_render_frame_group(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']), _i(state['W']),
+                                                    _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, zf, _i(int(stages)), rect,
+                                                    _i(state['raster_w']), _i(state['raster_n']), _stream()), 'kbe_render_frame_group')
+        return out
+
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
@@ -354,18 +381,11 @@ class HipKernels:
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
         scratch = state['scratch']
         group = max(1, min(4, int(os.environ.get('KBE_FILL_GROUP', DEFAULT_FILL_GROUP))))
-        if flags and lanes >= 2 and batch <= 0 and group > 1:
+        if batch <= 0 and group > 1 and (flags or os.environ.get('KBE_FILL_GROUP')):
             # KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets and fills them in the same launches
             # (dolly bench, us per frame: see DESIGN.md); n * lanes sets, allocated on first use
             flags |= (group - 1) << 1
-            stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H)))
-            sets = group * state['lanes']
-            if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
-                state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=dev)
-                for l in range(sets):
-                    self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch_groups'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
-                                'kbe_frame_scratch_init')
-            scratch = state['scratch_groups']
+            scratch, _ = self.group_scratch(state, group * state['lanes'])
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),

@@ -115,7 +115,7 @@ constexpr int PATCH_ROWS = 2;           // a raster unit is a 32 x 2 patch
 #ifndef KBE_PROJECT_BLOCK
 #define KBE_PROJECT_BLOCK 64        // one wave per workgroup: fits the gaps other lanes' kernels leave (29.7 vs 30.6 us per frame at 256)
 #endif
-__global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectArgs a)
+__device__ __forceinline__ void project_body(const ProjectArgs& a)
 {
     const int lane = threadIdx.x & 63;
     // wave-uniform values are made scalar explicitly (the unit -> point index arithmetic below then runs on the
@@ -292,7 +292,7 @@ __device__ __forceinline__ float4 fetch_rgbd(const TileArgs& a, int id)
     return make_float4(*(const float*) (r + off), *(const float*) (g + off), *(const float*) (b + off), *(const float*) (d + off));
 }
 
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileArgs a)
+__device__ __forceinline__ void tiles_body(const TileArgs& a)
 {
     __shared__ TileLds L;
 
@@ -469,6 +469,25 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             if (x0 + lx < W && y0 + ly < H) a.zkeys_clear[__umul24((uint32_t) (y0 + ly), (uint32_t) W) + (uint32_t) (x0 + lx)] = KBE_ZKEY_EMPTY;
         }
     }
+}
+
+// Both launches of the bucket route take up to KBE_SCATTER_JOBS frames (blockIdx.y = the frame; same cloud, same frame
+// size, each frame with its own camera and scratch set).  Frames are independent, and a launch on its own is bound by
+// its ramp and its latencies, not by the chip: k_project issues for 7 us of its 14, k_tiles for 8 of its 19.5.  Several
+// frames per launch fill those gaps inside ONE stream (the video loop's lanes do the same across streams, but HIP maps
+// a process's streams onto four hardware queues).
+constexpr int KBE_SCATTER_JOBS = KBE_FILL_JOBS;
+struct ProjectJobs { ProjectArgs a[KBE_SCATTER_JOBS]; };
+struct TileJobs { TileArgs a[KBE_SCATTER_JOBS]; };
+
+__global__ void __launch_bounds__(KBE_PROJECT_BLOCK) k_project(ProjectJobs jobs)
+{
+    project_body(jobs.a[blockIdx.y]);
+}
+
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_tiles(TileJobs jobs)
+{
+    tiles_body(jobs.a[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -751,6 +770,78 @@ int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
     return launched("kbe_frame_scratch_init");
 }
 
+}  // extern "C"
+
+namespace {
+// one frame of a group: its camera, its scratch set, where it goes, which of the set's z-buffers it uses (KBE_STAGE_ZBUF_*)
+struct FrameJob {
+    double focal;
+    const float* shift3;
+    void* scratch;
+    uint8_t* frame_u8;
+    float* render_f32; float* existing_f32; float* zee_f32; float* zee_pre_f32;
+    int zflags;
+};
+
+// the launches of `n` frames of the same cloud and size, each launch taking all n frames (bucket route)
+int render_jobs(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline, int n, const FrameJob* jobs,
+                int stages, const int* fill_rect, int raster_w, int raster_n, hipStream_t s)
+{
+    static const FillDirs dirs = make_fill_dirs();
+    ProjectJobs pj;
+    TileJobs tj;
+    FillTarget targets[KBE_SCATTER_JOBS];
+    int n_tiles = 0, rc = KBE_OK;
+    for (int k = 0; k < KBE_SCATTER_JOBS; k++) {
+        const FrameJob& job = jobs[k < n ? k : 0];
+        const Scratch sc = carve(job.scratch, W, H);
+        const Camera cam = make_camera(W, H, job.focal, baseline, job.shift3);
+        n_tiles = sc.tiles_x * sc.tiles_y;
+        // which z-buffer this frame splats into, and whether its tile launch clears the other one (include/kbe.h)
+        const bool alternate = (job.zflags & (KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B)) != 0;
+        uint32_t* const zk_use = (job.zflags & KBE_STAGE_ZBUF_B) ? sc.zkeys_b : sc.zkeys;
+        uint32_t* const zk_other = (job.zflags & KBE_STAGE_ZBUF_B) ? sc.zkeys : sc.zkeys_b;
+        ProjectArgs& p = pj.a[k];
+        p.points = points; p.N = N; p.cam = cam; p.zkeys = zk_use; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
+        p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
+        p.raster_w = 0; p.raster_n = 0;
+        p.dense = (size_t) N > 2 * (size_t) W * H;
+        p.buckets_32bit = (size_t) n_tiles * BUCKET_STRIDE * sizeof(float4) <= ((size_t) 1 << 32);
+        if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
+        TileArgs& a = tj.a[k];
+        a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
+        if (N == 0) a.points = a.image = a.depth_in = (const float*) sc.zkeys;     // never dereferenced for a record, but never NULL
+        a.zkeys = zk_use; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
+        a.zkeys_clear = alternate ? zk_other : nullptr; a.tile_count_clear = sc.tile_count;
+        a.frame = job.frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox; a.coarse = sc.coarse;
+        a.render = job.render_f32; a.existing = job.existing_f32; a.zee = job.zee_f32; a.zee_pre = job.zee_pre_f32;
+        targets[k] = FillTarget{ sc, sc.hole_count, job.frame_u8, job.render_f32, alternate ? 0 : 1, nullptr };
+    }
+    if (stages & KBE_STAGE_PROJECT) {
+#ifndef KBE_PROJECT_MAX_BLOCKS
+#define KBE_PROJECT_MAX_BLOCKS 1000000
+#endif
+        unsigned blocks = N > 0 ? blocks_for((size_t) N, KBE_PROJECT_BLOCK) + 2 : 1;
+        if (blocks > KBE_PROJECT_MAX_BLOCKS) blocks = KBE_PROJECT_MAX_BLOCKS;
+        hipLaunchKernelGGL(k_project, dim3(blocks, n), dim3(KBE_PROJECT_BLOCK), 0, s, pj);
+        if ((rc = launched("kbe_render_frame/project"))) return rc;
+    }
+    if (stages & KBE_STAGE_TILES) {
+        hipLaunchKernelGGL(k_tiles, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, tj);
+        if ((rc = launched("kbe_render_frame/tiles"))) return rc;
+    }
+    if (stages & KBE_STAGE_FILL) {
+        FillRect rect = { 0, 0, W - 1, H - 1 };
+        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        launch_fill(s, n, targets, W, H, stages, dirs, rect, n_tiles);
+        rc = launched("kbe_render_frame/fill");
+    }
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
 int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
                             double baseline, const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
                             float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect,
@@ -759,52 +850,26 @@ int kbe_render_frame_stages(const float* points, const float* image, const float
     KBE_REQUIRE(scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
                 W < (1 << 24) && H < (1 << 24) && ((uintptr_t) scratch & 15) == 0, "kbe_render_frame: bad arguments");
     KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame: cloud pointers are NULL");
-    static const FillDirs dirs = make_fill_dirs();
-    const hipStream_t s = (hipStream_t) stream;
-    const Scratch sc = carve(scratch, W, H);
-    const Camera cam = make_camera(W, H, focal, baseline, shift3);
-    const int n_tiles = sc.tiles_x * sc.tiles_y;
-    int rc = KBE_OK;
+    const FrameJob job = { focal, shift3, scratch, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32, stages & (KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B) };
+    return render_jobs(points, image, depth, N, W, H, baseline, 1, &job, stages, fill_rect, raster_w, raster_n, (hipStream_t) stream);
+}
 
-    // which z-buffer this frame splats into, and whether its tile launch clears the other one (include/kbe.h)
-    const bool alternate = (stages & (KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B)) != 0;
-    uint32_t* const zk_use = (stages & KBE_STAGE_ZBUF_B) ? sc.zkeys_b : sc.zkeys;
-    uint32_t* const zk_other = (stages & KBE_STAGE_ZBUF_B) ? sc.zkeys : sc.zkeys_b;
-    if (stages & KBE_STAGE_PROJECT) {
-        ProjectArgs p;
-        p.points = points; p.N = N; p.cam = cam; p.zkeys = zk_use; p.tile_count = sc.tile_count; p.buckets = sc.buckets;
-        p.tiles_x = sc.tiles_x; p.tiles_y = sc.tiles_y; p.hole_count = sc.hole_count;
-        p.raster_w = 0; p.raster_n = 0;
-        p.dense = (size_t) N > 2 * (size_t) W * H;
-        p.buckets_32bit = (size_t) n_tiles * BUCKET_STRIDE * sizeof(float4) <= ((size_t) 1 << 32);
-        if (raster_w > 0 && raster_n >= raster_w && raster_n <= N && raster_n % raster_w == 0) { p.raster_w = raster_w; p.raster_n = raster_n; }
-#ifndef KBE_PROJECT_MAX_BLOCKS
-#define KBE_PROJECT_MAX_BLOCKS 1000000
-#endif
-        unsigned blocks = N > 0 ? blocks_for((size_t) N, KBE_PROJECT_BLOCK) + 2 : 1;
-        if (blocks > KBE_PROJECT_MAX_BLOCKS) blocks = KBE_PROJECT_MAX_BLOCKS;
-        hipLaunchKernelGGL(k_project, dim3(blocks), dim3(KBE_PROJECT_BLOCK), 0, s, p);
-        if ((rc = launched("kbe_render_frame/project"))) return rc;
+int kbe_render_frame_group(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline, int n_frames,
+                           const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* zbuf_flags,
+                           int stages, const int* fill_rect, int raster_w, int raster_n, kbe_stream_t stream)
+{
+    KBE_REQUIRE(n_frames >= 1 && n_frames <= KBE_SCATTER_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+                (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24), "kbe_render_frame_group: bad arguments");
+    KBE_REQUIRE(N == 0 || (points && image && depth), "kbe_render_frame_group: cloud pointers are NULL");
+    FrameJob jobs[KBE_SCATTER_JOBS];
+    for (int k = 0; k < n_frames; k++) {
+        KBE_REQUIRE(scratch[k] && frames_u8[k] && ((uintptr_t) scratch[k] & 15) == 0, "kbe_render_frame_group: bad scratch / frame pointer");
+        for (int j = 0; j < k; j++) KBE_REQUIRE(scratch[j] != scratch[k], "kbe_render_frame_group: the frames of a group need scratch sets of their own");
+        jobs[k] = FrameJob{ focals[k], shifts + 3 * (size_t) k, scratch[k], frames_u8[k], nullptr, nullptr, nullptr, nullptr,
+                            zbuf_flags ? zbuf_flags[k] & (KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B) : 0 };
     }
-    if (stages & KBE_STAGE_TILES) {
-        TileArgs a;
-        a.points = points; a.image = image; a.depth_in = depth; a.N = N; a.cam = cam;
-        if (N == 0) a.points = a.image = a.depth_in = (const float*) sc.zkeys;     // never dereferenced for a record, but never NULL
-        a.zkeys = zk_use; a.tile_count = sc.tile_count; a.buckets = sc.buckets; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
-        a.zkeys_clear = alternate ? zk_other : nullptr; a.tile_count_clear = sc.tile_count;
-        a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count; a.bbox = sc.bbox; a.coarse = sc.coarse;
-        a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32;
-        hipLaunchKernelGGL(k_tiles, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
-        if ((rc = launched("kbe_render_frame/tiles"))) return rc;
-    }
-    if (stages & KBE_STAGE_FILL) {
-        FillRect rect = { 0, 0, W - 1, H - 1 };
-        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        const FillTarget target = { sc, sc.hole_count, frame_u8, render_f32, alternate ? 0 : 1, nullptr };
-        launch_fill(s, 1, &target, W, H, stages, dirs, rect, n_tiles);
-        rc = launched("kbe_render_frame/fill");
-    }
-    return rc;
+    return render_jobs(points, image, depth, N, W, H, baseline, n_frames, jobs, stages & ~(KBE_STAGE_ZBUF_A | KBE_STAGE_ZBUF_B), fill_rect, raster_w, raster_n,
+                       (hipStream_t) stream);
 }
 
 int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
@@ -896,7 +961,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     // scratch set of its own, and fills them in the same launches.  The table-driven fill is bound by its own chain of
     // dependent look-ups, not by the chip (272 us alone, 352 us with four of them overlapping), and more than four
     // streams do not overlap any better (the hardware queues): two frames per launch are the way to have eight in flight.
-    const int group = ((flags & KBE_VIDEO_FILL_DIST) && lanes >= KBE_FILL_BY_COUNT_MIN_LANES && batch <= 0) ? ((flags >> 1) & 3) + 1 : 1;    // KBE_VIDEO_FILL_GROUP(n)
+    const int group = batch <= 0 ? ((flags >> 1) & 3) + 1 : 1;         // KBE_VIDEO_FILL_GROUP(n)
     KBE_REQUIRE(group <= KBE_FILL_JOBS, "kbe_render_video: KBE_VIDEO_FILL_GROUP beyond the library's KBE_FILL_JOBS");
     const bool pairs = group > 1;
     // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
@@ -997,35 +1062,41 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     bool counting = false;
     auto render_group = [&](int l, int count, const int* idx, uint8_t* const* outs) {
         if (counting) { for (int j = 0; j < count; j++) set_total[l][j]++; return (int) KBE_OK; }
-        FillTarget targets[KBE_FILL_JOBS];
+        const int fill_flags = (lanes * group >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0) | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0);
         uint8_t* raws[KBE_FILL_JOBS];
         int rc = KBE_OK;
-        for (int j = 0; j < count && rc == KBE_OK; j++) {
-            const int i = idx[j];
-            char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
-            uint8_t* const raw = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
-            uint8_t* const target = crop ? raw : outs[j];
-            const Scratch sc = carve(scr, W, H);
-            const int k = set_frames[l][j]++;
-            if (packed) {
+        if (!packed) {
+            // bucket route: every launch (projection, tiles, fill) takes the whole group
+            FrameJob jobs[KBE_FILL_JOBS];
+            for (int j = 0; j < count; j++) {
+                const int i = idx[j], k = set_frames[l][j]++;
+                const bool last_of_set = k + 1 == set_total[l][j];
+                raws[j] = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
+                jobs[j] = FrameJob{ focals[i], shifts + 3 * (size_t) i, (char*) scratch + (size_t) (group * l + j) * sb, crop ? raws[j] : outs[j], nullptr, nullptr,
+                                    nullptr, nullptr, (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_set ? 0 : KBE_STAGE_ZBUF_A) };
+            }
+            rc = render_jobs(points, image, depth, N, W, H, baseline, count, jobs, KBE_VIDEO_STAGES | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0),
+                             crop ? rect : nullptr, raster_w, raster_n, ls[l]);
+        } else {
+            // fused route: one k_frame per frame, the fill for the whole group
+            FillTarget targets[KBE_FILL_JOBS];
+            for (int j = 0; j < count && rc == KBE_OK; j++) {
+                const int i = idx[j], k = set_frames[l][j]++;
+                char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
+                raws[j] = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
+                uint8_t* const target = crop ? raws[j] : outs[j];
+                const Scratch sc = carve(scr, W, H);
                 rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scr, target, nullptr, nullptr,
                                             nullptr, nullptr, KBE_STAGE_TILES, crop ? rect : nullptr, k & 1, (kbe_stream_t) ls[l]);
                 targets[j] = FillTarget{ sc, sc.hole_count + (k & 1), target, nullptr, 0, sc.hole_count + ((k & 1) ^ 1) };
-            } else {
-                const bool last_of_set = k + 1 == set_total[l][j];
-                const int zflags = (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_set ? 0 : KBE_STAGE_ZBUF_A);
-                rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scr, target, nullptr, nullptr,
-                                             nullptr, nullptr, KBE_STAGE_PROJECT | KBE_STAGE_TILES | zflags, crop ? rect : nullptr, raster_w, raster_n,
-                                             (kbe_stream_t) ls[l]);
-                targets[j] = FillTarget{ sc, sc.hole_count, target, nullptr, zflags ? 0 : 1, nullptr };
             }
-            raws[j] = raw;
+            if (rc != KBE_OK || count == 0) return rc;
+            FillRect fr = { 0, 0, W - 1, H - 1 };
+            if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
+            launch_fill(ls[l], count, targets, W, H, KBE_STAGE_FILL | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0), fill_dirs, fr,
+                        targets[0].sc.tiles_x * targets[0].sc.tiles_y);
+            rc = launched("kbe_render_video/fill");
         }
-        if (rc != KBE_OK || count == 0) return rc;
-        FillRect fr = { 0, 0, W - 1, H - 1 };
-        if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
-        launch_fill(ls[l], count, targets, W, H, KBE_STAGE_FILL | KBE_STAGE_FILL_BY_COUNT | KBE_STAGE_FILL_DIST, fill_dirs, fr, targets[0].sc.tiles_x * targets[0].sc.tiles_y);
-        if ((rc = launched("kbe_render_video/fill")) != KBE_OK) return rc;
         for (int j = 0; j < count && rc == KBE_OK && crop; j++) rc = kbe_crop_resize_u8(raws[j], W, H, crop_w, crop_h, outs[j], (kbe_stream_t) ls[l]);
         return rc;
     };

@@ -366,6 +366,28 @@ def test_bucket_route_video_alternates_its_z_buffers(K, monkeypatch, lanes, n_fr
     assert torch.equal(zp.view(torch.int32), ref.view(torch.int32))
 
 
+def test_group_of_frames_per_launch_equals_frames_on_their_own(K, monkeypatch):
+    """kbe_render_frame_group: projection, tile and fill launches that take 1..4 frames each (one grid dimension is the
+    frame), every frame with its own camera and scratch set, against kbe_render_frame per frame -- twice, the second time
+    with the sets' z-buffers alternating (A, then B)."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '0')
+    settings, oc = _scene((200, 312), 4, 'noise')
+    settings = dict(settings, dblSteps=[0.0, 0.3, 0.7, 1.0])
+    cams = common.frame_cameras(settings, oc)
+    state = common._prepared_cloud(K, oc)
+    alone = torch.stack([K.render_frame(state, sh, f, oc['dblBaseline']).clone() for f, sh in cams])
+    for n in (1, 3, 4):
+        out = torch.zeros(n, 200, 312, 3, dtype=torch.uint8, device='cuda')
+        for flags in (None, [128] * n, [256] * n, None):
+            out.zero_()
+            K.render_frame_group(state, cams[:n], oc['dblBaseline'], out, zbuf_flags=flags)
+            d = (out.int() - alone[:n].int()).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, 'n=%d flags=%s' % (n, flags)
+    with pytest.raises(Exception):
+        K.render_frame_group(state, cams * 2, oc['dblBaseline'], torch.zeros(8, 200, 312, 3, dtype=torch.uint8, device='cuda'))
+
+
 @pytest.mark.parametrize('fused', ['0', '1'])
 @pytest.mark.parametrize('group,n_frames,lanes', [('2', 7, '4'), ('3', 13, '2'), ('4', 16, '4'), ('4', 5, '3'), ('2', 1, '2')])
 def test_video_that_fills_several_frames_per_launch_equals_frames_on_their_own(K, monkeypatch, fused, group, n_frames, lanes):

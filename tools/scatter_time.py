@@ -20,3 +20,24 @@ oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'in
 cams = common.frame_cameras(settings, oc)
 kt = bench.time_kernels(oc, cams)
 print(' '.join('%s=%.2f' % (k, v * 1e6) for k, v in kt.items() if k != 'route' and k.startswith(('bucket', 'fused'))))
+
+# the bucket route's scatter (k_project + k_tiles) with 1..4 frames per launch, alone on a stream, us per FRAME
+K = _native.kernels()
+state = common._prepared_cloud(K, oc)
+if not state.get('fused') or os.environ.get('KBE_FUSED') == '0':
+    focal, shift3 = cams[len(cams) // 2]
+    out = torch.empty(8, size, size, 3, dtype=torch.uint8, device='cuda')
+    for n in (1, 2, 4, 6, 8):
+        group = [(focal, shift3)] * n
+
+        def run(flag):
+            K.render_frame_group(state, group, oc['dblBaseline'], out[:n], stages=3, zbuf_flags=[flag] * n)
+        run(128); run(256)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(40):
+            run(128 if r % 2 == 0 else 256)
+        e1.record()
+        torch.cuda.synchronize()
+        print('scatter with %d frame(s) per launch: %.2f us per frame' % (n, e0.elapsed_time(e1) * 1e3 / 40 / n))
