@@ -92,6 +92,9 @@ def measured_traffic():
         return {}, None
 
 
+GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group)
+
+
 def time_kernels(oc, cams, reps=40, fill_rect=None):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
@@ -137,6 +140,18 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
         if flip[0] & 1:
             alternating(3)()
     out['bucket:scatter'] = timed(alternating(3))
+    # the same two launches taking FOUR frames each (kbe_render_frame_group: what videos with KBE_VIDEO_FILL_GROUP use), per launch pair
+    group_out = torch.empty(GROUP_FRAMES, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
+    gflip = [0]
+
+    def grouped():
+        K.render_frame_group(state, [(focal, shift3)] * GROUP_FRAMES, Bl, group_out, stages=3, zbuf_flags=[256 if gflip[0] & 1 else 128] * GROUP_FRAMES)
+        gflip[0] += 1
+    out['bucket:scatter_group'] = timed(grouped)
+    if gflip[0] & 1:
+        grouped()
+    K.render_frame_group(state, [(focal, shift3)] * GROUP_FRAMES, Bl, group_out, stages=4, fill_rect=empty)       # leaves the sets clean
+    del group_out
     out['bucket:scatter+fill'] = timed(alternating(7, fill_rect=fill_rect))
     settle()
     out['bucket:reset'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b))
@@ -365,6 +380,20 @@ def main():
             return {'kernel': ' + '.join(route_launches[r]), 'us': round(t * 1e6, 2), 'achieved': scatter_bytes / t / 1e9,
                     'frac': scatter_bytes / t / 1e9 / HBM_PEAK_GBS, 'traffic': tr}
         main, other = roof(route), roof('bucket' if route == 'fused' else 'fused')
+        # frames per launch in the timed region (videos that fill with the tables render four frames per launch); the bucket
+        # route's launches with four frames each are reported either way
+        state = common._prepared_cloud(_native.kernels(), oc)
+        _, group_used = _native.kernels().video_launch_shape(state, cams, args.batch)
+        tg = kt['bucket:scatter_group']
+        grouped = {'kernel': 'k_project + k_tiles', 'frames_per_launch': GROUP_FRAMES, 'us': round(tg * 1e6, 2), 'us_per_frame': round(tg * 1e6 / GROUP_FRAMES, 2),
+                   'algorithmic_bytes': GROUP_FRAMES * scatter_bytes, 'achieved': GROUP_FRAMES * scatter_bytes / tg / 1e9,
+                   'frac': GROUP_FRAMES * scatter_bytes / tg / 1e9 / HBM_PEAK_GBS,
+                   'note': 'the same launches taking %d frames each (kbe_render_frame_group; videos with KBE_VIDEO_FILL_GROUP): bytes of %d frames over one launch pair'
+                           % (GROUP_FRAMES, GROUP_FRAMES)}
+        frames_per_launch = 1
+        if route == 'bucket' and group_used == GROUP_FRAMES:
+            frames_per_launch = GROUP_FRAMES
+            main = dict(main, us=grouped['us'], achieved=grouped['achieved'], frac=grouped['frac'])
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
@@ -382,7 +411,8 @@ def main():
                             'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
             'roofline': {'bound': 'hbm', 'kernel': main['kernel'] + ' (the scatter = render_pointcloud, %s route)' % route,
                          'achieved': main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': main['frac'],
-                         'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': scatter_bytes,
+                         'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': frames_per_launch * scatter_bytes,
+                         'frames_per_launch': frames_per_launch, 'grouped': grouped,
                          'formula': '28 N + 20 HW (SURVEY.md 8d)', 'us': main['us'],
                          'other_route': dict(other, route='bucket' if route == 'fused' else 'fused'),
                          'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions); the matching rocprofv3 --stats '

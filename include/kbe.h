@@ -291,6 +291,9 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * chip: n frames per launch take much less than n times as long).  `scratch` must then hold n * lanes sets
  * (n * lanes * kbe_video_scratch_stride bytes, every set initialised with kbe_frame_scratch_init); same frames. */
 #define KBE_VIDEO_FILL_GROUP(n) (((n) - 1) << 1)
+/* batch <= 0, frames to host memory: the lanes do not take turns on the PCIe link (for videos whose rendering binds, not the
+ * link: a lane waiting for its turn would only idle) */
+#define KBE_VIDEO_FREE_TRANSFERS 8
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

@@ -337,6 +337,26 @@ class HipKernels:
                                                     _i(state['raster_w']), _i(state['raster_n']), _stream()), 'kbe_render_frame_group')
         return out
 
+    def video_launch_shape(self, state, cameras, batch):
+        """(flags of kbe_render_video, frames per launch) for a video of `cameras`.
+        KBE_VIDEO_FILL_DIST, the table-driven hole fill: for videos whose frames have hundreds of thousands of holes -- a
+        cloud without appended points (no inpainting) seen by a camera that zooms out (a dolly zoom lowers the focal length:
+        the image shrinks into an empty border).  Measured, us per frame without / with: dolly 300 / 129 at 1024^2, 77 / 63
+        at 512^2 -- but a raw cloud on the ordinary camera path 35.2 / 37.8, 2048^2 139 / 151 (two more launches per frame
+        that find few holes).  KBE_FILL_DIST=1 / 0 forces it on / off.
+        KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets, every launch taking all n.  Such videos are
+        bound by their lanes' chains of launches, not by the chip (dolly: 131 us per frame with n = 1, 111 / 106 / 102 with
+        2 / 3 / 4, 92 with the scatter launches grouped as well); the bench workload with four lanes is bound by the
+        chip and loses 3-7 % (28.9 -> 30.9 us), so there n = 1 unless KBE_FILL_GROUP says otherwise."""
+        W, H = state['W'], state['H']
+        mode = os.environ.get('KBE_FILL_DIST', 'auto')
+        zooms_out = len(cameras) > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
+        flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
+        group = max(1, min(4, int(os.environ.get('KBE_FILL_GROUP', DEFAULT_FILL_GROUP))))
+        if not (batch is None or batch <= 0) or not (flags or os.environ.get('KBE_FILL_GROUP')):
+            group = 1
+        return flags | ((group - 1) << 1), group
+
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
@@ -371,21 +391,16 @@ class HipKernels:
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
-        # table-driven hole fill (KBE_STAGE_FILL_DIST) for videos whose frames have hundreds of thousands of holes: a cloud
-        # without appended points (no inpainting) seen by a camera that zooms out (a dolly zoom lowers the focal length: the
-        # image shrinks into an empty border).  Measured, us per frame without / with: dolly 300 / 129 at 1024^2, 77 / 63 at
-        # 512^2 -- but a raw cloud on the ordinary camera path 35.2 / 37.8, 2048^2 139 / 151 (two more launches per frame
-        # that find few holes).  KBE_FILL_DIST=1 / 0 forces it on / off.
-        mode = os.environ.get('KBE_FILL_DIST', 'auto')
-        zooms_out = n > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
-        flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
+        flags, group = self.video_launch_shape(state, cameras, batch)
+        # KBE_VIDEO_FREE_TRANSFERS: videos that fill with the tables are bound by their rendering (the link is half idle), and
+        # a lane waiting for its turn on the link only idles: bench --dolly 8.1 k frames/s delivered with turns, 9.1 k without
+        # (512^2 and 2048^2 frames, whose transfers fill the link to 70 %, keep the turns: 57 vs 53 k, 2.65 vs 2.03 k)
+        free = os.environ.get('KBE_FREE_TRANSFERS', 'auto')
+        if not host_out.is_cuda and (free == '1' or (free == 'auto' and flags & 1)):
+            flags |= 8
         scratch = state['scratch']
-        group = max(1, min(4, int(os.environ.get('KBE_FILL_GROUP', DEFAULT_FILL_GROUP))))
-        if batch <= 0 and group > 1 and (flags or os.environ.get('KBE_FILL_GROUP')):
-            # KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets and fills them in the same launches
-            # (dolly bench, us per frame: see DESIGN.md); n * lanes sets, allocated on first use
-            flags |= (group - 1) << 1
-            scratch, _ = self.group_scratch(state, group * state['lanes'])
+        if group > 1:
+            scratch, _ = self.group_scratch(state, group * state['lanes'])      # n * lanes sets, allocated on first use
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),

@@ -676,11 +676,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct DeliverCtl { uint32_t serving; uint32_t pad[31]; uint32_t done[32]; };
 static_assert(sizeof(DeliverCtl) <= 256, "kbe_video_stage_bytes reserves 256 bytes");      // serving: copies finished so far; done: per-copy workgroup count
 
-// the turn of a runtime transfer: pass == 0 waits (bounded) until `ticket` is served, pass == 1 hands the turn on
-__global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, uint32_t ticket, int pass)
+// the turn of a runtime transfer.  pass == 0: the group draws a ticket NOW, when its frames are ready -- first ready, first
+// served: with turns in the order of the groups a lane whose group is ready waited for lanes still rendering earlier groups
+// (dolly frames differ 5 x in cost along a video: passes of 109 and 145 ms alternated) -- and waits (bounded) until the
+// transfers in front of it have finished; pass == 1 hands the turn on.  pad[0]: tickets drawn so far.
+__global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, int pass)
 {
     if (threadIdx.x != 0) return;
-    if (pass) { atomicMax(&ctl->serving, ticket + 1); return; }
+    if (pass) { atomicAdd(&ctl->serving, 1u); return; }
+    const uint32_t ticket = atomicAdd(&ctl->pad[0], 1u);
     for (int polls = 0; polls < DELIVER_MAX_POLLS; polls++) {
         if (__hip_atomic_load(&ctl->serving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ticket) break;
         __builtin_amdgcn_s_sleep(32);
@@ -1132,7 +1136,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         //   batch < 0    per group of G = -batch consecutive frames, rendered by ONE lane into its G slots and sent with one
         //                runtime transfer (hipMemcpyAsync) between a gate kernel that waits for the turn and one that
         //                passes it on.
-        DeliverCtl* ctl = lanes > 1 ? (DeliverCtl*) (stage + ctl_offset) : nullptr;
+        // (where the rendering binds, not the link, the transfers need no order: a lane that waits for its turn only idles)
+        DeliverCtl* ctl = lanes > 1 && !(flags & KBE_VIDEO_FREE_TRANSFERS) ? (DeliverCtl*) (stage + ctl_offset) : nullptr;
         if (batch == 0) {
             for (int i = 0; i < n_frames && rc == KBE_OK; i++) {
                 const int l = i % lanes, slot = i % slots;
@@ -1164,10 +1169,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 }
                 else for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
                 if (rc != KBE_OK) break;
-                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, (uint32_t) g, 0);
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0);
                 const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
-                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, (uint32_t) g, 1);
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 1);
                 rc = launched("kbe_render_video/turn");
             }
         }
