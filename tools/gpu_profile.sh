@@ -40,6 +40,10 @@ for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPS
   done
 done
 ) > $OUT/other_workloads.txt
+# 4b. the bucket route's launches with four frames each (kbe_render_frame_group), alone on a stream: rocprofv3 --stats of exactly those
+rm -rf /tmp/kg
+KBE_FUSED=0 GROUP_ONLY=4 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kg -o b --output-format csv -- python $R/tools/scatter_time.py > $OUT/scatter_group4.txt 2>/dev/null
+if [ -f /tmp/kg/b_kernel_stats.csv ]; then cp /tmp/kg/b_kernel_stats.csv $OUT/scatter_group4_kernel_stats.csv; fi
 # 5. the dolly zoom (frames with very many holes: the distance-table fill): per-kernel stats of its frame loop, and what the fill does
 rm -rf /tmp/kd
 DOLLY=1 REPS=2 FRAMES=128 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kd -o b --output-format csv -- python $R/tools/throughput.py > $OUT/dolly_under_rocprof.txt 2>/dev/null

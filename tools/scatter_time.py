@@ -18,16 +18,18 @@ ofrom, oto = synthetic.default_windows(size, size, False)
 settings = {'dblSteps': [i / 63 for i in range(64)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False}
 oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint', settings, 1)
 cams = common.frame_cameras(settings, oc)
-kt = bench.time_kernels(oc, cams)
-print(' '.join('%s=%.2f' % (k, v * 1e6) for k, v in kt.items() if k != 'route' and k.startswith(('bucket', 'fused'))))
+only = os.environ.get('GROUP_ONLY')          # e.g. 4: only the launches with that many frames each (a clean rocprofv3 --stats of them)
+if not only:
+    kt = bench.time_kernels(oc, cams)
+    print(' '.join('%s=%.2f' % (k, v * 1e6) for k, v in kt.items() if k != 'route' and k.startswith(('bucket', 'fused'))))
 
 # the bucket route's scatter (k_project + k_tiles) with 1..4 frames per launch, alone on a stream, us per FRAME
 K = _native.kernels()
 state = common._prepared_cloud(K, oc)
 if not state.get('fused') or os.environ.get('KBE_FUSED') == '0':
     focal, shift3 = cams[len(cams) // 2]
-    out = torch.empty(8, size, size, 3, dtype=torch.uint8, device='cuda')
-    for n in (1, 2, 4, 6, 8):
+    out = torch.empty(4, size, size, 3, dtype=torch.uint8, device='cuda')
+    for n in ((int(only),) if only else (1, 2, 3, 4)):
         group = [(focal, shift3)] * n
 
         def run(flag):
