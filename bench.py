@@ -95,7 +95,7 @@ def measured_traffic():
 GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group)
 
 
-def time_kernels(oc, cams, reps=40, fill_rect=None):
+def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
     launches between two events; the tile kernel is timed alone (back to back on a prepared scratch) --
@@ -141,16 +141,16 @@ def time_kernels(oc, cams, reps=40, fill_rect=None):
             alternating(3)()
     out['bucket:scatter'] = timed(alternating(3))
     # the same two launches taking FOUR frames each (kbe_render_frame_group: what videos with KBE_VIDEO_FILL_GROUP use), per launch pair
-    group_out = torch.empty(GROUP_FRAMES, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
+    group_out = torch.empty(group_frames, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
     gflip = [0]
 
     def grouped():
-        K.render_frame_group(state, [(focal, shift3)] * GROUP_FRAMES, Bl, group_out, stages=3, zbuf_flags=[256 if gflip[0] & 1 else 128] * GROUP_FRAMES)
+        K.render_frame_group(state, [(focal, shift3)] * group_frames, Bl, group_out, stages=3, zbuf_flags=[256 if gflip[0] & 1 else 128] * group_frames)
         gflip[0] += 1
     out['bucket:scatter_group'] = timed(grouped)
     if gflip[0] & 1:
         grouped()
-    K.render_frame_group(state, [(focal, shift3)] * GROUP_FRAMES, Bl, group_out, stages=4, fill_rect=empty)       # leaves the sets clean
+    K.render_frame_group(state, [(focal, shift3)] * group_frames, Bl, group_out, stages=4, fill_rect=empty)       # leaves the sets clean
     del group_out
     out['bucket:scatter+fill'] = timed(alternating(7, fill_rect=fill_rect))
     settle()
@@ -361,7 +361,15 @@ def main():
         from ken_burns_effect_amd import _native
         lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
         host_lanes = _native.host_lanes(lanes, n_points, size, size, 3 * size * size)
-        kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]))
+        # frames per launch in the timed region (small frames and videos that fill with the tables render several), and its route
+        state = common._prepared_cloud(_native.kernels(), oc)
+        _, group_used = _native.kernels().video_launch_shape(state, cams, args.batch)
+        group_frames = group_used if group_used > 1 else GROUP_FRAMES
+        kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames)
+        if kt['route'] == 'fused' and group_used > 1 and os.environ.get('KBE_FUSED') != '1':
+            kt['route'] = 'bucket'      # grouped videos take the bucket route (_native.render_video)
+            for k in ('scatter', 'scatter+fill'):
+                kt[k] = kt['bucket:' + k]
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch)
@@ -380,20 +388,16 @@ def main():
             return {'kernel': ' + '.join(route_launches[r]), 'us': round(t * 1e6, 2), 'achieved': scatter_bytes / t / 1e9,
                     'frac': scatter_bytes / t / 1e9 / HBM_PEAK_GBS, 'traffic': tr}
         main, other = roof(route), roof('bucket' if route == 'fused' else 'fused')
-        # frames per launch in the timed region (videos that fill with the tables render four frames per launch); the bucket
-        # route's launches with four frames each are reported either way
-        state = common._prepared_cloud(_native.kernels(), oc)
-        _, group_used = _native.kernels().video_launch_shape(state, cams, args.batch)
         tg = kt['bucket:scatter_group']
-        grouped = {'kernel': 'k_project + k_tiles', 'frames_per_launch': GROUP_FRAMES, 'us': round(tg * 1e6, 2), 'us_per_frame': round(tg * 1e6 / GROUP_FRAMES, 2),
-                   'algorithmic_bytes': GROUP_FRAMES * scatter_bytes, 'achieved': GROUP_FRAMES * scatter_bytes / tg / 1e9,
-                   'frac': GROUP_FRAMES * scatter_bytes / tg / 1e9 / HBM_PEAK_GBS,
+        grouped = {'kernel': 'k_project_group + k_tiles_group', 'frames_per_launch': group_frames, 'us': round(tg * 1e6, 2), 'us_per_frame': round(tg * 1e6 / group_frames, 2),
+                   'algorithmic_bytes': group_frames * scatter_bytes, 'achieved': group_frames * scatter_bytes / tg / 1e9,
+                   'frac': group_frames * scatter_bytes / tg / 1e9 / HBM_PEAK_GBS,
                    'note': 'the same launches taking %d frames each (kbe_render_frame_group; videos with KBE_VIDEO_FILL_GROUP): bytes of %d frames over one launch pair'
-                           % (GROUP_FRAMES, GROUP_FRAMES)}
+                           % (group_frames, group_frames)}
         frames_per_launch = 1
-        if route == 'bucket' and group_used == GROUP_FRAMES:
-            frames_per_launch = GROUP_FRAMES
-            main = dict(main, us=grouped['us'], achieved=grouped['achieved'], frac=grouped['frac'])
+        if route == 'bucket' and group_used > 1:
+            frames_per_launch = group_used
+            main = dict(main, kernel=grouped['kernel'], us=grouped['us'], achieved=grouped['achieved'], frac=grouped['frac'])
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,

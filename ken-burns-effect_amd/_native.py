@@ -352,8 +352,16 @@ class HipKernels:
         mode = os.environ.get('KBE_FILL_DIST', 'auto')
         zooms_out = len(cameras) > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
-        group = max(1, min(4, int(os.environ.get('KBE_FILL_GROUP', DEFAULT_FILL_GROUP))))
-        if not (batch is None or batch <= 0) or not (flags or os.environ.get('KBE_FILL_GROUP')):
+        if os.environ.get('KBE_FILL_GROUP'):
+            group = max(1, min(4, int(os.environ['KBE_FILL_GROUP'])))
+        elif flags:
+            group = DEFAULT_FILL_GROUP
+        else:
+            # small frames are bound by their launches, not by the chip (measured, bucket route, us per frame with 1 / 2 / 4
+            # frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 / 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4,
+            # 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)
+            group = 4 if W * H <= 576 * 576 else (2 if W * H <= 900 * 900 else 1)
+        if not (batch is None or batch <= 0):
             group = 1
         return flags | ((group - 1) << 1), group
 
@@ -392,6 +400,9 @@ class HipKernels:
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
         flags, group = self.video_launch_shape(state, cameras, batch)
+        # with several frames per launch the bucket route beats the one-launch route at every size (512^2: 8.6 vs 11.1 us per
+        # frame, 256^2: 6.2 vs 7.4): KBE_FUSED=auto then means the bucket route for a video (a frame on its own keeps k_frame)
+        fused = bool(state.get('fused')) and (group == 1 or os.environ.get('KBE_FUSED') == '1')
         # KBE_VIDEO_FREE_TRANSFERS: videos that fill with the tables are bound by their rendering (the link is half idle), and
         # a lane waiting for its turn on the link only idles: bench --dolly 8.1 k frames/s delivered with turns, 9.1 k without
         # (512^2 and 2048^2 frames, whose transfers fill the link to 70 %, keep the turns: 57 vs 53 k, 2.65 vs 2.03 k)
@@ -405,7 +416,7 @@ class HipKernels:
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
-                                              _ptr(state['packed'], torch.uint8) if state.get('fused') else None, _d(state['cloud_focal']),
+                                              _ptr(state['packed'], torch.uint8) if fused else None, _d(state['cloud_focal']),
                                               _i(flags), _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
         return host_out
 
