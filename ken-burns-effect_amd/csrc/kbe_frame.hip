@@ -1116,7 +1116,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                         targets[0].sc.tiles_x * targets[0].sc.tiles_y);
             rc = launched("kbe_render_video/fill");
         }
-        for (int j = 0; j < count && rc == KBE_OK && crop; j++) rc = kbe_crop_resize_u8(raws[j], W, H, crop_w, crop_h, outs[j], (kbe_stream_t) ls[l]);
+        if (rc == KBE_OK && crop) rc = crop_resize_group(count, raws, W, H, crop_w, crop_h, outs, ls[l]);
         return rc;
     };
     // whoever synchronises `stream` afterwards also sees every frame delivered and every other stream idle

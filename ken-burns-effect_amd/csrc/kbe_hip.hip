@@ -309,8 +309,7 @@ constexpr int CR_PBYTES = CR_PCOLS * 3, CR_PSTRIDE = (CR_PBYTES + 3) / 4 + 1;   
 constexpr int CR_RROWS = CR_PROWS + 1, CR_RDW = ((CR_PCOLS + 1) * 3 + 3 + 3) / 4 + 1;  // raw rows / dwords per raw row
 static_assert(CR_RROWS * CR_RDW <= 3 * CR_THREADS && CR_THREADS == 4 * CR_TW && CR_TH == 8, "crop tile geometry");
 
-__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
-                                                               uint8_t* __restrict__ out)
+__device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_, uint8_t* __restrict__ out)
 {
     __shared__ uint32_t s_raw[CR_RROWS][CR_RDW];
     __shared__ uint32_t s_patch[CR_PROWS][CR_PSTRIDE];
@@ -438,6 +437,19 @@ __global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
+                                                               uint8_t* __restrict__ out)
+{
+    crop_resize_body(img, W, H, cw, ch_, out);
+}
+
+// the same for up to four frames of the same size in one launch (blockIdx.z = the frame): the video loop's groups
+struct CropJobs { const uint8_t* img[4]; uint8_t* out[4]; };
+__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8_group(CropJobs jobs, int W, int H, int cw, int ch_)
+{
+    crop_resize_body(jobs.img[blockIdx.z], W, H, cw, ch_, jobs.out[blockIdx.z]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -755,6 +767,22 @@ int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int c
                        (hipStream_t) stream, frame_hwc, W, H, crop_w, crop_h, out_hwc);
     return launched("kbe_crop_resize_u8");
 }
+
+}  // extern "C"
+
+namespace kbe {
+// kbe_crop_resize_u8 for n <= 4 frames of the same size in one launch (kbe_render_video's groups)
+int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int crop_w, int crop_h, uint8_t* const* outs, hipStream_t stream)
+{
+    if (n == 1) return kbe_crop_resize_u8(frames[0], W, H, crop_w, crop_h, outs[0], (kbe_stream_t) stream);
+    CropJobs jobs;
+    for (int k = 0; k < 4; k++) { jobs.img[k] = frames[k < n ? k : 0]; jobs.out[k] = outs[k < n ? k : 0]; }
+    hipLaunchKernelGGL(k_crop_resize_u8_group, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH, n), dim3(CR_THREADS), 0, stream, jobs, W, H, crop_w, crop_h);
+    return launched("kbe_crop_resize_u8 (group)");
+}
+}  // namespace kbe
+
+extern "C" {
 
 int kbe_depth_to_points(const float* depth, const float* valid, int B, int W, int H, double focal, float* points,
                         kbe_stream_t stream)

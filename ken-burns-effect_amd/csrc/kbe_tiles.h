@@ -128,6 +128,8 @@ struct FillJob {                    // ... and as the kernels see it
 };
 struct FillJobs { FillJob j[KBE_FILL_JOBS]; };
 void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, int H, int stages, const FillDirs& dirs, const FillRect& rect, int n_tiles);
+// kbe_hip.hip: kbe_crop_resize_u8 for n <= 4 frames of the same size in one launch
+int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int crop_w, int crop_h, uint8_t* const* outs, hipStream_t stream);
 // kbe_fused.hip: the one-launch scatter of a frame from the packed cloud (k_frame)
 void launch_frame_fused(hipStream_t s, unsigned n_tiles, const void* packed, int N, double cloud_focal, const Camera& cam, const Scratch& sc, int* hole_count,
                         uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32, float* zee_pre_f32);
