@@ -286,10 +286,12 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
 KBE_API size_t kbe_video_scratch_stride(int W, int H);
 KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 #define KBE_VIDEO_FILL_DIST 1        /* kbe_render_video flags: KBE_STAGE_FILL_DIST for every frame */
-/* with KBE_VIDEO_FILL_DIST, batch <= 0 and two or more lanes: a lane renders n = 2..4 frames, each into a scratch set of its
- * own, and fills them in the same launches (the table-driven fill is bound by its chain of dependent look-ups, not by the
- * chip: n frames per launch take much less than n times as long).  `scratch` must then hold n * lanes sets
- * (n * lanes * kbe_video_scratch_stride bytes, every set initialised with kbe_frame_scratch_init); same frames. */
+/* batch <= 0: a lane renders n = 2..4 frames at a time, each into a scratch set of its own, and every launch of the bucket
+ * route (projection, tiles, fill, crop) takes all n (the fused route: its fill and crop).  For videos that are bound by
+ * their lanes' chains of launches rather than by the chip -- small frames, frames that fill with the tables -- n frames per
+ * launch take much less than n times as long; a 1024 x 1024 video of an inpainted cloud on four lanes is bound by the chip
+ * and loses 3-7 %.  `scratch` must then hold n * lanes sets (n * lanes * kbe_video_scratch_stride bytes, every set
+ * initialised with kbe_frame_scratch_init); same frames. */
 #define KBE_VIDEO_FILL_GROUP(n) (((n) - 1) << 1)
 /* batch <= 0, frames to host memory: the lanes do not take turns on the PCIe link (for videos whose rendering binds, not the
  * link: a lane waiting for its turn would only idle) */
