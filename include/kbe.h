@@ -271,7 +271,7 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  * lanes taking turns on the PCIe link (a bounded, advisory device-side wait), by `batch`:
  *   batch < 0: groups of G = -batch consecutive frames are rendered by one lane into its own G buffers and leave
  *       with ONE hipMemcpyAsync per group (the runtime's transfer engine).  The default of the Python host side:
- *       G = 8 on 2 lanes keeps the link busy back to back (59 us per 1024^2 frame, 53 GB/s of PCIe Gen5 x16).
+ *       G = 16 on 2 lanes keeps the link busy back to back (58 us per 1024^2 frame, 54 GB/s of PCIe Gen5 x16; G = 8: 59 us).
  *   batch == 0: per frame, by a small copy kernel (k_deliver: 16 workgroups, 16-byte stores, throttled).
  *   batch <= 0 with host_out = DEVICE memory: every frame's last kernel stores straight into host_out[i]
  *       (the frames stay in HBM).

@@ -369,7 +369,7 @@ class HipKernels:
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
         also be a DEVICE tensor: the frames then stay in HBM (the last kernel of every frame stores straight into
-        it, no transfer).  ``batch`` selects the hand-off to host memory (None: groups of up to 8 frames per
+        it, no transfer).  ``batch`` selects the hand-off to host memory (None: groups of up to 16 frames per
         transfer on KBE_HOST_LANES lanes; see include/kbe.h); ``overlap`` only matters for ``batch`` > 0."""
         n, W, H = len(cameras), state['W'], state['H']
         dev = state['points'].device
@@ -386,7 +386,7 @@ class HipKernels:
             # taking turns on the link (default); 0 = per frame by a copy kernel; > 0 = round 1's staged ring.
             lanes = host_lanes(lanes, state['N'], W, H, 3 * W * H)      # a cropped frame is resized back to W x H (common.py:257)
             if batch is None:
-                batch = int(os.environ.get('KBE_DELIVERY_BATCH', '0')) or -max(1, min(8, n // (4 * lanes)))
+                batch = int(os.environ.get('KBE_DELIVERY_BATCH', '0')) or -max(1, min(16, n // (4 * lanes)))
         batch = max(-64, int(batch))
         need = int(self.lib.kbe_video_stage_bytes(_i(W), _i(H), _i(lanes), _i(batch)))
         if 'stage' not in state or state['stage'].numel() < need:
