@@ -215,3 +215,27 @@ def test_host_lanes_two_where_the_link_binds_all_where_the_rendering_does(monkey
     assert _native.host_lanes(1, 1137109, 1024, 1024, 3 << 20) == 1
     monkeypatch.setenv('KBE_HOST_LANES', '3')
     assert _native.host_lanes(4, 1137109, 1024, 1024, 3 << 20) == 3
+
+
+def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
+    """_native.video_launch_shape: the table-driven fill for clouds without appended points seen by a camera that zooms out;
+    frames per launch by what binds the video (4 for such videos and for small frames, 2 up to 900^2, 1 for the bench's)."""
+    from ken_burns_effect_amd import _native
+    for k in ('KBE_FILL_DIST', 'KBE_FILL_GROUP'):
+        monkeypatch.delenv(k, raising=False)
+    cls = [c for c in vars(_native).values() if isinstance(c, type) and hasattr(c, 'video_launch_shape')][0]
+    shape = lambda state, cams, batch=None: cls.video_launch_shape(None, state, cams, batch)       # noqa: E731
+    still = [(512.0, (0.0, 0.0, 0.0))] * 8
+    zoom = [(512.0 - 40.0 * i, (0.0, 0.0, -20.0 * i)) for i in range(8)]
+    inpainted = {'W': 1024, 'H': 1024, 'N': 1137109, 'cloud_focal': 512.0}
+    raw = {'W': 1024, 'H': 1024, 'N': 1048576, 'cloud_focal': 512.0}
+    assert shape(inpainted, still) == (0, 1) and shape(inpainted, zoom) == (0, 1)
+    assert shape(raw, still) == (0, 1)
+    assert shape(raw, zoom) == (1 | (3 << 1), 4)
+    assert shape(raw, zoom, batch=8) == (1, 1), 'the staged ring renders one frame per launch'
+    assert shape({'W': 512, 'H': 512, 'N': 300000, 'cloud_focal': 512.0}, still) == (3 << 1, 4)
+    assert shape({'W': 768, 'H': 768, 'N': 700000, 'cloud_focal': 512.0}, still) == (1 << 1, 2)
+    monkeypatch.setenv('KBE_FILL_GROUP', '3')
+    assert shape(inpainted, still) == (2 << 1, 3)
+    monkeypatch.setenv('KBE_FILL_DIST', '0')
+    assert shape(raw, zoom) == (2 << 1, 3)
