@@ -222,6 +222,21 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N ranks of this script under torch.distributed.run, one process per
+    GPU, rendezvous on 127.0.0.1 -- the same command line the driver uses when it starts the ranks itself.  Rank 0's JSON line
+    passes through on stdout; the exit status is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('bench.py: starting %d ranks: %s\n' % (n, ' '.join(cmd)))
+    return subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8')))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -243,37 +258,70 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # before the first HIP call: RCCL needs dmabuf IPC on this stack
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # `python bench.py --gpus N`: one process per GPU, started here
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world_size == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world_size)
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    if world_size != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run with '
+                 '--nproc-per-node N)' % (args.gpus, world_size))
+    launch_only = os.environ.get('KBE_BENCH_LAUNCH_ONLY') == '1'        # tests/test_bench_launcher.py: rendezvous + collectives, no rendering
+    if not launch_only and not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (the product path has no CPU fallback)')
     # one process per GPU.  (KBE_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer
-    # GPUs than ranks -- ranks then share devices; never use that for a measurement.)
+    # GPUs than ranks -- ranks then share devices; such a line carries "scaling_valid": false.)
     backend = os.environ.get('KBE_DIST_BACKEND', 'nccl')
-    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = torch.device('cuda', dev_index)
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    scaling_valid, scaling_note = True, None
+    if world_size > 1 and backend == 'nccl' and n_dev < world_size and not launch_only:
+        sys.exit('bench.py: --gpus %d but this box shows %d GPU(s): one process per GPU over RCCL needs %d devices '
+                 '(KBE_DIST_BACKEND=gloo shares devices between ranks for a functional check -- not a measurement)' % (world_size, n_dev, world_size))
+    if n_dev:
+        dev_index = local_rank if backend == 'nccl' else local_rank % n_dev
+        torch.cuda.set_device(dev_index)
+        device = torch.device('cuda', dev_index)
+    else:
+        dev_index, device = 0, torch.device('cpu')
+    ranks_seen = 1
     if world_size > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend == 'nccl':
-            # RCCL over xGMI.  This path has never run (no multi-GPU box was available to the builder): should the
-            # communicator fail to come up -- on every rank, as configuration errors do -- the run goes on with gloo
-            # for its three collectives (one cloud broadcast, barriers, a max over ranks) and says so in the line
+        if backend == 'nccl' and n_dev:
+            # RCCL over xGMI.  Should the communicator fail to come up -- on every rank, as configuration errors do -- the run
+            # goes on with gloo for its three collectives (one cloud broadcast, barriers, a max over ranks), and the line says
+            # so LOUDLY: "scaling_valid": false, config.collectives names the failure, stderr carries the exception
             try:
                 dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=device)
-                probe = torch.zeros(1, device=device)
+                probe = torch.ones(1, device=device)
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
+                ranks_seen = int(probe.item())
             except Exception as exc:                            # noqa: BLE001
-                sys.stderr.write('bench.py: RCCL did not come up (%s: %s); falling back to gloo\n' % (type(exc).__name__, exc))
+                sys.stderr.write('bench.py: RCCL DID NOT COME UP (%s: %s); continuing on gloo -- this is NOT an xGMI measurement\n' % (type(exc).__name__, exc))
                 if dist.is_initialized():
                     dist.destroy_process_group()
-                backend = 'gloo (RCCL failed)'
+                backend = 'gloo (RCCL failed: %s)' % type(exc).__name__
+                scaling_valid, scaling_note = False, 'RCCL failed to initialise; collectives ran on gloo over TCP'
                 dist.init_process_group('gloo', rank=rank, world_size=world_size)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world_size)
+            if backend == 'nccl':
+                backend = 'gloo'                                # launch-only check on a box without GPUs
+            dist.init_process_group(backend.split()[0], rank=rank, world_size=world_size)
+            scaling_valid, scaling_note = False, 'KBE_DIST_BACKEND=%s: ranks may share devices; functional check only' % backend
+        if not backend.startswith('nccl'):
+            probe = torch.ones(1)
+            dist.all_reduce(probe)
+            ranks_seen = int(probe.item())
+        if ranks_seen != world_size:
+            sys.exit('bench.py: the all-reduce of ones over %s returned %d, expected %d ranks' % (backend, ranks_seen, world_size))
+    if launch_only:
+        if rank == 0:
+            print(json.dumps({'launcher': 'ok', 'world_size': world_size, 'ranks_seen': ranks_seen, 'collectives': backend if world_size > 1 else None,
+                              'scaling_valid': scaling_valid}), flush=True)
+        if world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from ken_burns_effect_amd import common, sharding, synthetic
     # multi-GPU: every rank's frames land in pinned memory of the NUMA node its GPU hangs off (best effort; the CPU
@@ -410,7 +458,7 @@ def main():
                        'device_only_lanes': lanes, 'passes': len(times),
                        'pass_ms': {'median': round(elapsed * 1e3, 3), 'min': round(min(times) * 1e3, 3), 'max': round(max(times) * 1e3, 3)},
                        'sharding': 'frames round-robin over ranks; one cloud broadcast (set-up, cloud_broadcast_ms)',
-                       'collectives': backend if world_size > 1 else None},
+                       'collectives': backend if world_size > 1 else None, 'ranks_seen': ranks_seen},
             'device_only': {'value': args.steps * world_size / elapsed_dev, 'unit': 'frames/s', 'ms_per_step': elapsed_dev / args.steps * 1e3,
                             'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
             'roofline': {'bound': 'hbm', 'kernel': main['kernel'] + ' (the scatter = render_pointcloud, %s route)' % route,
@@ -428,6 +476,10 @@ def main():
             line['pcie'] = {'achieved': args.steps * size * size * 3 / elapsed / 1e9, 'unit': 'GB/s per GPU', 'peak': 63.0,
                             'note': 'uint8 frames of %.2f MB over PCIe Gen5 x16 (63 GB/s spec, ~57 measured with hipMemcpyAsync on an idle chip)'
                                     % (size * size * 3 / 1e6)}
+        if world_size > 1:
+            line['scaling_valid'] = scaling_valid
+            if scaling_note:
+                line['scaling_note'] = scaling_note
         if broadcast_ms is not None:
             line['cloud_broadcast_ms'] = broadcast_ms
             line['config']['rank0_numa_node'] = numa_node

@@ -386,8 +386,15 @@ class HipKernels:
             # taking turns on the link (default); 0 = per frame by a copy kernel; > 0 = round 1's staged ring.
             lanes = host_lanes(lanes, state['N'], W, H, 3 * W * H)      # a cropped frame is resized back to W x H (common.py:257)
             if batch is None:
-                batch = int(os.environ.get('KBE_DELIVERY_BATCH', '0')) or -max(1, min(16, n // (4 * lanes)))
-        batch = max(-64, int(batch))
+                env = os.environ.get('KBE_DELIVERY_BATCH', '0')
+                try:
+                    batch = int(env)
+                except ValueError:
+                    raise KbeError('KBE_DELIVERY_BATCH=%r is not an integer (frames per transfer: < 0 groups per lane, > 0 staged ring)' % env)
+                batch = batch or -max(1, min(16, n // (4 * lanes)))
+        # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
+        batch = int(batch)
+        batch = -min(-batch, max(n, 1), 64) if batch < 0 else min(batch, max(n, 1), 64)
         need = int(self.lib.kbe_video_stage_bytes(_i(W), _i(H), _i(lanes), _i(batch)))
         if 'stage' not in state or state['stage'].numel() < need:
             state['stage'] = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -693,12 +693,12 @@ static_assert(sizeof(DeliverCtl) <= 256, "kbe_video_stage_bytes reserves 256 byt
 // served: with turns in the order of the groups a lane whose group is ready waited for lanes still rendering earlier groups
 // (dolly frames differ 5 x in cost along a video: passes of 109 and 145 ms alternated) -- and waits (bounded) until the
 // transfers in front of it have finished; pass == 1 hands the turn on.  pad[0]: tickets drawn so far.
-__global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, int pass)
+__global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, int pass, int max_polls)
 {
     if (threadIdx.x != 0) return;
     if (pass) { atomicAdd(&ctl->serving, 1u); return; }
     const uint32_t ticket = atomicAdd(&ctl->pad[0], 1u);
-    for (int polls = 0; polls < DELIVER_MAX_POLLS; polls++) {
+    for (int polls = 0; polls < max_polls; polls++) {
         if (__hip_atomic_load(&ctl->serving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ticket) break;
         __builtin_amdgcn_s_sleep(32);
     }
@@ -1051,7 +1051,12 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         for (int l = 1; l < lanes; l++) (void) hipStreamWaitEvent(ls[l], start, 0);
         if (ringed && ds[0] != cs) (void) hipStreamWaitEvent(ds[0], start, 0);
     }
-    int lane_frames[KBE_MAX_LANES] = {};
+    // which lane renders frame i with one frame per launch (render() below): whole groups of G = -batch consecutive frames when
+    // they are handed to pinned host memory per group, round-robin otherwise; a lane's frame count tells its LAST frame
+    const bool by_groups = batch < 0 && host_dev != nullptr;
+    auto lane_of = [&](int i) { return by_groups ? (i / -batch) % lanes : i % lanes; };
+    int lane_frames[KBE_MAX_LANES] = {}, lane_total[KBE_MAX_LANES] = {};
+    for (int i = 0; i < n_frames; i++) lane_total[lane_of(i)]++;
     auto render = [&](int i, int l, uint8_t* out) {
         uint8_t* raw = stage + (size_t) l * fb;
         const int fill_flags = lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? (KBE_STAGE_FILL_BY_COUNT | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0)) : 0;
@@ -1065,8 +1070,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             // a lane's frames alternate between the two z-buffers (A, B, A, ...), each clearing the other's in its tile
             // launch; a lane's LAST frame, if it falls on A, takes the stand-alone form (A cleared by its fill launch), so
             // that every call leaves A empty -- B is always cleared before it is used
+            // (the lane's last frame by COUNT: with groups of G frames per lane `i + lanes >= n_frames` named frames in the
+            // middle of a lane's share, which then ran stand-alone and left B dirty for the lane's next frame)
             const int k = lane_frames[l]++;
-            const bool last_of_lane = i + lanes >= n_frames;
+            const bool last_of_lane = k + 1 == lane_total[l];
             const int zflags = (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_lane ? 0 : KBE_STAGE_ZBUF_A);
             rc = kbe_render_frame_stages(points, image, depth, N, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                          (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
@@ -1165,6 +1172,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
         } else {
             const int G = -batch;
+            // how long a group may wait for its turn: the transfers of every other lane in front of it (a poll is ~1 us; the
+            // link moves ~50 bytes per ns), three times over -- a fixed 4 ms was no margin for 16 frames of 2048^2 (3.8 ms each)
+            const double group_us = (double) G * (double) fb / 50.0e3;
+            const int turn_polls = (int) fmin(fmax(3.0 * lanes * group_us, (double) DELIVER_MAX_POLLS), 1.0e6);
             if (pairs) {                                                // the frames of every scratch set, counted first
                 counting = true;
                 for (int i0 = 0, g = 0; i0 < n_frames; i0 += G, g++) {
@@ -1184,10 +1195,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 }
                 else for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
                 if (rc != KBE_OK) break;
-                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0);
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls);
                 const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
-                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 1);
+                if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 1, 0);
                 rc = launched("kbe_render_video/turn");
             }
         }

@@ -1,0 +1,56 @@
+"""bench.py's multi-rank start-up, on CPU: `python bench.py --gpus 2` must start its own ranks (the driver's first command
+shape), and the driver's second shape (`python -m torch.distributed.run ... bench.py --gpus 2`) must be accepted as it is.
+KBE_BENCH_LAUNCH_ONLY=1 stops after the rendezvous and the all-reduce of ones (no GPU here); the collectives then run on gloo
+and the line says so ("scaling_valid": false)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ, KBE_BENCH_LAUNCH_ONLY='1', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1'], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line['launcher'] == 'ok' and line['world_size'] == 2 and line['ranks_seen'] == 2
+    assert line['collectives'].startswith('gloo') and line['scaling_valid'] is False       # never mistaken for xGMI
+
+
+def test_bench_under_the_drivers_launcher():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1'],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _line(r.stdout)['ranks_seen'] == 2
+
+
+def test_bench_rejects_a_world_size_that_does_not_match():
+    env = dict(_env(), WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr
+
+
+def test_single_rank_launch_check():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _line(r.stdout) == {'launcher': 'ok', 'world_size': 1, 'ranks_seen': 1, 'collectives': None, 'scaling_valid': True}

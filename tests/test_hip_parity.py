@@ -366,6 +366,36 @@ def test_bucket_route_video_alternates_its_z_buffers(K, monkeypatch, lanes, n_fr
     assert torch.equal(zp.view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize('host_lanes', ['2', '3', '4'])
+@pytest.mark.parametrize('batch,n_frames', [(-2, 16), (-4, 19), (-8, 32), (-4, 16), (-8, 19), (-16, 64)])
+def test_bucket_route_video_delivered_in_groups_alternates_its_z_buffers(K, monkeypatch, host_lanes, batch, n_frames):
+    """Frames handed to pinned host memory in groups of G = -batch per lane, ONE frame per launch (the shape of the 1024^2
+    bench): a lane then renders whole groups of consecutive frames, so its last frame is not `i + lanes >= n_frames`.
+    (Round 2 got that wrong: frames in the middle of a lane's share ran stand-alone, left z-buffer B dirty, and the lane's
+    next B frame rendered over stale keys -- lanes=2, n=64, G=8 -> frame 63.)  Every delivered frame must equal the frame
+    rendered on its own, twice in a row, and a stand-alone frame afterwards must find an empty z-buffer."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '0')
+    monkeypatch.setenv('KBE_FILL_GROUP', '1')
+    monkeypatch.setenv('KBE_LANES', '4')
+    monkeypatch.setenv('KBE_HOST_LANES', host_lanes)
+    settings, oc = _scene((160, 224), 8)
+    settings = dict(settings, dblSteps=[i / (n_frames - 1) for i in range(n_frames)])
+    cams = common.frame_cameras(settings, oc)
+    state = common._prepared_cloud(K, oc)
+    assert not state['fused']
+    alone = np.stack([K.render_frame(state, sh, f, oc['dblBaseline']).cpu().numpy() for f, sh in cams])
+    for rep in range(2):
+        video = common.render_frames(cams, oc, None, batch=batch)
+        d = np.abs(video.astype(np.int32) - alone.astype(np.int32))
+        worst = [int(i) for i in np.nonzero(d.reshape(n_frames, -1).max(axis=1) > 1)[0]]
+        assert not worst, 'pass %d: frames %s differ from the frames rendered on their own' % (rep, worst)
+        assert (d > 0).mean() < 1e-3
+        again = K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy()
+        d = np.abs(again.astype(np.int32) - alone[0].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, 'a stand-alone frame after the video (pass %d)' % rep
+
+
 def test_group_of_frames_per_launch_equals_frames_on_their_own(K, monkeypatch):
     """kbe_render_frame_group: projection, tile and fill launches that take 1..4 frames each (one grid dimension is the
     frame), every frame with its own camera and scratch set, against kbe_render_frame per frame -- twice, the second time
