@@ -120,9 +120,15 @@ def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
 
     empty = (1, 1, 0, 0)
     out = {'route': 'fused' if state.get('fused') else 'bucket'}
-    # the fused route: the scatter = ONE launch (k_frame); back to back on the stream, hole counter left alone (stage flag
-    # 64) so that nothing but the kernel sits between the events
-    out['fused:scatter'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2 | 64, fused=True))
+    # the fused route: the scatter = k_bin + k_frame; back to back on the stream, consecutive frames alternating between the
+    # scratch's two hole counters as in a video (no fill here to zero them: the hole list is bounded, the frames not used)
+    fpar = [0]
+
+    def fused_scatter():
+        K.render_frame(state, shift3, focal, Bl, stages=2, fused=True, parity=fpar[0] & 1)
+        fpar[0] += 1
+    out['fused:scatter'] = timed(fused_scatter)
+    K.render_frame(state, shift3, focal, Bl, fused=True)       # a frame on its own zeroes the counters the run above left
     out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
     # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM.  In a video consecutive frames alternate
     # between two z-buffers and each tile launch clears the other one (stage flags 128 / 256), so the scatter is these two

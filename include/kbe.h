@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 5
+#define KBE_ABI_VERSION 6
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -146,7 +146,9 @@ KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B,
  * image [3,N] (tensorInpaImage), depth [N] (tensorInpaDepth).  Any point order is correct;
  * spatially coherent order (e.g. raster) is faster.
  *
- * scratch: kbe_frame_scratch_bytes(W, H) bytes, initialised ONCE with kbe_frame_scratch_init;
+ * scratch: kbe_frame_scratch_bytes(W, H, N) bytes (N = points of the largest cloud rendered with it: a scratch set ends
+ *          with 12 bytes per point for kbe_render_frame_fused; 0 when only the bucket route is used), initialised ONCE with
+ *          kbe_frame_scratch_init;
  *          every kbe_render_frame call leaves it ready for the next one.
  *   frame_u8      [H,W,3]   out
  *   render_f32    [4,H,W]   optional: the filled float render (parity checks)
@@ -154,7 +156,7 @@ KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B,
  *   zee_f32       [H*W]     optional: the degridded z-buffer the accumulation tested against
  *   zee_pre_f32   [H*W]     optional: the z-buffer before degrid (bit-exact contract)
  * ------------------------------------------------------------------------------------- */
-KBE_API size_t kbe_frame_scratch_bytes(int W, int H);
+KBE_API size_t kbe_frame_scratch_bytes(int W, int H, int N);
 KBE_API int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream);
 
 KBE_API int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
@@ -199,8 +201,8 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
  * _ZBUF_A (render the last frame stand-alone instead).  kbe_render_video does all of this itself. */
 #define KBE_STAGE_ZBUF_A 128
 #define KBE_STAGE_ZBUF_B 256
-/* kbe_render_frame_fused with parity -1 only: do not zero the hole counter first (bench.py times the scatter launch
- * alone, back to back; the frames of such a run are not valid) */
+/* kbe_render_frame_fused with parity -1 only: do not zero the hole counters first (timing aid; the frames of such a run
+ * are not valid) */
 #define KBE_STAGE_KEEP_HOLE_COUNT 64
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
@@ -219,24 +221,27 @@ KBE_API int kbe_render_frame_group(const float* points, const float* image, cons
                                    const int* fill_rect, int raster_w, int raster_n, kbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * The same frame from the PACKED cloud, with the whole of render_pointcloud in ONE launch (the default route of the
- * Python host side).
+ * The same frame from the PACKED cloud: render_pointcloud as two launches with nothing but 12 bytes per point between them
+ * (the default route of the Python host side).
  *
  * kbe_cloud_pack, once per video after the set-up loop has grown the cloud: sorts the points by where they lie in
  * the cloud's own view (Morton order of 8 x 8-pixel cells for points projected with `focal` onto a W x H raster; any
  * order is correct, this one is fast; raster_w / raster_n: the layout hint of kbe_render_frame_stages, 0, 0 if unknown:
- * the first raster_n points then keep their own 8 x 8 cells), cuts them into blocks of 64, and builds over them a hierarchy of boxes that
- * bound where a block's points can land in any view.  `packed`: DEVICE buffer of kbe_cloud_pack_bytes(N) bytes,
+ * the first raster_n points then keep their own 8 x 8 cells), stores them as {x, y, z} and {r, g, b, depth} records, cuts
+ * them into blocks of 64 (sub-blocks of 16), and builds over the blocks a hierarchy of boxes that bound where a block's
+ * points can land in any view (only the slow paths use it).  `packed`: DEVICE buffer of kbe_cloud_pack_bytes(N) bytes,
  * 256-byte aligned, owned by the caller; the original three tensors are not needed afterwards.
  *
- * kbe_render_frame_fused: one frame.  `stages`: KBE_STAGE_TILES = the scatter (z-splat into an LDS z-tile, degrid,
- * z-tested gather, normalise, uint8 -- a tile pulls the points that can reach it through the box hierarchy; no
- * z-buffer, bucket or accumulator in HBM, no global atomic), KBE_STAGE_FILL (+ schedule flags) = the hole fill.
+ * kbe_render_frame_fused: one frame.  `stages`: KBE_STAGE_TILES = the scatter -- k_place: every point shifted and projected
+ * once, its {ox, oy, dblError} stored at its own index (the scratch set's last 12 N bytes), every sub-block listed for the
+ * one to four tiles its points reach; k_frame: a tile pulls the points of its list, z-splat into an LDS z-tile, degrid,
+ * z-tested gather, normalise, uint8 -- no z-buffer, bucket or accumulator in HBM, no per-point global atomic;
+ * KBE_STAGE_FILL (+ schedule flags) = the hole fill.
  * `cloud_focal` = the focal given to kbe_cloud_pack.  `parity`: the scratch holds two hole counters; consecutive
  * frames on one scratch alternate 0, 1, 0, ... (the fill of a frame zeroes the counter of the next), starting from
  * a scratch whose counters are zero (kbe_frame_scratch_init, or any frame rendered with parity -1); -1 = a frame on
- * its own: the counter is zeroed by a memset in front of the scatter.  Outputs, scratch and fill_rect as
- * kbe_render_frame_stages; results equal the bucket path's up to the order of the fp32 sums.
+ * its own: the counters are zeroed by a memset in front of the scatter.  Outputs, scratch (kbe_frame_scratch_bytes(W, H, N)
+ * bytes) and fill_rect as kbe_render_frame_stages; results equal the bucket path's up to the order of the fp32 sums.
  * ------------------------------------------------------------------------------------- */
 KBE_API size_t kbe_cloud_pack_bytes(int N);
 KBE_API int kbe_cloud_pack(const float* points, const float* image, const float* depth, int N, int W, int H, double focal,
@@ -245,6 +250,13 @@ KBE_API int kbe_render_frame_fused(const void* packed, int N, double cloud_focal
                                    const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32,
                                    float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages,
                                    const int* fill_rect, int parity, kbe_stream_t stream);
+
+/* ... and for a GROUP of 1..4 frames of the same packed cloud and size: the placement launch, the tile launch and the fill
+ * each take all the frames (as kbe_render_frame_group on the other route).  scratch [n]: one initialised scratch set per
+ * frame (kbe_frame_scratch_bytes(W, H, N) each); parities [n] (or NULL: all -1): as kbe_render_frame_fused, per scratch set. */
+KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
+                                         const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
+                                         const int* parities, int stages, const int* fill_rect, kbe_stream_t stream);
 
 /* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
  * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
@@ -278,12 +290,12 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  *   batch > 0: round 1's scheme, kept for comparison and for host memory the device cannot address: frames are
  *       staged on the device in two halves of `batch` frames and leave with one hipMemcpyAsync per half on
  *       copy_stream (NULL: on `stream`), cross-stream events per half.
- *   scratch: lanes * kbe_video_scratch_stride(W, H) bytes (n times that with KBE_VIDEO_FILL_GROUP(n)), each lane's part
+ *   scratch: lanes * kbe_video_scratch_stride(W, H, N) bytes (n times that with KBE_VIDEO_FILL_GROUP(n)), each lane's part
  *            initialised with kbe_frame_scratch_init;
  *   stage:   DEVICE buffer, 256-byte aligned, of kbe_video_stage_bytes(W, H, lanes, batch) bytes.
  * The call creates and destroys its HIP events. */
 #define KBE_MAX_LANES 8
-KBE_API size_t kbe_video_scratch_stride(int W, int H);
+KBE_API size_t kbe_video_scratch_stride(int W, int H, int N);
 KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 #define KBE_VIDEO_FILL_DIST 1        /* kbe_render_video flags: KBE_STAGE_FILL_DIST for every frame */
 /* batch <= 0: a lane renders n = 2..4 frames at a time, each into a scratch set of its own, and every launch of the bucket

@@ -20,11 +20,11 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
@@ -206,7 +206,7 @@ class HipKernels:
             key = (dev, W, H)
             scratch = self._tiled_scratch.get(key)
             if scratch is None:
-                scratch = torch.empty(int(self.lib.kbe_frame_scratch_bytes(_i(W), _i(H))), dtype=torch.uint8, device=dev)
+                scratch = torch.empty(int(self.lib.kbe_frame_scratch_bytes(_i(W), _i(H), _i(0))), dtype=torch.uint8, device=dev)
                 self._check(self.lib.kbe_frame_scratch_init(_ptr(scratch, torch.uint8), _i(W), _i(H), _stream()), 'kbe_frame_scratch_init')
                 self._tiled_scratch = {key: scratch}           # one size at a time (200 MB at 1024^2)
             render = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
@@ -256,7 +256,7 @@ class HipKernels:
         # one scratch per lane of the frame loop (render_video renders consecutive frames on `lanes` streams);
         # render_frame uses lane 0's
         lanes = max(1, min(MAX_LANES, int(os.environ.get('KBE_LANES', DEFAULT_LANES))))
-        stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H)))
+        stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H), _i(N)))
         state['lanes'] = lanes
         state['scratch'] = torch.empty(lanes * stride, dtype=torch.uint8, device=dev)
         for l in range(lanes):
@@ -286,11 +286,12 @@ class HipKernels:
                                                 _ptr(state['packed'], torch.uint8), _stream()), 'kbe_cloud_pack')
 
     def render_frame(self, state, shift3, focal, baseline, render_f32=None, existing_f32=None, zee_f32=None,
-                     zee_pre_f32=None, out=None, stages=7, fill_rect=None, fused=None):
+                     zee_pre_f32=None, out=None, stages=7, fill_rect=None, fused=None, parity=-1):
         """One frame of common.py:238-255 (shift -> render -> fill -> uint8) -> uint8 [H,W,3] on the device.
         fill_rect = (x0, y0, x1, y1): only holes inside are filled (see include/kbe.h).  ``fused`` (default: the
         state's route): the one-launch scatter on the packed cloud; False: the bucket path (k_project + k_tiles).
-        ``stages``: bit 1 = projection launch (bucket path only), 2 = scatter / tile launch, 4 = hole fill (+ flags)."""
+        ``stages``: bit 1 = projection launch (bucket path only), 2 = scatter / tile launch, 4 = hole fill (+ flags).
+        ``parity`` (fused route, include/kbe.h): -1 = a frame on its own; 0, 1, 0, ... for consecutive frames on one scratch."""
         frame = state['frame'] if out is None else out
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
         if state.get('fused') if fused is None else fused:
@@ -299,7 +300,7 @@ class HipKernels:
                                                         _i(state['W']), _i(state['H']), _d(float(focal)), _d(float(baseline)),
                                                         _shift(shift3), _ptr(state['scratch'], torch.uint8), _ptr(frame, torch.uint8),
                                                         _ptr(render_f32), _ptr(existing_f32), _ptr(zee_f32), _ptr(zee_pre_f32),
-                                                        _i(int(stages) & ~1), rect, _i(-1), _stream()), 'kbe_render_frame_fused')
+                                                        _i(int(stages) & ~1), rect, _i(int(parity)), _stream()), 'kbe_render_frame_fused')
             return frame
         self._check(self.lib.kbe_render_frame_stages(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']),
                                                      _i(state['N']), _i(state['W']), _i(state['H']), _d(float(focal)),
@@ -313,7 +314,7 @@ class HipKernels:
     def group_scratch(self, state, sets):
         """`sets` initialised scratch sets for launches that take several frames (kbe_render_frame_group, KBE_VIDEO_FILL_GROUP),
         allocated on first use: (tensor, stride in bytes)."""
-        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H'])))
+        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
         if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
             state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=state['points'].device)
             for l in range(sets):
@@ -335,6 +336,22 @@ class HipKernels:
         self._check(self.lib.kbe_render_frame_group(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']), _i(state['W']),
                                                     _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, zf, _i(int(stages)), rect,
                                                     _i(state['raster_w']), _i(state['raster_n']), _stream()), 'kbe_render_frame_group')
+        return out
+
+    def render_frame_group_fused(self, state, cameras, baseline, out, stages=6, parities=None, fill_rect=None):
+        """kbe_render_frame_group_fused: the same on the packed cloud (k_place + k_frame + fill, each taking all the frames)."""
+        n = len(cameras)
+        self._pack(state)
+        scratch, stride = self.group_scratch(state, max(n, 4))
+        focals = (ctypes.c_double * n)(*[float(c[0]) for c in cameras])
+        shifts = (ctypes.c_float * (3 * n))(*[float(v) for c in cameras for v in c[1]])
+        sets = (ctypes.c_void_p * n)(*[scratch.data_ptr() + k * stride for k in range(n)])
+        frames = (ctypes.c_void_p * n)(*[out[k].data_ptr() for k in range(n)])
+        par = None if parities is None else (ctypes.c_int * n)(*[int(v) for v in parities])
+        rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
+        self._check(self.lib.kbe_render_frame_group_fused(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']),
+                                                          _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, par, _i(int(stages)), rect,
+                                                          _stream()), 'kbe_render_frame_group_fused')
         return out
 
     def video_launch_shape(self, state, cameras, batch):

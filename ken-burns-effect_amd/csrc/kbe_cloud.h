@@ -7,7 +7,9 @@
 // once per video (it is resident for all frames):
 //   * points sorted by the Morton code of the 8 x 8-pixel cell they project to in the cloud's own view (the image
 //     raster for the image pixels, their own view for the appended ones), cut into BLOCKS of 64 consecutive points:
-//     a block is a spatially compact handful of neighbours, read with three coalesced 256-byte loads;
+//     a block is a spatially compact handful of neighbours -- for the image pixels one 8 x 8 cell of the raster, its four
+//     SUB-BLOCKS of 16 points the cell's 4 x 4 quadrants.  Positions {x, y, z} and {r, g, b, depth} are kept as two arrays
+//     of structures (12 + 16 bytes per point);
 //   * per block a NODE: a box that bounds where its points can land in ANY view -- {p = (x, y) * Fd / z, z} for
 //     ordinary points (the projection (p z + s Fd) F' / ((z + sz) Fd) is monotone in p and in z, so the four corners
 //     of the box bound it), and an {x, y, z} box for degenerate points (z < 1, masked points at the origin, points
@@ -23,6 +25,7 @@
 namespace kbe {
 
 constexpr int kCloudBlock = 64;         // points per block (one per lane)
+constexpr int kCloudSub = 16;           // points per SUB-BLOCK (a quarter of a block): the unit of a tile's candidate list (kbe_fused.hip)
 constexpr int kCloudFan = 32;           // children per node
 constexpr int kCloudTopMax = 64;        // nodes of the top level at most (one wave tests them in one go)
 constexpr int kCloudMaxLevels = 6;      // 64 * 32^5 blocks: far beyond the 2^30-point limit of the frame loop
@@ -35,10 +38,13 @@ struct CloudNode {                      // 64 bytes
 };
 static_assert(sizeof(CloudNode) == 64, "node size");
 
+struct CloudPoint { float x, y, z; };            // 12 bytes, tightly packed: streamed once per frame by the placement launch
+struct CloudColour { float r, g, b, depth; };   // 16 bytes: one 128-bit load per record in the tile launch
+static_assert(sizeof(CloudPoint) == 12 && sizeof(CloudColour) == 16, "packed point layout");
+
 struct PackedCloud {                    // passed to the kernels by value
-    const float* xyz;                   // [3][Np]
-    const float* rgb;                   // [3][Np]
-    const float* depth;                 // [Np]
+    const CloudPoint* pd;               // [Np]  position
+    const CloudColour* col;             // [Np]  colour and the depth channel (28 bytes per point in all: what the reference's tensors hold)
     int Np;                             // points incl. padding (a multiple of 64; padding has z = NaN and is culled)
     int n_levels;                       // level 0 = blocks
     int count[kCloudMaxLevels];
@@ -49,7 +55,7 @@ struct PackedCloud {                    // passed to the kernels by value
 struct CloudLayout {                    // byte offsets inside the caller's `packed` buffer, a pure function of N
     int Np, n_levels;
     int count[kCloudMaxLevels];
-    size_t xyz, rgb, depth, level[kCloudMaxLevels], keys_in, keys_out, idx_in, idx_out, sort_tmp, sort_tmp_bytes, total;
+    size_t pd, col, level[kCloudMaxLevels], keys_in, keys_out, idx_in, idx_out, sort_tmp, sort_tmp_bytes, total;
 };
 
 inline size_t cloud_align(size_t v) { return (v + 255) & ~(size_t) 255; }
@@ -69,9 +75,8 @@ inline CloudLayout cloud_layout_base(int N)
     }
     L.n_levels = lv + 1;
     size_t o = 0;
-    L.xyz = o;   o += cloud_align(3 * sizeof(float) * (size_t) L.Np);
-    L.rgb = o;   o += cloud_align(3 * sizeof(float) * (size_t) L.Np);
-    L.depth = o; o += cloud_align(sizeof(float) * (size_t) L.Np);
+    L.pd = o;    o += cloud_align(sizeof(CloudPoint) * (size_t) L.Np);
+    L.col = o;   o += cloud_align(sizeof(CloudColour) * (size_t) L.Np);
     for (int l = 0; l < L.n_levels; l++) { L.level[l] = o; o += cloud_align(sizeof(CloudNode) * (size_t) L.count[l]); }
     L.keys_in = o;  o += cloud_align(4 * (size_t) L.Np);
     L.keys_out = o; o += cloud_align(4 * (size_t) L.Np);
@@ -85,9 +90,8 @@ inline PackedCloud cloud_view(const void* packed, const CloudLayout& L, float fd
 {
     PackedCloud pc = {};
     const char* b = (const char*) packed;
-    pc.xyz = (const float*) (b + L.xyz);
-    pc.rgb = (const float*) (b + L.rgb);
-    pc.depth = (const float*) (b + L.depth);
+    pc.pd = (const CloudPoint*) (b + L.pd);
+    pc.col = (const CloudColour*) (b + L.col);
     pc.Np = L.Np;
     pc.n_levels = L.n_levels;
     for (int l = 0; l < L.n_levels; l++) { pc.count[l] = L.count[l]; pc.level[l] = (const CloudNode*) (b + L.level[l]); }

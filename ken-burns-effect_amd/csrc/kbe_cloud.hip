@@ -72,20 +72,24 @@ __global__ void __launch_bounds__(256) k_cloud_keys(const float* __restrict__ po
 
 __global__ void __launch_bounds__(256) k_cloud_gather(const float* __restrict__ points, const float* __restrict__ image,
                                                       const float* __restrict__ depth, int N, int Np, const uint32_t* __restrict__ order,
-                                                      float* __restrict__ xyz, float* __restrict__ rgb, float* __restrict__ dep)
+                                                      CloudPoint* __restrict__ pd, CloudColour* __restrict__ col)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Np) return;
     const uint32_t i = order[j];
     const bool real = i < (uint32_t) N;
-    const size_t n = (size_t) N, np = (size_t) Np;
-    xyz[j] = real ? points[i] : 0.0f;
-    xyz[np + j] = real ? points[n + i] : 0.0f;
-    xyz[2 * np + j] = real ? points[2 * n + i] : __builtin_nanf("");      // padding: z = NaN fails `z >= 0.001` (common.py:453)
-    rgb[j] = real ? image[i] : 0.0f;
-    rgb[np + j] = real ? image[n + i] : 0.0f;
-    rgb[2 * np + j] = real ? image[2 * n + i] : 0.0f;
-    dep[j] = real ? depth[i] : 0.0f;
+    const size_t n = (size_t) N;
+    CloudPoint p;
+    p.x = real ? points[i] : 0.0f;
+    p.y = real ? points[n + i] : 0.0f;
+    p.z = real ? points[2 * n + i] : __builtin_nanf("");         // padding: z = NaN fails `z >= 0.001` (common.py:453)
+    CloudColour c;
+    c.r = real ? image[i] : 0.0f;
+    c.g = real ? image[n + i] : 0.0f;
+    c.b = real ? image[2 * n + i] : 0.0f;
+    c.depth = real ? depth[i] : 0.0f;
+    pd[j] = p;
+    col[j] = c;
 }
 
 __device__ __forceinline__ void node_clear(CloudNode& n)
@@ -97,15 +101,15 @@ __device__ __forceinline__ void node_clear(CloudNode& n)
 }
 
 // level 0: one thread per block of 64 points (once per video: simplicity over speed)
-__global__ void __launch_bounds__(256) k_cloud_blocks(const float* __restrict__ xyz, int Np, float fd, CloudNode* __restrict__ nodes, int n_blocks)
+__global__ void __launch_bounds__(256) k_cloud_blocks(const CloudPoint* __restrict__ pd, float fd, CloudNode* __restrict__ nodes, int n_blocks)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     CloudNode n;
     node_clear(n);
     for (int k = 0; k < kCloudBlock; k++) {
-        const size_t j = (size_t) b * kCloudBlock + k;
-        const float x = xyz[j], y = xyz[(size_t) Np + j], z = xyz[2 * (size_t) Np + j];
+        const CloudPoint p = pd[(size_t) b * kCloudBlock + k];
+        const float x = p.x, y = p.y, z = p.z;
         float px = 0.0f, py = 0.0f;
         const int cls = classify(x, y, z, fd, px, py);
         if (cls == 1) {
@@ -183,9 +187,9 @@ int kbe_cloud_pack(const float* points, const float* image, const float* depth, 
     size_t tmp = L.sort_tmp_bytes;
     const hipError_t e = rocprim::radix_sort_pairs((void*) (b + L.sort_tmp), tmp, keys_in, keys_out, idx_in, idx_out, (size_t) L.Np, 0, 32, s);
     if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_cloud_pack: radix_sort_pairs", e);
-    hipLaunchKernelGGL(k_cloud_gather, dim3(grid), dim3(256), 0, s, points, image, depth, N, L.Np, idx_out, (float*) (b + L.xyz),
-                       (float*) (b + L.rgb), (float*) (b + L.depth));
-    hipLaunchKernelGGL(k_cloud_blocks, dim3(blocks_for((size_t) L.count[0])), dim3(256), 0, s, (const float*) (b + L.xyz), L.Np, (float) focal,
+    hipLaunchKernelGGL(k_cloud_gather, dim3(grid), dim3(256), 0, s, points, image, depth, N, L.Np, idx_out, (CloudPoint*) (b + L.pd),
+                       (CloudColour*) (b + L.col));
+    hipLaunchKernelGGL(k_cloud_blocks, dim3(blocks_for((size_t) L.count[0])), dim3(256), 0, s, (const CloudPoint*) (b + L.pd), (float) focal,
                        (CloudNode*) (b + L.level[0]), L.count[0]);
     for (int l = 1; l < L.n_levels; l++)
         hipLaunchKernelGGL(k_cloud_parents, dim3(blocks_for((size_t) L.count[l])), dim3(256), 0, s, (const CloudNode*) (b + L.level[l - 1]),

@@ -148,6 +148,20 @@ __device__ __forceinline__ int winner_corner(const Proj& p)
     return -1;
 }
 
+// The same for FINITE weights (every point project_xy lets through: |ox|, |oy| < 1e9), without branches: the first
+// corner whose weight is >= the other three is the first that attains their maximum -- an argmax that only a strictly
+// larger weight displaces.  (With a NaN among the weights the reference picks none; callers that cannot rule NaNs out
+// use winner_corner.)
+__device__ __forceinline__ int winner_corner_finite(const Proj& p)
+{
+    float best = p.w[0];
+    int k = 0;
+    if (p.w[1] > best) { best = p.w[1]; k = 1; }
+    if (p.w[2] > best) { best = p.w[2]; k = 2; }
+    if (p.w[3] > best) { k = 3; }
+    return k;
+}
+
 __device__ __forceinline__ bool inside(int x, int y, int W, int H)
 {
     return ((unsigned) x < (unsigned) W) & ((unsigned) y < (unsigned) H);      // two compares instead of four

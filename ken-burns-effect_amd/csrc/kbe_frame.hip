@@ -45,7 +45,7 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += stride) { zkeys[i] = KBE_ZKEY_EMPTY; if (zkeys_b) zkeys_b[i] = KBE_ZKEY_EMPTY; }
     for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
-    if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; }
+    if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; hole_count[2] = 0; hole_count[3] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -754,14 +754,14 @@ __global__ void __launch_bounds__(DELIVER_THREADS) k_deliver(const uint8_t* __re
 
 extern "C" {
 
-size_t kbe_frame_scratch_bytes(int W, int H)
+size_t kbe_frame_scratch_bytes(int W, int H, int N)
 {
-    return (W <= 0 || H <= 0) ? 0 : scratch_bytes(W, H);
+    return (W <= 0 || H <= 0 || N < 0) ? 0 : scratch_set_bytes(W, H, N);
 }
 
-size_t kbe_video_scratch_stride(int W, int H)
+size_t kbe_video_scratch_stride(int W, int H, int N)
 {
-    return (W <= 0 || H <= 0) ? 0 : ((scratch_bytes(W, H) + 255) & ~(size_t) 255);
+    return (W <= 0 || H <= 0 || N < 0) ? 0 : ((scratch_set_bytes(W, H, N) + 255) & ~(size_t) 255);
 }
 
 // stage = [lanes raw frames][lanes * fin finished frames][ring half 0: batch frames][ring half 1: batch frames][turn counter]
@@ -916,12 +916,14 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     int* const count_next = sc.hole_count + (parity == 1 ? 0 : 1);
     int rc = KBE_OK;
     if (parity < 0 && !(stages & KBE_STAGE_KEEP_HOLE_COUNT)) {
-        // a frame on its own: the caller keeps no frame parity, so the hole counter is zeroed in front of the launch
-        const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 2 * sizeof(int), s);
+        // a frame on its own: the caller keeps no frame parity, so the hole counters (and the binning launch's flags behind
+        // them) are zeroed in front of the launch
+        const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 4 * sizeof(int), s);
         if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_fused: hipMemsetAsync", e);
     }
     if (stages & KBE_STAGE_TILES) {
-        launch_frame_fused(s, (unsigned) n_tiles, packed, N, cloud_focal, cam, sc, count_now, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32);
+        const FusedTarget t = { cam, sc, scratch_place(scratch, W, H), parity, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32 };
+        launch_frames_fused(s, 1, packed, N, cloud_focal, &t);
         if ((rc = launched("kbe_render_frame_fused/scatter"))) return rc;
     }
     if (stages & KBE_STAGE_FILL) {
@@ -934,6 +936,44 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     return rc;
 }
 
+
+int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames, const double* focals,
+                                 const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* parities, int stages,
+                                 const int* fill_rect, kbe_stream_t stream)
+{
+    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FILL_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+                (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_fused: bad arguments");
+    static const FillDirs dirs = make_fill_dirs();
+    const hipStream_t s = (hipStream_t) stream;
+    FusedTarget ft[KBE_FILL_JOBS];
+    FillTarget targets[KBE_FILL_JOBS];
+    int n_tiles = 0, rc = KBE_OK;
+    for (int k = 0; k < n_frames; k++) {
+        KBE_REQUIRE(scratch[k] && frames_u8[k] && ((uintptr_t) scratch[k] & 15) == 0, "kbe_render_frame_group_fused: bad scratch / frame pointer");
+        for (int j = 0; j < k; j++) KBE_REQUIRE(scratch[j] != scratch[k], "kbe_render_frame_group_fused: the frames of a group need scratch sets of their own");
+        const int par = parities ? parities[k] : -1;
+        KBE_REQUIRE(par >= -1 && par <= 1, "kbe_render_frame_group_fused: parity is -1, 0 or 1");
+        const Scratch sc = carve(scratch[k], W, H);
+        n_tiles = sc.tiles_x * sc.tiles_y;
+        if (par < 0 && !(stages & KBE_STAGE_KEEP_HOLE_COUNT)) {
+            const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 4 * sizeof(int), s);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_fused: hipMemsetAsync", e);
+        }
+        ft[k] = FusedTarget{ make_camera(W, H, focals[k], baseline, shifts + 3 * (size_t) k), sc, scratch_place(scratch[k], W, H), par, frames_u8[k], nullptr, nullptr, nullptr, nullptr };
+        targets[k] = FillTarget{ sc, sc.hole_count + (par == 1 ? 1 : 0), frames_u8[k], nullptr, 0, par >= 0 ? sc.hole_count + (par == 1 ? 0 : 1) : nullptr };
+    }
+    if (stages & KBE_STAGE_TILES) {
+        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft);
+        if ((rc = launched("kbe_render_frame_group_fused/scatter"))) return rc;
+    }
+    if (stages & KBE_STAGE_FILL) {
+        FillRect rect = { 0, 0, W - 1, H - 1 };
+        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        launch_fill(s, n_frames, targets, W, H, stages, dirs, rect, n_tiles);
+        rc = launched("kbe_render_frame_group_fused/fill");
+    }
+    return rc;
+}
 
 int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
                                 double baseline, const float* shift3, void* scratch, float* render, float* existing,
@@ -974,7 +1014,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
     const hipStream_t cs = (hipStream_t) stream;
     const size_t fb = (size_t) W * H * 3;
-    const size_t sb = (scratch_bytes(W, H) + 255) & ~(size_t) 255;      // == kbe_frame_scratch_bytes rounded: lane stride
+    const size_t sb = (scratch_set_bytes(W, H, N) + 255) & ~(size_t) 255;      // == kbe_video_scratch_stride: lane stride
     const bool crop = crop_w > 0;
     // KBE_VIDEO_FILL_PAIRS (with _FILL_DIST; `scratch` then holds 2 * lanes sets): a lane renders TWO frames, each into a
     // scratch set of its own, and fills them in the same launches.  The table-driven fill is bound by its own chain of
@@ -1040,7 +1080,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     if (packed) {
         // every lane starts the call on hole counter 0: both of its counters are zeroed here, on `stream`, before the lanes start
         for (int l = 0; l < group * lanes; l++) {
-            const hipError_t e = hipMemsetAsync(carve((char*) scratch + (size_t) l * sb, W, H).hole_count, 0, 2 * sizeof(int), cs);
+            const hipError_t e = hipMemsetAsync(carve((char*) scratch + (size_t) l * sb, W, H).hole_count, 0, 4 * sizeof(int), cs);
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
         }
     }
@@ -1104,19 +1144,21 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             rc = render_jobs(points, image, depth, N, W, H, baseline, count, jobs, KBE_VIDEO_STAGES | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0),
                              crop ? rect : nullptr, raster_w, raster_n, ls[l]);
         } else {
-            // fused route: one k_frame per frame, the fill for the whole group
+            // fused route: the binning launch, the tile launch and the fill each take the whole group
             FillTarget targets[KBE_FILL_JOBS];
-            for (int j = 0; j < count && rc == KBE_OK; j++) {
+            FusedTarget ft[KBE_FILL_JOBS];
+            for (int j = 0; j < count; j++) {
                 const int i = idx[j], k = set_frames[l][j]++;
                 char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
                 raws[j] = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
                 uint8_t* const target = crop ? raws[j] : outs[j];
                 const Scratch sc = carve(scr, W, H);
-                rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i, scr, target, nullptr, nullptr,
-                                            nullptr, nullptr, KBE_STAGE_TILES, crop ? rect : nullptr, k & 1, (kbe_stream_t) ls[l]);
+                ft[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), sc, scratch_place(scr, W, H), k & 1, target, nullptr, nullptr, nullptr, nullptr };
                 targets[j] = FillTarget{ sc, sc.hole_count + (k & 1), target, nullptr, 0, sc.hole_count + ((k & 1) ^ 1) };
             }
-            if (rc != KBE_OK || count == 0) return rc;
+            if (count == 0) return rc;
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft);
+            if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };
             if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
             launch_fill(ls[l], count, targets, W, H, KBE_STAGE_FILL | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0), fill_dirs, fr,

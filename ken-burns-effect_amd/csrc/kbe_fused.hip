@@ -10,34 +10,57 @@ namespace kbe { PackedCloud cloud_open(const void* packed, int N, double focal);
 namespace {
 
 // ---------------------------------------------------------------------------------------
-// THE FUSED SCATTER: render_pointcloud (common.py:428-686) of one frame in ONE launch, from the packed cloud
-// (kbe_cloud.h).  No global z-buffer, no bucket records, no global atomic: a tile PULLS its points.
-//   cull     the tile walks the node hierarchy of the cloud (a node = a conservative box of where its points can land
-//            in this view) down to its candidate blocks of 64 points: ~20 of 18 k at 1024^2, 2-3 node tests per thread;
-//   splat    every candidate point is shifted (common.py:104-109) and projected (:447-468); a point whose north-west
-//            corner lies in the tile or within two pixels of it min-splats the key of its dblError into the tile's
-//            z-buffer IN LDS (tile + 1-pixel halo: one ds_min_u32 on the winner corner, :486-506), and a point whose
-//            corner can colour a tile pixel becomes a record {ox, oy, dblError, index} in LDS, threaded into the
-//            per-pixel lists at once;
-//   then     exactly k_tiles: degrid (:525-568) in LDS, colours by point index, z-tested gather in registers
-//            (:586-669), normalise (:686), hole mask (:253), uint8 (:255), coalesced stores.
+// THE FUSED SCATTER: render_pointcloud (common.py:428-686) of one frame from the packed cloud (kbe_cloud.h) in two
+// launches.  No global z-buffer, no bucket of records, no per-point atomic in HBM: a tile PULLS its points.
+//   k_place  one lane per point, in packed order: shift (common.py:104-109), projection (:447-468), dblError (:470); the
+//            point's PLACEMENT {ox, oy, dblError} is stored at the point's own index (12 bytes, perfectly coalesced -- no
+//            counter, no slot, no grouping of lanes by tile).  The 16 lanes of a SUB-BLOCK (a 4 x 4 quadrant of an 8 x 8
+//            source cell) then reduce the bounding box of their north-west corners with four DPP steps, and the sub-block's
+//            id is appended to the candidate list of every tile that box can reach: one or two tiles, rarely four, each
+//            lane of the sub-block taking one of them (~2 atomics per 16 points).
+//   k_frame  one workgroup per 32 x 16 target tile:
+//   splat    every point of the listed sub-blocks (~1.6 x the points that actually reach the tile) is fetched with its
+//            colours (a 96- and a 128-bit load); one whose north-west corner lies in the tile or within two pixels of it
+//            min-splats the key of its dblError into the tile's z-buffer IN LDS (tile + 1-pixel halo: one ds_min_u32 on
+//            the winner corner, :472-506), and one whose corner can colour a tile pixel becomes a record
+//            {ox, oy, dblError} + {r, g, b, depth} in LDS, threaded into the per-pixel lists at once;
+//   then     exactly k_tiles: degrid (:525-568) in LDS, z-tested gather in registers (:586-669), normalise (:686), hole
+//            mask (:253), uint8 (:255), coalesced stores.
 // A halo pixel's z is the minimum over the points whose WINNER corner it is; those have their north-west corner
-// within one more pixel, hence the two-pixel reach of the splat.  Neighbouring tiles project the blocks they share
-// again (~2.3 tiles per block of an 8 x 8 patch): arithmetic that replaces 16-byte records written to and read back
-// from HBM, the 4-byte z-buffer's atomics, its reset, and a kernel boundary.
-// More than REC_CAP records on a tile (piled-up points, a cloud denser than the raster): the z-buffer is finished
-// first, then the candidates are taken again in runs that fit (their record counts were noted on the first pass).
-// More candidate blocks than the LDS list holds (MAXC: > 32 k points on one tile): the tile scans block ranges
-// instead of a list, testing each block's node inline.  Slow paths, but any cloud renders correctly.
+// within one more pixel, hence the two-pixel reach of the splat.  Against the bucket route: every point is still projected
+// exactly once, but what crosses HBM between the two launches is 12 bytes per point written and read in place instead of
+// 16-byte records appended to per-tile buckets (with the counter atomics and the grouping of lanes that takes), the 4-byte
+// z-buffer's atomics, its read-back and its reset.
+// More than REC_CAP records on a tile (piled-up points, a cloud denser than the raster): the records beyond go to the
+// tile's spill area in HBM and are gathered in further rounds.  A list that overflows, sub-blocks whose points scatter
+// over the whole frame (an incoherent cloud), more spilled records than the spill area holds: the tile scans block ranges
+// of the cloud with inline node tests instead and takes its records in runs that fit.  Slow paths, but any cloud renders
+// correctly.
 // ---------------------------------------------------------------------------------------
-constexpr int MAXC = 256;                   // candidate blocks a tile lists in LDS at once
-constexpr int RING = 128;                   // a wave's ring of waiting points: at most 63 left over + 64 new
+constexpr int MAXC = TILE_THREADS;      // candidate blocks per window of the slow path (one per thread in its prefix scan)
+constexpr int LIST_CAP = KBE_CAND_CAP;      // sub-blocks a tile's candidate list holds (kbe_tiles.h: the scratch is sized by it)
+// A sub-block whose points reach more than BIN_WIDE_FAN tiles is "wide": it is still listed for every tile of its box, but
+// the frame keeps a running total of such entries, and once that exceeds BIN_WIDE_BUDGET entries per tile of the frame (an
+// incoherent cloud: every sub-block reaches every tile) the lists are abandoned and every tile scans the blocks itself.
+constexpr int BIN_WIDE_FAN = 64;
+constexpr int BIN_WIDE_BUDGET = 32;
+__device__ __forceinline__ unsigned bin_budget(int tiles_x, int tiles_y) { return (unsigned) BIN_WIDE_BUDGET * (unsigned) (tiles_x * tiles_y) + 4096u; }
 static_assert(MAXC == TILE_THREADS, "one candidate per thread in the prefix scan of the slow path");
+static_assert(LIST_CAP % TILE_THREADS == 0 && kCloudBlock % kCloudSub == 0 && kCloudSub == 16, "list geometry: a sub-block is one DPP row");
+
+struct Placement { float ox, oy, err; };     // 12 bytes per point and frame; ox = PLACE_NONE: the point touches no pixel
+static_assert(sizeof(Placement) == 12, "placement record");
+constexpr float PLACE_NONE = -1.0e9f;        // no image position is that large (project_xy drops |ox| >= 1e9)
 
 struct FrameArgs {
     PackedCloud pc;
     Camera cam;
     int tiles_x, tiles_y;
+    const Placement* place; // [Np]  this frame's placements (k_place)
+    int* tile_count;        // [n_tiles * CNT_STRIDE]: candidates listed per tile (k_place counts, k_frame zeroes its own)
+    const int* cand;        // [n_tiles][LIST_CAP]
+    const unsigned* bin_flag;       // this frame's total of wide list entries (k_place; beyond the budget the lists are not complete) ...
+    unsigned* bin_flag_next;        // ... and the next frame's, zeroed here
     uint8_t* frame;         // [H,W,3]
     float* depth;           // [H*W]
     uint32_t* mask;         // [H][ceil(W/32)]
@@ -52,19 +75,24 @@ struct FrameArgs {
     float4* spill;          // [n_tiles][BUCKET_STRIDE]: where a tile's records beyond REC_CAP wait for their round
 };
 
+struct PlaceArgs {
+    PackedCloud pc;
+    Camera cam;
+    int tiles_x, tiles_y;
+    Placement* place;
+    int* tile_count;
+    int* cand;
+    unsigned* bin_flag;     // running total of the wide sub-blocks' list entries (beyond the budget: the lists are abandoned)
+};
+
 struct FrameLds {
     TileLds T;
-    int list[2][MAXC];      // node ids of the level being expanded / the candidate blocks
-    int cnt[MAXC];          // records each candidate contributes (slow path: prefix sums)
-    int n_at[kCloudMaxLevels];      // survivors per level
-    int overflow;           // some level had more than MAXC survivors
     int n_ovf;              // records that did not fit the first round and went to the tile's spill area
-    int ring[TILE_THREADS / 64][RING];      // per wave: indices of the points waiting for the exact work
     int wave_sum[TILE_THREADS / 64];
     int run_end;
 };
 
-struct CullView {           // the view, as the node tests need it
+struct CullView {           // the view, as the node tests of the slow path need it
     float g, Sx, Sy;        // F' / Fd, shift_x * Fd, shift_y * Fd
     float focal, sx, sy, sz;
     float rx0, rx1, ry0, ry1;       // the tile's reach in (image position - principal point): [x0 - 2, x0 + TW + 1) etc.
@@ -112,156 +140,235 @@ __device__ __forceinline__ bool node_hits(const CloudNode& n, const CullView& q)
     return hit;
 }
 
-__device__ __forceinline__ float4 fetch_rgbd(const FrameArgs& a, int id)
-{
-#if defined(KBE_FRAME_STOP) && defined(KBE_FRAME_NO_RGBD)       // (dev) what do the colour loads cost?
-    return make_float4(0.5f, 0.25f, 0.125f, 700.0f + (float) (id & 1));
+#if defined(KBE_FRAME_STATS)     // dev build only (tools/frame_stats.py): what k_place and the tiles of k_frame did, summed over launches
+__device__ unsigned long long g_frame_stats[8];     // tiles, list entries written, candidate sub-blocks, points in z reach, records, slow tiles, spilling tiles, wide sub-blocks
 #endif
-    const uint32_t off = (uint32_t) id << 2;
-    const char* r = (const char*) a.pc.rgb;
-    const char* g = (const char*) (a.pc.rgb + (size_t) a.pc.Np);
-    const char* b = (const char*) (a.pc.rgb + 2 * (size_t) a.pc.Np);
-    const char* d = (const char*) a.pc.depth;
-    return make_float4(*(const float*) (r + off), *(const float*) (g + off), *(const float*) (b + off), *(const float*) (d + off));
+
+// ---------------------------------------------------------------------------------------
+// k_place: the placements and the candidate lists of one frame.  A point matters to tile (tx, ty) when its north-west
+// corner (nwx, nwy) lies in [tx TW - 2, tx TW + TW] x [ty TH - 2, ty TH + TH] (k_frame's z reach), i.e. for
+// tx = (nwx - 1) >> log2 TW .. (nwx + 2) >> log2 TW; a sub-block is listed for the tiles of the box of its points' corners.
+// Points that touch no pixel (behind the near plane, common.py:453; corner outside [-1, W - 1] x [-1, H - 1]) are marked and
+// take no part in the box.  The order of a list's entries is the order the atomics retire in: it only decides the order of
+// the fp32 sums, as the bucket order does on the other route.
+// ---------------------------------------------------------------------------------------
+constexpr int KBE_FRAME_JOBS = KBE_FILL_JOBS;
+struct PlaceJobs { PlaceArgs a[KBE_FRAME_JOBS]; };
+
+// minimum over the 16 lanes of a DPP row, left in every lane of the row: four v_min_i32 that read their second operand
+// through the DPP cross-lane path (the compiler's own rendering of the same steps is a copy, a DPP copy and a min each).
+// A DPP read needs two wait states behind the VALU write of its source; inline asm gets no hazard handling, hence the s_nop.
+__device__ __forceinline__ int row_min(int v)
+{
+    asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
+{
+    const PlaceArgs& a = jobs.a[blockIdx.y];
+    const Camera& cam = a.cam;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // Np is a multiple of 64: whole waves only
+    if (i >= a.pc.Np) return;
+    const int lane = threadIdx.x & 63;
+    const CloudPoint p = a.pc.pd[i];
+    float x = p.x, y = p.y, z = p.z, ox = 0.0f, oy = 0.0f;
+    apply_shift(cam, x, y, z);
+    bool ok = project_xy(cam, x, y, z, ox, oy);
+    const int nwx = (int) floorf(ox), nwy = (int) floorf(oy);
+    ok = ok && ((unsigned) (nwx + 1) <= (unsigned) cam.W) & ((unsigned) (nwy + 1) <= (unsigned) cam.H);      // a corner inside the image: -1 <= nw < size
+    Placement pl;
+    pl.ox = ok ? ox : PLACE_NONE;
+    pl.oy = ok ? oy : PLACE_NONE;
+    pl.err = project_err_fast(cam, ok ? z : 1024.0f);
+    a.place[i] = pl;
+
+    // the tiles the sub-block reaches: per lane the first and last tile its point matters to (monotone in the corner, so the
+    // minimum / maximum over the row are those of the box); lanes that are out take no part
+    static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "tile sizes are powers of two");
+    constexpr int BIG = 1 << 24;
+    const int tx0 = max(row_min(ok ? (nwx - 1) >> __builtin_ctz(TW) : BIG), 0), tx1 = min(-row_min(ok ? -((nwx + 2) >> __builtin_ctz(TW)) : BIG), a.tiles_x - 1);
+    const int ty0 = max(row_min(ok ? (nwy - 1) >> __builtin_ctz(TH) : BIG), 0), ty1 = min(-row_min(ok ? -((nwy + 2) >> __builtin_ctz(TH)) : BIG), a.tiles_y - 1);
+    const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;               // uniform over the row; no point in: tx0 = BIG, w < 0
+    const bool some = w > 0 && h > 0;
+    const int sub = i / kCloudSub, j = lane & (kCloudSub - 1);
+    auto list_for = [&](int tx, int ty) {
+        const int t = __mul24(ty, a.tiles_x) + tx;
+        const int pos = atomicAdd(&a.tile_count[(uint32_t) t * CNT_STRIDE], 1);
+        if (pos < LIST_CAP) a.cand[(size_t) t * LIST_CAP + pos] = sub;         // beyond: the tile sees count > LIST_CAP and scans
+    };
+    if (some && w <= 4 && h <= 4) {
+        // the usual box of one to four tiles (at most 4 x 4): lane j of the row takes tile (j & 3, j >> 2) of it -- one
+        // atomic per lane, no loop, no division
+#if defined(KBE_FRAME_STATS)
+        if (j == 0) atomicAdd(&g_frame_stats[1], (unsigned long long) (w * h));
+#endif
+        if ((j & 3) < w && (j >> 2) < h) list_for(tx0 + (j & 3), ty0 + (j >> 2));
+    } else if (some) {
+        // a larger box: its points scatter.  Beyond BIN_WIDE_FAN tiles it is counted against the frame's budget by the row's
+        // first lane (the look first keeps the total from running away once it is spent); beyond the budget the lists are
+        // abandoned: every tile scans the blocks itself (k_frame's ranged path).  (All 16 lanes of the row are here together.)
+        const int fan = w * h;
+        bool listing = true;
+        if (fan > BIN_WIDE_FAN) {
+            const unsigned budget = bin_budget(a.tiles_x, a.tiles_y);
+            int go = 0;
+            if (j == 0 && __hip_atomic_load(a.bin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= budget)
+                go = atomicAdd(a.bin_flag, (unsigned) fan) + (unsigned) fan <= budget;
+            listing = __shfl(go, lane & ~(kCloudSub - 1)) != 0;
+        }
+#if defined(KBE_FRAME_STATS)
+        if (j == 0 && listing) { atomicAdd(&g_frame_stats[1], (unsigned long long) fan); if (fan > BIN_WIDE_FAN) atomicAdd(&g_frame_stats[7], 1ull); }
+#endif
+        if (listing)
+            for (int k = j; k < fan; k += kCloudSub) { const int r = k / w; list_for(tx0 + (k - r * w), ty0 + r); }
+    }
 }
 
 // what a pass over candidate blocks does with each point
-enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4, PASS_SPILL = 8 };
+enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4, PASS_SPILL = 8, PASS_COLOUR = 16 };
 
-#if defined(KBE_FRAME_STATS)     // dev build only (tools/frame_stats.py): what the tiles of k_frame did, summed over launches
-__device__ unsigned long long g_frame_stats[8];     // tiles, top-level survivors, candidate blocks, points in z reach, records, slow tiles, ranged tiles
-#endif
 #if defined(KBE_FRAME_STOP)      // dev build only (tools/gpu_variant_pmc.sh): the kernel ends after stage KBE_FRAME_STOP, to cost the stages
 #define KBE_STOP_AFTER(n) do { if (KBE_FRAME_STOP == (n)) return; } while (0)
 #else
 #define KBE_STOP_AFTER(n) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k_frame(FrameArgs a)
+// a wave-uniform LDS fetch-and-add: one lane's ds_add_rtn_u32, the old value in a scalar for all
+__device__ __forceinline__ int lds_add_rtn_uniform(int* counter, int v)
+{
+    typedef __attribute__((address_space(3))) int* LdsPtr;
+    int old = 0;
+    if ((threadIdx.x & 63) == 0)
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"((uint32_t) (uintptr_t) (LdsPtr) counter), "v"(v) : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
+
+// what the shared tile machinery (tile_degrid, gather, tile_epilogue: kbe_tiles.h) reads of a frame's arguments
+struct TileOut {
+    struct { int W, H; } cam;
+    uint8_t* frame; float* depth; uint32_t* mask; int* holes; int* hole_count; int4* bbox; uint32_t* coarse;
+    float* render; float* existing; float* zee; float* zee_pre;
+};
+
+// The arguments are read through a pointer into the kernel-argument segment rather than taken by value: the kernel has three
+// phases with almost disjoint needs (splat: lists, placements, colours; resolve: the output planes; slow path: the cloud's
+// hierarchy and the whole camera), and held in registers all at once they overflow the scalar file -- the compiler then
+// parked sixteen of them in a vector register and fetched them back in every trip of the splat loop.  Making the pointer
+// opaque between the phases has each phase load what it needs when it starts.
+typedef const __attribute__((address_space(4))) FrameArgs* FrameArgsPtr;
+
+__device__ __forceinline__ void frame_body(FrameArgsPtr ap)
 {
     __shared__ FrameLds F;
     TileLds& L = F.T;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int tiles_x = ap->tiles_x, tiles_y = ap->tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
-    const int W = a.cam.W, H = a.cam.H;
-    const Camera& cam = a.cam;
-    const PackedCloud& pc = a.pc;
+    const int W = ap->cam.W, H = ap->cam.H;
     uint32_t* const zk = (uint32_t*) L.zpre;            // the tile's z-buffer as keys until the splat is complete
+    constexpr int WAVES = TILE_THREADS / 64;
 
-    CullView q;
-    q.g = cam.focal_f / pc.fd;
-    q.sx = cam.has_shift ? cam.sx : 0.0f; q.sy = cam.has_shift ? cam.sy : 0.0f; q.sz = cam.has_shift ? cam.sz : 0.0f;
-    q.Sx = q.sx * pc.fd; q.Sy = q.sy * pc.fd;
-    q.focal = cam.focal_f;
-    q.rx0 = (float) (x0 - 2) - cam.cx_f; q.rx1 = (float) (x0 + TW + 1) - cam.cx_f;
-    q.ry0 = (float) (y0 - 2) - cam.cy_f; q.ry1 = (float) (y0 + TH + 1) - cam.cy_f;
-
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
-    for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
-    if (tid < kCloudMaxLevels) F.n_at[tid] = 0;
-    if (tid == 0) {
-        L.nrec = 0;
-        F.overflow = 0;
-        F.n_ovf = 0;
-        lds_dummy_record(L);
-    }
-    __syncthreads();
-
-    // ---- cull: top level, then level by level down to the blocks
-    auto append = [&](int* list, int* counter, bool hit, int id) {
-        const unsigned long long m = __ballot(hit);
-        if (m) {                                                // wave-uniform
-            int base = 0;
-            const int leader = __ffsll((long long) m) - 1;
-            if (lane == leader) base = atomicAdd(counter, __popcll(m));
-            base = __builtin_amdgcn_readlane(base, leader);
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (hit) {
-                if (pos < MAXC) list[pos] = id;
-                else F.overflow = 1;
-            }
+    // The candidate list first (everything else waits for it).  A wave takes four sub-blocks per step -- sixteen lanes each, a
+    // lane one point -- and the steps go round the waves; the operands of FOUR steps are requested before the first is
+    // worked on (a tile has ~14 steps, a wave three or four of them: usually all its loads are in flight at once, and it
+    // waits for memory once instead of once per step -- with one step of look-ahead a step's ~100 instructions could not
+    // cover a round trip to L2 / HBM under load).  Every lane reads its own list entries from global memory, and reads them
+    // WITHOUT waiting for the count: entries past it are stale ids or whatever the scratch held, so they are clamped to the
+    // cloud and the count decides later which steps exist.  None of these loads sits under a branch: a load under a branch
+    // makes every later wait a wait for everything (kbe_frame.hip, k_tiles).
+    constexpr int DEPTH = 4, SUBS_PER_STEP = 64 / kCloudSub;
+    int* const tile_count = ap->tile_count;
+    const int count = tile_count[tile * CNT_STRIDE];
+    const bool wide = *ap->bin_flag > bin_budget(tiles_x, tiles_y);
+    const int* const my_list = ap->cand + (size_t) tile * LIST_CAP;
+    const Placement* const place = ap->place;
+    const CloudColour* const colours = ap->pc.col;
+    const uint32_t last_sub = (uint32_t) (ap->pc.Np / kCloudSub) - 1u;
+    float4* const spill = ap->spill + (size_t) tile * BUCKET_STRIDE;
+    Placement pl[DEPTH]; CloudColour cc[DEPTH]; int ix[DEPTH], ent[DEPTH];
+    auto fetch_entries = [&](int st0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[min((st0 + d * WAVES) * SUBS_PER_STEP + (lane >> 4), LIST_CAP - 1)];
+    };
+    auto fetch_points = [&]() {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            ix[d] = (int) (min((uint32_t) ent[d], last_sub) * kCloudSub) + (lane & (kCloudSub - 1));
+            pl[d] = place[ix[d]];
+            cc[d] = colours[ix[d]];
         }
     };
-    const int top = pc.n_levels - 1;
-    int cur = 0;
-    for (int n0 = 0; n0 < pc.count[top]; n0 += TILE_THREADS) {
-        const int n = n0 + tid;
-        const bool hit = n < pc.count[top] && node_hits(pc.level[top][n], q);
-        append(F.list[0], &F.n_at[top], hit, n);
+    fetch_entries(wave);
+    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+    for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
+    if (tid == 0) {
+        L.nrec = 0;
+        F.n_ovf = 0;
+        lds_dummy_record(L);
+        if (blockIdx.x == 0) *ap->bin_flag_next = 0;
     }
+    fetch_points();                                     // in flight across the barrier
+    const bool listed = !wide & (count <= LIST_CAP);            // uniform
     __syncthreads();
-    for (int lvl = top - 1; lvl >= 0 && !F.overflow; lvl--) {
-        const int items = min(F.n_at[lvl + 1], MAXC) * kCloudFan;
-        for (int it0 = 0; it0 < items; it0 += TILE_THREADS) {
-            const int it = it0 + tid;
-            int child = 0;
-            bool hit = false;
-            if (it < items) {
-                child = F.list[cur][it / kCloudFan] * kCloudFan + (it % kCloudFan);
-                hit = child < pc.count[lvl] && node_hits(pc.level[lvl][child], q);
-            }
-            append(F.list[cur ^ 1], &F.n_at[lvl], hit, child);
-        }
-        cur ^= 1;
-        __syncthreads();
-    }
-    KBE_STOP_AFTER(1);                                          // (dev) the cull
-    const bool ranged = F.overflow != 0;                        // uniform: scan block ranges instead of a list
-    const int n_blocks = pc.count[0];
-    const int* const cand = F.list[cur];
+    // (only now: every wave of the workgroup has its copy of the count)
+    if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
+    KBE_STOP_AFTER(1);                                          // (dev) the list
 
-    // ---- the exact work on one point per lane: shift (common.py:104-109), projection (:447-468), then by `flags`
-    // PASS_Z the min-splat of its dblError on the winner corner (:470-506), PASS_COUNT how many of the wave's points
-    // become records (noted for candidate `c`), PASS_INSERT its record threaded into the per-pixel lists while there
-    // is room (slots >= REC_CAP are dropped: the caller then knows from the total that the tile needs the slow path).
-    auto exact_point = [&](int flags, float x, float y, float z, bool valid, int idx, int c, float4* spill) {
-        float ox = 0.0f, oy = 0.0f;
-        apply_shift(cam, x, y, z);
-        const bool ok = project_xy(cam, x, y, z, ox, oy) && valid;
+    // ---- what a tile does with one placed point per lane {ox, oy, dblError}: by `flags` PASS_Z the min-splat of its dblError
+    // on the winner corner (:472-506), PASS_COUNT how many of the wave's points become records (noted for candidate `c`),
+    // PASS_INSERT its record threaded into the per-pixel lists while there is room (slots >= REC_CAP are dropped or, with
+    // PASS_SPILL, go to the tile's spill area), PASS_COLOUR: the record's colours are `col` (else: the point's index waits
+    // in their place until they are fetched).
+    // (slow path) records each candidate block of a window contributes, then their prefix sums: in the tile's spill area, which
+    // only the normal path's further rounds use -- 1 KB less LDS is what lets a fifth workgroup onto the CU
+    int* const slow_cnt = (int*) spill;
+    auto placed_point = [&](int flags, float ox, float oy, float err, bool ok, int idx, int c, const float4& col) {
         Proj p;
         p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
         const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
         // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
-        const bool in_z = ok && ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
+        const bool in_z = ok & ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
         // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
-        const bool in_r = in_z && ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &&
+        const bool in_r = ok & ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &
                           ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H);
-        float err = 0.0f;
 #if defined(KBE_FRAME_STATS)
         { const unsigned long long mz = __ballot(in_z); if (lane == 0 && (flags & PASS_Z)) atomicAdd(&g_frame_stats[3], (unsigned long long) __popcll(mz)); }
 #endif
-        if (in_z) {
-            err = project_err_fast(cam, z);
-            if (flags & PASS_Z) {
-                project_weights(ox, oy, p);
-                const int k = winner_corner(p);                                     // common.py:486-506
-                if (k >= 0) {
-                    const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-                    const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
-                    if (inside(cx, cy, W, H) && ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
-                        atomicMin(&zk[__mul24(ly, KW) + lx], zkey_encode(err));
-                }
-            }
+        if (in_z && (flags & PASS_Z)) {
+            project_weights(ox, oy, p);
+            const int k = winner_corner_finite(p);                                  // common.py:486-506 (ox, oy are finite)
+            const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
+            const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
+            // (byte offset from a 24-bit multiply-add: written on the element index the compiler folded the x 4 into a
+            // quarter-rate 32-bit multiply)
+            if (inside(cx, cy, W, H) & ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
+                atomicMin((uint32_t*) ((char*) zk + (__umul24((uint32_t) ly, KW * 4u) + ((uint32_t) lx << 2))), zkey_encode(err));
         }
         if (flags & (PASS_COUNT | PASS_INSERT)) {
             const unsigned long long m = __ballot(in_r);
             const int n_r = __popcll(m);
-            if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = n_r;
+            if ((flags & PASS_COUNT) && lane == 0) slow_cnt[c] = n_r;
             if ((flags & PASS_INSERT) && m) {                   // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&L.nrec, n_r);
-                base = __builtin_amdgcn_readfirstlane(base);
+                // ONE LDS atomic for the wave (written as the instruction: around `if (lane == 0) atomicAdd(..)` the compiler's
+                // atomic optimizer builds a dozen instructions of lane counting for a case that cannot occur here)
+                int base = lds_add_rtn_uniform(&L.nrec, n_r);
+                const int limit = REC_CAP;
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (in_r && slot < REC_CAP) {
-                    const int next = atomicExch(&L.head[__mul24(ry - 1, BW) + (rx - 1)], slot << 4);
+                if (in_r && slot < limit) {
+                    const int next = atomicExch((int*) ((char*) L.head + (__umul24((uint32_t) (ry - 1), BW * 4u) + ((uint32_t) (rx - 1) << 2))), slot << 4);
                     L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
-                    L.rgbd[slot].x = __int_as_float(idx);                           // the point, until its colours arrive
+                    if (flags & PASS_COLOUR) L.rgbd[slot] = col;
+                    else L.rgbd[slot].x = __int_as_float(idx);                      // the point, until its colours arrive
                 }
-                if ((flags & PASS_SPILL) && base + n_r > REC_CAP) {                 // wave-uniform; a few tiles in a hundred
-                    const bool sp = in_r && slot >= REC_CAP;
+                if ((flags & PASS_SPILL) && base + n_r > limit) {                   // wave-uniform; a few tiles in a hundred
+                    const bool sp = in_r && slot >= limit;
                     const unsigned long long ms = __ballot(sp);
                     int sbase = 0;
                     if (lane == 0) sbase = atomicAdd(&F.n_ovf, __popcll(ms));
@@ -273,37 +380,35 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         }
     };
 
-    constexpr int WAVES = TILE_THREADS / 64;
-    auto load_block = [&](int b, float& x, float& y, float& z) {
-        const uint32_t off = (uint32_t) ((b < 0 ? 0 : b) * kCloudBlock + lane) << 2;               // Np <= 2^30: 32-bit byte offsets
-        x = *(const float*) ((const char*) pc.xyz + off);
-        y = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
-        z = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
-    };
-
-    // ---- slow path only: one exact pass over candidates [c0, c1) of the window starting at block `wbase` (list mode:
-    // wbase unused).  A wave takes every fourth candidate; the coordinates of its next block are loaded before it
-    // works on the current one.
-    auto pass = [&](int flags, int c0, int c1, int wbase) {
-        auto block_of = [&](int c) -> int {                     // wave-uniform
-            if (c >= c1) return -1;
-            if (!ranged) return cand[c];
-            const int b = wbase + c;
-            return (b < n_blocks && node_hits(pc.level[0][b], q)) ? b : -1;
-        };
-        int c = c0 + wave;
-        int b_next = block_of(c);
-        float xn, yn, zn;
-        load_block(b_next, xn, yn, zn);
-        for (; c < c1; c += WAVES) {                            // wave-uniform
-            const int b = b_next;
-            const float x = xn, y = yn, z = zn;
-            b_next = block_of(c + WAVES);
-            load_block(b_next, xn, yn, zn);
-            if (b < 0) { if ((flags & PASS_COUNT) && lane == 0) F.cnt[c] = 0; continue; }
-            exact_point(flags, x, y, z, true, b * kCloudBlock + lane, c, nullptr);
+    // ---- the normal path: the points of the listed sub-blocks, their placements and colours requested above (a 96- and a
+    // 128-bit load per point).  About a third of the points are near misses that belong to a neighbouring tile: they cost
+    // a floor and a range test.  Records beyond REC_CAP (a few tiles in a hundred: two surfaces over one another at a depth
+    // edge) spill into the tile's own area of the scratch in HBM and are gathered in further rounds.  A tile with more
+    // than 64 candidate sub-blocks takes further trips of four steps per wave.
+    const int n_cand = listed ? count : 0;
+    {
+        const int n_steps = (n_cand + SUBS_PER_STEP - 1) / SUBS_PER_STEP;
+        for (int st0 = wave; st0 < n_steps; st0 += DEPTH * WAVES) {    // wave-uniform
+            const bool more = st0 + DEPTH * WAVES < n_steps;
+            if (more) fetch_entries(st0 + DEPTH * WAVES);       // the next trip's entries while this trip's points are worked on
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++)
+                if (st0 + d * WAVES < n_steps) {
+                    const bool valid = (st0 + d * WAVES) * SUBS_PER_STEP + (lane >> 4) < n_cand;
+                    placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
+                }
+            if (more) fetch_points();
         }
-    };
+    }
+    __syncthreads();
+    KBE_STOP_AFTER(3);                                          // (dev) + the splat
+
+    // ---- the second phase reads its arguments now
+    asm volatile("" : "+s"(ap) :: "memory");
+    TileOut a;
+    a.cam.W = W; a.cam.H = H;
+    a.frame = ap->frame; a.depth = ap->depth; a.mask = ap->mask; a.holes = ap->holes; a.hole_count = ap->hole_count; a.bbox = ap->bbox; a.coarse = ap->coarse;
+    a.render = ap->render; a.existing = ap->existing; a.zee = ap->zee; a.zee_pre = ap->zee_pre;
 
     constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
     constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
@@ -329,83 +434,26 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
         for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
         return (bool) __builtin_amdgcn_readfirstlane((int) fast);
     };
+    auto fetch_rgbd = [&](int id) {
+        const CloudColour c = colours[id];
+        return make_float4(c.r, c.g, c.b, c.depth);
+    };
 
     PixAcc acc[PIX_PER_THREAD];
 #pragma unroll
     for (int m = 0; m < PIX_PER_THREAD; m++) { acc[m].rg = (f2) (0.0f); acc[m].bd = (f2) (0.0f); acc[m].w = 0.0f; }
 
-    // ---- the normal path, a stream per wave with no workgroup barrier inside.  Every candidate point gets an
-    // APPROXIMATE position (one reciprocal, good to a thousandth of a pixel); two thirds of the candidates are near
-    // misses that belong to neighbouring tiles and end here, after ~20 instructions instead of ~130.  The points
-    // within a pixel of the tile's reach -- and every point nearer than z = 2, where process_shift's z / (z + 1e-7) is
-    // not exactly 1 and the approximation does not hold -- are pushed onto the wave's ring (their indices); whenever 64
-    // are waiting, the wave takes them off, reads their coordinates again (it has just read them: cache hits) and does
-    // the EXACT work with every lane busy: z-splat into the LDS z-tile, record into the per-pixel lists.  Records
-    // beyond REC_CAP (a few tiles in a hundred: two surfaces over one another at a depth edge) spill into the tile's
-    // own area of the scratch in HBM and are gathered in further rounds.
-    const int n_cand = ranged ? 0 : min(F.n_at[0], MAXC);
-    float4* const spill = a.spill + (size_t) tile * BUCKET_STRIDE;
-    if (!ranged) {
-        int* const ring = F.ring[wave];
-        int head = 0, tail = 0;                                 // wave-uniform
-        int c = wave;
-        int b_next = c < n_cand ? cand[c] : -1;
-        float xn, yn, zn;
-        load_block(b_next, xn, yn, zn);
-        const float wx = (float) (TW + 3) + 1.0f, wy = (float) (TH + 3) + 1.0f;
-        while (c < n_cand || tail > head) {                     // wave-uniform
-            if (c < n_cand) {
-                const int b = b_next;
-                const float x = xn, y = yn, z = zn;
-                c += WAVES;
-                b_next = c < n_cand ? cand[c] : -1;
-                load_block(b_next, xn, yn, zn);
-                const float zs = z + q.sz;
-                const float t = q.focal * __builtin_amdgcn_rcpf(zs);
-                const float ax = (x + q.sx) * t - q.rx0, ay = (y + q.sy) * t - q.ry0;      // position relative to the start of the reach
-                const bool take = (zs >= 0.0009f) && (!(z >= 2.0f) || ((ax >= -1.0f) & (ax < wx) & (ay >= -1.0f) & (ay < wy)));
-                const unsigned long long m = __ballot(take);
-                if (take) ring[(tail + __popcll(m & ((1ull << lane) - 1ull))) & (RING - 1)] = b * kCloudBlock + lane;
-                tail += __popcll(m);
-            }
-            if (tail - head >= 64 || (c >= n_cand && tail > head)) {
-                const int n = min(64, tail - head);
-                const bool valid = lane < n;
-                const int idx = valid ? ring[(head + lane) & (RING - 1)] : 0;
-                head += n;
-                const uint32_t off = (uint32_t) idx << 2;
-                const float x = *(const float*) ((const char*) pc.xyz + off);
-                const float y = *(const float*) ((const char*) (pc.xyz + (size_t) pc.Np) + off);
-                const float z = *(const float*) ((const char*) (pc.xyz + 2 * (size_t) pc.Np) + off);
-                exact_point(PASS_Z | PASS_INSERT | PASS_SPILL, x, y, valid ? z : 4.0f, valid, idx, 0, spill);
-            }
-        }
-    }
-    __syncthreads();
-    KBE_STOP_AFTER(3);                                          // (dev) + the stream
     const int total = L.nrec;
     bool fast;
     const int n_spill = F.n_ovf;
-    if (!ranged && n_spill <= BUCKET_CAP) {
-        // ---- the first REC_CAP records are in LDS.  Colours by point index now (in flight during the degrid)
-        const int n_first = min(total, REC_CAP);
-        float4 cc[PER];
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int i = tid + u * TILE_THREADS;
-            cc[u] = fetch_rgbd(a, i < n_first ? __float_as_int(L.rgbd[i].x) : 0);
-        }
+    if (listed && n_spill <= BUCKET_CAP) {
+        // ---- the first REC_CAP records are in LDS with their colours
         decode_z();
         __syncthreads();
         fast = tile_is_fast();
         tile_degrid(a, L, tid, x0, y0, fast);
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int i = tid + u * TILE_THREADS;
-            if (i < n_first) L.rgbd[i] = cc[u];
-        }
-        __syncthreads();
-        KBE_STOP_AFTER(4);                                      // (dev) + colours, degrid
+        __syncthreads();                                        // the epilogue stages its bytes where the degrid still reads its neighbours' z
+        KBE_STOP_AFTER(4);                                      // (dev) + degrid
         if (fast) gather<true>(a, L, tid, x0, y0, acc);
         else gather<false>(a, L, tid, x0, y0, acc);
         KBE_STOP_AFTER(5);                                      // (dev) + gather
@@ -414,7 +462,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             const int n = min(REC_CAP, n_spill - r0);
             __syncthreads();                                    // the previous gather is done with the lists
             for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
-            float4 rr[PER];
+            float4 rr[PER], cc[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const int i = tid + u * TILE_THREADS;
@@ -423,7 +471,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const int i = tid + u * TILE_THREADS;
-                cc[u] = fetch_rgbd(a, i < n ? __float_as_int(rr[u].w) : 0);
+                cc[u] = fetch_rgbd(i < n ? __float_as_int(rr[u].w) : 0);
             }
             __syncthreads();
 #pragma unroll
@@ -436,20 +484,61 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             else gather<false>(a, L, tid, x0, y0, acc);
         }
     } else {
-        // ---- the slow path, a small uniform state machine around ONE more copy of the pass: [ranged: the z-splat,
-        // window by window;] degrid; then per window [ranged: count,] prefix sums of the counts and runs of at most
-        // REC_CAP records: insert, colours, gather.
+        // ---- the slow path, a small uniform state machine around ONE copy of an exact pass over blocks: the tile scans ALL
+        // blocks of the cloud in windows of MAXC, each block's node tested inline: the z-splat, window by window (a tile
+        // that got here from its list does it again: min is idempotent); degrid; then per window the record counts, their
+        // prefix sums, and runs of at most REC_CAP records: insert, colours, gather.
+        const FrameArgs* const gp = (const FrameArgs*) ap;      // (struct copies want a generic pointer)
+        const Camera cam = gp->cam;
+        const PackedCloud pc = gp->pc;
+        const int n_blocks = pc.count[0];
+        CullView q;
+        q.g = cam.focal_f / pc.fd;
+        q.sx = cam.has_shift ? cam.sx : 0.0f; q.sy = cam.has_shift ? cam.sy : 0.0f; q.sz = cam.has_shift ? cam.sz : 0.0f;
+        q.Sx = q.sx * pc.fd; q.Sy = q.sy * pc.fd;
+        q.focal = cam.focal_f;
+        q.rx0 = (float) (x0 - 2) - cam.cx_f; q.rx1 = (float) (x0 + TW + 1) - cam.cx_f;
+        q.ry0 = (float) (y0 - 2) - cam.cy_f; q.ry1 = (float) (y0 + TH + 1) - cam.cy_f;
+        const float4 no_colour = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto load_block = [&](int b, float& x, float& y, float& z) {
+            const CloudPoint p = pc.pd[(b < 0 ? 0 : b) * kCloudBlock + lane];
+            x = p.x; y = p.y; z = p.z;
+        };
+        // one exact pass over candidates [c0, c1) of the window of 64-point blocks starting at block `wbase`: shift
+        // (common.py:104-109), projection (:447-468), dblError (:470), then as a placed point.  A wave takes every fourth
+        // candidate; the coordinates of its next block are loaded before it works on the current one.
+        auto pass = [&](int flags, int c0, int c1, int wbase) {
+            auto block_of = [&](int c) -> int {                 // wave-uniform
+                if (c >= c1) return -1;
+                const int b = wbase + c;
+                return (b < n_blocks && node_hits(pc.level[0][b], q)) ? b : -1;
+            };
+            int c = c0 + wave;
+            int b_next = block_of(c);
+            float xn, yn, zn;
+            load_block(b_next, xn, yn, zn);
+            for (; c < c1; c += WAVES) {                        // wave-uniform
+                const int b = b_next;
+                float x = xn, y = yn, z = zn;
+                b_next = block_of(c + WAVES);
+                load_block(b_next, xn, yn, zn);
+                if (b < 0) { if ((flags & PASS_COUNT) && lane == 0) slow_cnt[c] = 0; continue; }
+                float ox = 0.0f, oy = 0.0f;
+                apply_shift(cam, x, y, z);
+                const bool ok = project_xy(cam, x, y, z, ox, oy);
+                placed_point(flags, ox, oy, project_err_fast(cam, ok ? z : 1024.0f), ok, b * kCloudBlock + lane, c, no_colour);
+            }
+        };
         enum { S_ZWIN, S_DEGRID, S_COUNT, S_SCAN, S_RUN, S_DONE };
-        // (list mode gets here with a z-buffer that is complete only if phase B ran: it is simply done again, with the counts)
         int state = S_ZWIN, wb = 0, c0 = 0, done = 0;
 #if defined(KBE_FRAME_STOP) && defined(KBE_FRAME_SKIP_SLOW)      // (dev) what would the launch cost without its slow tiles?
         state = S_DONE;
 #endif
         fast = false;
         while (state != S_DONE) {                               // uniform
-            const int n_win = ranged ? min(MAXC, n_blocks - wb) : n_cand;
+            const int n_win = min(MAXC, n_blocks - wb);
             int flags = 0, p0 = 0, p1 = n_win;
-            if (state == S_ZWIN) flags = ranged ? PASS_Z : (PASS_Z | PASS_COUNT);
+            if (state == S_ZWIN) flags = PASS_Z;
             else if (state == S_COUNT) flags = PASS_COUNT;
             else if (state == S_RUN) {
                 for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
@@ -457,7 +546,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
                 __syncthreads();
                 // the run ends in front of the first candidate whose prefix sum exceeds done + REC_CAP
                 for (int c = c0 + tid; c < n_win; c += TILE_THREADS)
-                    if (F.cnt[c] - done > REC_CAP && (c == c0 || F.cnt[c - 1] - done <= REC_CAP)) F.run_end = c;
+                    if (slow_cnt[c] - done > REC_CAP && (c == c0 || slow_cnt[c - 1] - done <= REC_CAP)) F.run_end = c;
                 __syncthreads();
                 flags = PASS_INSERT; p0 = c0; p1 = F.run_end;
             }
@@ -465,40 +554,40 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
             __syncthreads();
             if (state == S_ZWIN) {
                 wb += MAXC;
-                if (!ranged || wb >= n_blocks) state = S_DEGRID;
+                if (wb >= n_blocks) state = S_DEGRID;
             } else if (state == S_DEGRID) {
                 decode_z();
                 __syncthreads();
                 fast = tile_is_fast();
                 tile_degrid(a, L, tid, x0, y0, fast);
                 wb = 0;
-                state = ranged ? S_COUNT : S_SCAN;
+                state = S_COUNT;
             } else if (state == S_COUNT) {
                 state = S_SCAN;
             } else if (state == S_SCAN) {
                 // inclusive prefix sums of the counts, one entry per thread
-                const int e = tid < n_win ? F.cnt[tid] : 0;
+                const int e = tid < n_win ? slow_cnt[tid] : 0;
                 int v = e;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
                 if (lane == 63) F.wave_sum[tid >> 6] = v;
                 __syncthreads();
                 for (int w = 0; w < (tid >> 6); w++) v += F.wave_sum[w];
-                if (tid < n_win) F.cnt[tid] = v;
+                if (tid < n_win) slow_cnt[tid] = v;
                 c0 = 0; done = 0;
                 state = n_win > 0 ? S_RUN : S_DONE;
-                if (state == S_DONE && ranged && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
+                if (state == S_DONE && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
             } else if (state == S_RUN) {
                 const int n = min(L.nrec, REC_CAP);
-                for (int i = tid; i < n; i += TILE_THREADS) L.rgbd[i] = fetch_rgbd(a, __float_as_int(L.rgbd[i].x));
+                for (int i = tid; i < n; i += TILE_THREADS) L.rgbd[i] = fetch_rgbd(__float_as_int(L.rgbd[i].x));
                 __syncthreads();
                 if (fast) gather<true>(a, L, tid, x0, y0, acc);
                 else gather<false>(a, L, tid, x0, y0, acc);
                 c0 = p1;
-                done = c0 > 0 ? F.cnt[c0 - 1] : 0;
+                done = c0 > 0 ? slow_cnt[c0 - 1] : 0;
                 if (c0 >= n_win) {
                     state = S_DONE;
-                    if (ranged && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
+                    if (wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
                 }
             }
             __syncthreads();
@@ -507,32 +596,67 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_TILE_ATTR)) k
 #if defined(KBE_FRAME_STATS)
     if (tid == 0) {
         atomicAdd(&g_frame_stats[0], 1ull);
-        atomicAdd(&g_frame_stats[1], (unsigned long long) F.n_at[top]);
         atomicAdd(&g_frame_stats[2], (unsigned long long) n_cand);
         atomicAdd(&g_frame_stats[4], (unsigned long long) total);
-        atomicAdd(&g_frame_stats[5], (unsigned long long) !(!ranged && n_spill <= BUCKET_CAP));
+        atomicAdd(&g_frame_stats[5], (unsigned long long) !(listed && n_spill <= BUCKET_CAP));
         atomicAdd(&g_frame_stats[6], (unsigned long long) (n_spill > 0));
-        atomicAdd(&g_frame_stats[7], (unsigned long long) n_spill);
     }
+#else
+    (void) total;
 #endif
     tile_epilogue(a, L, acc, tile, x0, y0);
 }
 
+struct FrameJobs { FrameArgs a[KBE_FRAME_JOBS]; };
+
+// five workgroups per CU (32 KB of LDS each; 96 registers per lane, a few of the gather's spilled): with the tile's list read
+// straight into registers the LDS allows it, and a fifth wave per SIMD covers more of the others' waits than the spills cost
+#ifndef KBE_FRAME_WAVES
+#define KBE_FRAME_WAVES 5
+#endif
+#define KBE_FRAME_ATTR amdgpu_waves_per_eu(KBE_FRAME_WAVES, KBE_FRAME_WAVES)
+
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame(FrameArgs)
+{
+    frame_body((FrameArgsPtr) __builtin_amdgcn_kernarg_segment_ptr());                          // the one argument, at offset 0
+}
+
+// several frames of the same cloud and size per launch (blockIdx.y = the frame), as the bucket route's grouped launches
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group(FrameJobs)
+{
+    frame_body((FrameArgsPtr) __builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y);
+}
 
 }  // namespace
 
 namespace kbe {
-void launch_frame_fused(hipStream_t s, unsigned n_tiles, const void* packed, int N, double cloud_focal, const Camera& cam, const Scratch& sc, int* hole_count,
-                        uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32, float* zee_pre_f32)
+// the scatter of n <= KBE_FILL_JOBS frames of the same packed cloud and frame size: one placement launch and one tile launch,
+// each taking all n frames (frame k: its camera, scratch set, placement array, and hole counter / list total pair by parity)
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t)
 {
-    FrameArgs a;
-    a.pc = cloud_open(packed, N, cloud_focal);
-    a.cam = cam;
-    a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y;
-    a.frame = frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = hole_count; a.bbox = sc.bbox; a.coarse = sc.coarse;
-    a.render = render_f32; a.existing = existing_f32; a.zee = zee_f32; a.zee_pre = zee_pre_f32; a.spill = sc.buckets;
-    hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, a);
+    PlaceJobs pj;
+    FrameJobs fj;
+    const PackedCloud pc = cloud_open(packed, N, cloud_focal);
+    unsigned n_tiles = 0;
+    for (int k = 0; k < KBE_FRAME_JOBS; k++) {
+        const FusedTarget& f = t[k < n ? k : 0];
+        const Scratch& sc = f.sc;
+        n_tiles = (unsigned) (sc.tiles_x * sc.tiles_y);
+        const int par = f.parity == 1 ? 1 : 0;
+        PlaceArgs& b = pj.a[k];
+        b.pc = pc; b.cam = f.cam; b.tiles_x = sc.tiles_x; b.tiles_y = sc.tiles_y; b.place = (Placement*) f.place; b.tile_count = sc.tile_count; b.cand = sc.cand;
+        b.bin_flag = (unsigned*) sc.hole_count + 2 + par;
+        FrameArgs& a = fj.a[k];
+        a.pc = pc; a.cam = f.cam; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y; a.place = (const Placement*) f.place;
+        a.tile_count = sc.tile_count; a.cand = sc.cand; a.bin_flag = (const unsigned*) sc.hole_count + 2 + par; a.bin_flag_next = (unsigned*) sc.hole_count + 2 + (par ^ 1);
+        a.frame = f.frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count + par; a.bbox = sc.bbox; a.coarse = sc.coarse;
+        a.render = f.render_f32; a.existing = f.existing_f32; a.zee = f.zee_f32; a.zee_pre = f.zee_pre_f32; a.spill = sc.buckets;
+    }
+    hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
+    if (n == 1) hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, fj.a[0]);
+    else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
+size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe
 
 #if defined(KBE_FRAME_STATS)

@@ -27,7 +27,7 @@ namespace kbe {
 #define KBE_TILE_THREADS 256
 #endif
 #ifndef KBE_TILE_CAP
-#define KBE_TILE_CAP 768
+#define KBE_TILE_CAP 736     // with 736 (and not 768) k_frame's workgroup stays under 30 KB of LDS: five of them fit a CU
 #endif
 #ifndef KBE_BUCKET_FACTOR
 #define KBE_BUCKET_FACTOR 12
@@ -47,6 +47,9 @@ constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's 
 #endif
 constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between two buckets: NOT a power-of-two multiple, or the
                                                     // live head of every bucket lands on the same few HBM channels
+#ifndef KBE_CAND_CAP
+#define KBE_CAND_CAP 512
+#endif
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
 static_assert(TW * TH % TILE_THREADS == 0 && TILE_THREADS % 64 == 0 && REC_CAP >= TILE_THREADS && TW % 32 == 0, "tile geometry");
@@ -58,12 +61,13 @@ struct Scratch {                            // carve-out of the caller's scratch
     float2* strips;         // [16][W + H + 8]  per fill direction and line across the image: where along it valid pixels can be (k_hole_dist)
     uint8_t* dist_blocks;   // [tiles_y * TH / 8][tiles_x * TW / 8]  the same distance between 8 x 8 blocks, in blocks
     int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
-    int* hole_count;        // [1]
+    int* hole_count;        // [4]  two hole counters (the fused route alternates them), then the fused route's two "a sub-block was too wide to list" words
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
     uint32_t* coarse;       // [n_tiles]: bit (cy * (TW/8) + cx) = the 8x8 block (cx, cy) of the tile holds a valid pixel
     int* holes;             // [H*W]
     float* depth;           // [H*W]  render[3] * (existing > 0): the fill compares the two ends of a ray with it
     uint32_t* mask;         // [H][ceil(W/32)]  bit = depth > 0: what the fill walks on (32x smaller than the plane)
+    int* cand;              // [n_tiles][KBE_CAND_CAP]  fused route: the sub-blocks of the packed cloud that can reach each tile (k_place)
     float4* buckets;        // [n_tiles][BUCKET_STRIDE]  {ox, oy, dblError, point index}
     int tiles_x, tiles_y;
 };
@@ -90,18 +94,24 @@ inline Scratch carve(void* base, int W, int H)
     s.dist = (uint8_t*) p;        p += align16(hw);
     s.strips = (float2*) p;       p += align16(8 * 16 * (size_t) (W + H + 8));
     s.dist_blocks = (uint8_t*) p; p += align16(n_tiles * (TW / 8) * (TH / 8));
+    s.cand = (int*) p;            p += align16(4 * n_tiles * KBE_CAND_CAP);
     s.buckets = (float4*) p;
     return s;
 }
 
+// the fixed part of a scratch set; a set used by the fused route is followed by its placement array (scratch_set_bytes)
 inline size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
-           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + align16(hw) + align16(8 * 16 * (size_t) (W + H + 8)) + align16(n_tiles * (TW / 8) * (TH / 8)) + n_tiles * BUCKET_STRIDE * sizeof(float4);
+           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + align16(hw) + align16(8 * 16 * (size_t) (W + H + 8)) + align16(n_tiles * (TW / 8) * (TH / 8)) + align16(4 * n_tiles * KBE_CAND_CAP) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
+
+size_t fused_place_bytes(int N);    // kbe_fused.hip: 12 bytes per packed point, a frame's placements {ox, oy, dblError}
+inline size_t scratch_set_bytes(int W, int H, int N) { return align16(scratch_bytes(W, H)) + (N >= 0 ? align16(fused_place_bytes(N)) : 0); }
+inline void* scratch_place(void* base, int W, int H) { return (char*) base + align16(scratch_bytes(W, H)); }
 
 struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are filled
 
@@ -130,9 +140,16 @@ struct FillJobs { FillJob j[KBE_FILL_JOBS]; };
 void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, int H, int stages, const FillDirs& dirs, const FillRect& rect, int n_tiles);
 // kbe_hip.hip: kbe_crop_resize_u8 for n <= 4 frames of the same size in one launch
 int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int crop_w, int crop_h, uint8_t* const* outs, hipStream_t stream);
-// kbe_fused.hip: the one-launch scatter of a frame from the packed cloud (k_frame)
-void launch_frame_fused(hipStream_t s, unsigned n_tiles, const void* packed, int N, double cloud_focal, const Camera& cam, const Scratch& sc, int* hole_count,
-                        uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32, float* zee_pre_f32);
+// kbe_fused.hip: the scatter of 1..KBE_FILL_JOBS frames from the packed cloud (k_bin + k_frame, each launch taking all the frames)
+struct FusedTarget {
+    Camera cam;
+    Scratch sc;
+    void* place;            // the scratch set's placement array (fused_place_bytes(N) bytes behind its fixed part)
+    int parity;             // which of the scratch set's hole counters / list totals the frame uses (-1 = 0)
+    uint8_t* frame_u8;
+    float* render_f32; float* existing_f32; float* zee_f32; float* zee_pre_f32;
+};
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* targets);
 
 // blockIdx -> tile id such that each XCD (block b runs on XCD b % 8) owns a contiguous band of
 // tile rows: the records of neighbouring tiles reference neighbouring points (shared L2 lines).

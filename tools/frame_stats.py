@@ -29,9 +29,9 @@ out = (ctypes.c_ulonglong * 8)()
 torch.cuda.synchronize()
 K.lib.kbe_debug_frame_stats(out, 1)
 for focal, shift3 in common.frame_cameras(settings, oc):
-    K.render_frame(state, shift3, focal, oc['dblBaseline'])
+    K.render_frame(state, shift3, focal, oc['dblBaseline'], fused=True)
     torch.cuda.synchronize()
     K.lib.kbe_debug_frame_stats(out, 1)
     t = max(1, out[0])
-    print('tiles %d: top-level survivors %.1f, candidate blocks %.1f (%.0f points), points in z reach %.0f, staged %.0f, records %.0f per tile; tiles on the slow path %d, with a second round %d'
-          % (out[0], out[1] / t, out[2] / t, 64.0 * out[2] / t, out[3] / t, out[7] / t, out[4] / t, out[5], out[6]))
+    print('tiles %d: list entries %.1f, candidate sub-blocks %.1f (%.0f points), points in z reach %.0f, records %.0f per tile; wide sub-blocks %d; tiles on the slow path %d, with a second round %d'
+          % (out[0], out[1] / t, out[2] / t, 16.0 * out[2] / t, out[3] / t, out[4] / t, out[7], out[5], out[6]))

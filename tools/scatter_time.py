@@ -43,3 +43,25 @@ if not state.get('fused') or os.environ.get('KBE_FUSED') == '0':
         e1.record()
         torch.cuda.synchronize()
         print('scatter with %d frame(s) per launch: %.2f us per frame' % (n, e0.elapsed_time(e1) * 1e3 / 40 / n))
+
+# the fused route's scatter (k_place + k_frame) with 1..4 frames per launch, alone on a stream, us per FRAME
+K._pack(state)
+focal, shift3 = cams[len(cams) // 2]
+out = torch.empty(4, size, size, 3, dtype=torch.uint8, device='cuda')
+for n in (1, 2, 3, 4):
+    group = [(focal, shift3)] * n
+    par = [0]
+
+    def run():
+        K.render_frame_group_fused(state, group, oc['dblBaseline'], out[:n], stages=2, parities=[par[0] & 1] * n)
+        par[0] += 1
+    run(); run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(40):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print('fused scatter with %d frame(s) per launch: %.2f us per frame' % (n, e0.elapsed_time(e1) * 1e3 / 40 / n))
+K.render_frame_group_fused(state, [(focal, shift3)] * 4, oc['dblBaseline'], out, stages=6)     # parity -1: leaves the sets' counters zeroed
