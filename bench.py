@@ -92,10 +92,24 @@ def measured_traffic():
         return {}, None
 
 
-GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group)
+def measured_instructions():
+    """Per-launch wave-level VALU instruction counts of the scatter kernels from the committed PMC pass (SQ_INSTS_VALU;
+    tools/gpu_pmc_scatter.sh -> profiles/r*_scatter_insts.json); {} when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_scatter_insts.json')))
+    if not files:
+        return {}, None
+    try:
+        return json.load(open(files[-1]))['kernels'], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return {}, None
 
 
-def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
+GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group / _fused)
+VALU_ISSUE_PER_US = 1024 * 2400.0 / 4.0     # wave-level VALU instructions the chip issues per us: 1024 SIMDs, one per 4 cycles each, 2.4 GHz
+
+
+def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
     launches between two events; the tile kernel is timed alone (back to back on a prepared scratch) --
@@ -119,8 +133,8 @@ def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     empty = (1, 1, 0, 0)
-    out = {'route': 'fused' if state.get('fused') else 'bucket'}
-    # the fused route: the scatter = k_bin + k_frame; back to back on the stream, consecutive frames alternating between the
+    out = {}
+    # the fused route: the scatter = k_place + k_frame; back to back on the stream, consecutive frames alternating between the
     # scratch's two hole counters as in a video (no fill here to zero them: the hole list is bounded, the frames not used)
     fpar = [0]
 
@@ -129,6 +143,16 @@ def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
         fpar[0] += 1
     out['fused:scatter'] = timed(fused_scatter)
     K.render_frame(state, shift3, focal, Bl, fused=True)       # a frame on its own zeroes the counters the run above left
+    # the same two launches (k_place, k_frame) taking `group_frames` frames each (kbe_render_frame_group_fused), per launch pair
+    fgroup_out = torch.empty(group_frames, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
+    gpar = [0]
+
+    def fused_grouped():
+        K.render_frame_group_fused(state, [(focal, shift3)] * group_frames, Bl, fgroup_out, stages=2, parities=[gpar[0] & 1] * group_frames)
+        gpar[0] += 1
+    out['fused:scatter_group'] = timed(fused_grouped)
+    K.render_frame_group_fused(state, [(focal, shift3)] * group_frames, Bl, fgroup_out, stages=6, fill_rect=empty)    # parity -1: leaves the sets' counters zeroed
+    del fgroup_out
     out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
     # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM.  In a video consecutive frames alternate
     # between two z-buffers and each tile launch clears the other one (stage flags 128 / 256), so the scatter is these two
@@ -167,7 +191,7 @@ def time_kernels(oc, cams, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
     out['bucket:tiles'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=2, **b))       # k_tiles alone on a prepared scratch
     K.render_frame(state, shift3, focal, Bl, stages=4, fill_rect=empty, **b)           # leave the scratch clean
     for k in ('scatter', 'scatter+fill'):
-        out[k] = out[out['route'] + ':' + k]
+        out[k] = out[route + ':' + k]
     out['fill'] = out['scatter+fill'] - out['scatter']
     frame = K.render_frame(state, shift3, focal, Bl)
     cw, ch = int(0.9 * W), int(0.9 * H)
@@ -411,47 +435,63 @@ def main():
     times_dev = times if args.device_only else timed(run_device)
     elapsed_dev = float(np.median(times_dev))
 
+    # the delivered frames against the frames left in HBM (two runs of the same cameras; the accumulation order may differ in the
+    # last bit): the first and the last frame of the pass, every value
+    frames_check = None
+    if host_out is not None:
+        worst = 0
+        for k in (0, args.steps // 2, args.steps - 1):
+            d = (host_out[k].to(torch.int16) - dev_out[k].cpu().to(torch.int16)).abs()
+            worst = max(worst, int(d.max()))
+            frames_check = max(frames_check or 0.0, float((d > 0).float().mean()))
+        frames_check = {'max_abs_diff': worst, 'worst_fraction_differing': frames_check, 'frames': [0, args.steps // 2, args.steps - 1],
+                        'ok': worst <= 1 and frames_check < 1e-3}
+        if not frames_check['ok']:
+            sys.stderr.write('bench.py: DELIVERED FRAMES DIFFER from the frames left in HBM: %s\n' % frames_check)
+
     if rank == 0:
         from ken_burns_effect_amd import _native
         lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
         host_lanes = _native.host_lanes(lanes, n_points, size, size, 3 * size * size)
-        # frames per launch in the timed region (small frames and videos that fill with the tables render several), and its route
+        # the route and the frames per launch of the timed region (_native.video_launch_shape: the fused route with four frames
+        # per launch where the frames are delivered to host memory; a zoom-out or a cloud denser than the raster: the bucket route)
         state = common._prepared_cloud(_native.kernels(), oc)
-        _, group_used = _native.kernels().video_launch_shape(state, cams, args.batch)
+        _, group_used, fused_used = _native.kernels().video_launch_shape(state, cams, args.batch, to_host=not args.device_only)
+        route = 'fused' if fused_used else 'bucket'
         group_frames = group_used if group_used > 1 else GROUP_FRAMES
-        kt = time_kernels(oc, cams, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames)
-        if kt['route'] == 'fused' and group_used > 1 and os.environ.get('KBE_FUSED') != '1':
-            kt['route'] = 'bucket'      # grouped videos take the bucket route (_native.render_video)
-            for k in ('scatter', 'scatter+fill'):
-                kt[k] = kt['bucket:' + k]
+        kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames)
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
-        # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch)
-        # over the HIP-event time of the launches that implement it, back to back alone on a stream -- for the route the
-        # timed region took at this size (bucket: k_project + k_tiles, the tile launch clearing the other frame's z-buffer;
-        # fused: k_frame), with the other route's figures beside it.
-        route = kt.pop('route')
+        # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch) per frame
+        # over the HIP-event time of the launches that implement it, back to back alone on a stream -- for the route and the
+        # number of frames per launch the timed region took (fused: k_place + k_frame; bucket: k_project + k_tiles, the tile
+        # launch clearing the other frame's z-buffer), with the one-frame launches and the other route beside it.
         scatter_bytes = 28 * n_points + 20 * HW
-        route_launches = {'fused': ['k_frame'], 'bucket': ['k_project', 'k_tiles']}
+        route_launches = {'fused': ['k_place', 'k_frame'], 'bucket': ['k_project', 'k_tiles']}
         # the committed PMC passes are of the default workload only
-        per_kernel, traffic_src = measured_traffic() if (size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1) else ({}, None)
+        default_workload = size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1
+        per_kernel, traffic_src = measured_traffic() if default_workload else ({}, None)
+        insts, insts_src = measured_instructions() if default_workload else ({}, None)
 
-        def roof(r):
-            t = kt[r + ':scatter']
-            tr = sum(per_kernel[k] for k in route_launches[r]) if all(k in per_kernel for k in route_launches[r]) else None
-            return {'kernel': ' + '.join(route_launches[r]), 'us': round(t * 1e6, 2), 'achieved': scatter_bytes / t / 1e9,
-                    'frac': scatter_bytes / t / 1e9 / HBM_PEAK_GBS, 'traffic': tr}
-        main, other = roof(route), roof('bucket' if route == 'fused' else 'fused')
-        tg = kt['bucket:scatter_group']
-        grouped = {'kernel': 'k_project_group + k_tiles_group', 'frames_per_launch': group_frames, 'us': round(tg * 1e6, 2), 'us_per_frame': round(tg * 1e6 / group_frames, 2),
-                   'algorithmic_bytes': group_frames * scatter_bytes, 'achieved': group_frames * scatter_bytes / tg / 1e9,
-                   'frac': group_frames * scatter_bytes / tg / 1e9 / HBM_PEAK_GBS,
-                   'note': 'the same launches taking %d frames each (kbe_render_frame_group; videos with KBE_VIDEO_FILL_GROUP): bytes of %d frames over one launch pair'
-                           % (group_frames, group_frames)}
-        frames_per_launch = 1
-        if route == 'bucket' and group_used > 1:
-            frames_per_launch = group_used
-            main = dict(main, kernel=grouped['kernel'], us=grouped['us'], achieved=grouped['achieved'], frac=grouped['frac'])
+        def roof(r, frames):
+            t = kt[r + (':scatter_group' if frames > 1 else ':scatter')]
+            names = route_launches[r]
+            tr = sum(per_kernel[k] for k in names) if all(k in per_kernel for k in names) else None
+            out = {'route': r, 'kernel': ' + '.join(n + ('_group' if frames > 1 and n != 'k_place' else '') for n in names), 'frames_per_launch': frames,
+                   'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / frames, 2), 'algorithmic_bytes': frames * scatter_bytes,
+                   'achieved': frames * scatter_bytes / t / 1e9, 'frac': frames * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
+                   'traffic': None if tr is None else frames * tr}
+            if all(k in insts for k in names):
+                # the other roofline these launches live under: wave-level VALU instructions per frame over the chip's issue rate
+                n_valu = sum(insts[k]['valu'] for k in names)
+                out['valu_issue'] = {'insts_per_frame': n_valu, 'us_at_peak': round(n_valu / VALU_ISSUE_PER_US, 2),
+                                     'frac': n_valu / VALU_ISSUE_PER_US / (t * 1e6 / frames)}
+            return out
+        frames_per_launch = group_used
+        main = roof(route, frames_per_launch)
+        single = roof(route, 1)
+        grouped = roof(route, group_frames)
+        other = roof('bucket' if route == 'fused' else 'fused', group_frames)
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
@@ -469,15 +509,18 @@ def main():
                             'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
             'roofline': {'bound': 'hbm', 'kernel': main['kernel'] + ' (the scatter = render_pointcloud, %s route)' % route,
                          'achieved': main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': main['frac'],
-                         'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': frames_per_launch * scatter_bytes,
-                         'frames_per_launch': frames_per_launch, 'grouped': grouped,
-                         'formula': '28 N + 20 HW (SURVEY.md 8d)', 'us': main['us'],
-                         'other_route': dict(other, route='bucket' if route == 'fused' else 'fused'),
-                         'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions); the matching rocprofv3 --stats '
-                                 'summary is the one taken with KBE_LANES=1 KBE_HOST_LANES=1 (profiles/): in the timed region the kernels of '
-                                 'several frames overlap and per-kernel durations stretch',
+                         'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': main['algorithmic_bytes'],
+                         'frames_per_launch': frames_per_launch, 'us': main['us'], 'us_per_frame': main['us_per_frame'],
+                         'formula': '28 N + 20 HW per frame (SURVEY.md 8d)',
+                         'valu_issue': main.get('valu_issue'), 'valu_issue_source': insts_src,
+                         'one_frame_per_launch': single, 'grouped': grouped, 'other_route': other,
+                         'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions), with the number of frames per '
+                                 'launch the timed region uses; the matching rocprofv3 --stats summary is profiles/*scatter_group*_kernel_stats.csv '
+                                 '(in the timed region the kernels of several lanes overlap and per-kernel durations stretch)',
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
+        if frames_check is not None:
+            line['frames_check'] = frames_check
         if not args.device_only:
             line['pcie'] = {'achieved': args.steps * size * size * 3 / elapsed / 1e9, 'unit': 'GB/s per GPU', 'peak': 63.0,
                             'note': 'uint8 frames of %.2f MB over PCIe Gen5 x16 (63 GB/s spec, ~57 measured with hipMemcpyAsync on an idle chip)'

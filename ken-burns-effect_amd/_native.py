@@ -27,7 +27,7 @@ SYMBOLS = (
 ABI_VERSION = 6
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
-FUSED_MAX_PIXELS = 640 * 640     # rasters up to this size take the one-launch scatter by default (KBE_FUSED=auto)
+FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
@@ -263,14 +263,17 @@ class HipKernels:
             self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
                         'kbe_frame_scratch_init')
         # Two routes for the scatter of a frame, same results (tests/test_hip_parity.py::test_fused_scatter_equals_the_bucket_path):
-        #   bucket  k_project -> k_tiles: every point projected once, 16-byte records through HBM; fewer instructions;
-        #   fused   k_frame on the packed cloud (kbe_cloud_pack, once per cloud): one launch, z-tile in LDS, no global
-        #           atomics, ~0.7x the algorithmic HBM bytes, but every point is projected by the ~2.3 tiles it may reach.
-        # Both are bound by instruction issue, so at 1024^2 and above the bucket route is 15-25 % faster (28.5 vs 39 us per
-        # frame); below ~640^2 a frame is bound by its launches and the fused route wins (512^2: 12.1 vs 16.7 us per frame).
-        # KBE_FUSED = auto (default) | 1 | 0.
+        #   fused   k_place -> k_frame on the packed cloud (kbe_cloud_pack, once per cloud): every point projected once, its
+        #           12-byte placement stored in place, a tile pulls the sub-blocks listed for it, z-tile in LDS; no per-point
+        #           global atomic, 1.4x the algorithmic HBM bytes;
+        #   bucket  k_project -> k_tiles: 16-byte records appended to per-tile buckets, z-buffer in HBM: 2.0x the bytes.
+        # Measured, us per frame left in HBM, bucket / fused: 1024^2 inpainted cloud 29.4 / 25.3, raw 37.4 / 35.5, 2048^2 raw
+        # 144 / 122, 512^2 9.3 / 9.1, 256^2 4.3 / 4.5 -- but clouds much denser than the raster pile more records on a tile
+        # than its LDS holds and the fused route's further rounds go through HBM: 2048^2 from 16.8 M points 375 / 403, and a
+        # dolly zoom-out (the image shrinks, the density grows along the video) 97 / 151.  KBE_FUSED = auto (default: fused
+        # unless the cloud has more than 1.5 points per pixel; render_video also looks at the camera path) | 1 | 0.
         mode = os.environ.get('KBE_FUSED', 'auto')
-        state['fused'] = (W * H <= FUSED_MAX_PIXELS) if mode == 'auto' else mode != '0'
+        state['fused'] = (N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode != '0'
         state['cloud_focal'] = float(focal) if focal else 512.0
         if state['fused']:
             self._pack(state)
@@ -354,33 +357,39 @@ class HipKernels:
                                                           _stream()), 'kbe_render_frame_group_fused')
         return out
 
-    def video_launch_shape(self, state, cameras, batch):
-        """(flags of kbe_render_video, frames per launch) for a video of `cameras`.
+    def video_launch_shape(self, state, cameras, batch, to_host=False):
+        """(flags of kbe_render_video, frames per launch, fused route?) for a video of `cameras`.
         KBE_VIDEO_FILL_DIST, the table-driven hole fill: for videos whose frames have hundreds of thousands of holes -- a
         cloud without appended points (no inpainting) seen by a camera that zooms out (a dolly zoom lowers the focal length:
         the image shrinks into an empty border).  Measured, us per frame without / with: dolly 300 / 129 at 1024^2, 77 / 63
         at 512^2 -- but a raw cloud on the ordinary camera path 35.2 / 37.8, 2048^2 139 / 151 (two more launches per frame
         that find few holes).  KBE_FILL_DIST=1 / 0 forces it on / off.
-        KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets, every launch taking all n.  Such videos are
-        bound by their lanes' chains of launches, not by the chip (dolly: 131 us per frame with n = 1, 111 / 106 / 102 with
-        2 / 3 / 4, 92 with the scatter launches grouped as well); the bench workload with four lanes is bound by the
-        chip and loses 3-7 % (28.9 -> 30.9 us), so there n = 1 unless KBE_FILL_GROUP says otherwise."""
+        KBE_VIDEO_FILL_GROUP(n): a lane renders n frames into n scratch sets, every launch taking all n.  A launch on its
+        own is bound by its ramp and its tail as much as by its work (the fused scatter of a 1024^2 frame: 35 us alone, 27 /
+        23 per frame with 2 / 4 frames per launch), so frames left in HBM take 27.5 / 25.3 / 26.7 us with n = 1 / 2 / 4 on
+        four lanes (the lanes fill the same gaps), and where the PCIe link binds (frames delivered to host memory: 59 us
+        per frame whatever n) n = 4 leaves the most of the chip idle.  Small frames are bound by their launches: 4 up to
+        576^2.  KBE_FILL_GROUP overrides.
+        The route: the state's (prepare_cloud), except that a camera that zooms out takes the bucket route (the density of
+        the points on the shrinking image grows along the video: 97 against 151 us per frame)."""
         W, H = state['W'], state['H']
         mode = os.environ.get('KBE_FILL_DIST', 'auto')
         zooms_out = len(cameras) > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
+        fused = bool(state.get('fused')) and (os.environ.get('KBE_FUSED') == '1' or not zooms_out)
         if os.environ.get('KBE_FILL_GROUP'):
             group = max(1, min(4, int(os.environ['KBE_FILL_GROUP'])))
         elif flags:
             group = DEFAULT_FILL_GROUP
+        elif fused:
+            group = 4 if (W * H <= 576 * 576 or to_host) else 2
         else:
-            # small frames are bound by their launches, not by the chip (measured, bucket route, us per frame with 1 / 2 / 4
-            # frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 / 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4,
-            # 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)
+            # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
+            # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)
             group = 4 if W * H <= 576 * 576 else (2 if W * H <= 900 * 900 else 1)
         if not (batch is None or batch <= 0):
             group = 1
-        return flags | ((group - 1) << 1), group
+        return flags | ((group - 1) << 1), group, fused
 
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
@@ -423,10 +432,9 @@ class HipKernels:
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
-        flags, group = self.video_launch_shape(state, cameras, batch)
-        # with several frames per launch the bucket route beats the one-launch route at every size (512^2: 8.6 vs 11.1 us per
-        # frame, 256^2: 6.2 vs 7.4): KBE_FUSED=auto then means the bucket route for a video (a frame on its own keeps k_frame)
-        fused = bool(state.get('fused')) and (group == 1 or os.environ.get('KBE_FUSED') == '1')
+        flags, group, fused = self.video_launch_shape(state, cameras, batch, to_host=not host_out.is_cuda)
+        if fused:
+            self._pack(state)
         # KBE_VIDEO_FREE_TRANSFERS: videos that fill with the tables are bound by their rendering (the link is half idle), and
         # a lane waiting for its turn on the link only idles: bench --dolly 8.1 k frames/s delivered with turns, 9.1 k without
         # (512^2 and 2048^2 frames, whose transfers fill the link to 70 %, keep the turns: 57 vs 53 k, 2.65 vs 2.03 k)

@@ -219,23 +219,31 @@ def test_host_lanes_two_where_the_link_binds_all_where_the_rendering_does(monkey
 
 def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     """_native.video_launch_shape: the table-driven fill for clouds without appended points seen by a camera that zooms out;
-    frames per launch by what binds the video (4 for such videos and for small frames, 2 up to 900^2, 1 for the bench's)."""
+    frames per launch by what binds the video; the scatter route (a zoom-out piles the points up: the bucket route)."""
     from ken_burns_effect_amd import _native
-    for k in ('KBE_FILL_DIST', 'KBE_FILL_GROUP'):
+    for k in ('KBE_FILL_DIST', 'KBE_FILL_GROUP', 'KBE_FUSED'):
         monkeypatch.delenv(k, raising=False)
     cls = [c for c in vars(_native).values() if isinstance(c, type) and hasattr(c, 'video_launch_shape')][0]
-    shape = lambda state, cams, batch=None: cls.video_launch_shape(None, state, cams, batch)       # noqa: E731
+    shape = lambda state, cams, batch=None, **kw: cls.video_launch_shape(None, state, cams, batch, **kw)       # noqa: E731
     still = [(512.0, (0.0, 0.0, 0.0))] * 8
     zoom = [(512.0 - 40.0 * i, (0.0, 0.0, -20.0 * i)) for i in range(8)]
-    inpainted = {'W': 1024, 'H': 1024, 'N': 1137109, 'cloud_focal': 512.0}
-    raw = {'W': 1024, 'H': 1024, 'N': 1048576, 'cloud_focal': 512.0}
-    assert shape(inpainted, still) == (0, 1) and shape(inpainted, zoom) == (0, 1)
-    assert shape(raw, still) == (0, 1)
-    assert shape(raw, zoom) == (1 | (3 << 1), 4)
-    assert shape(raw, zoom, batch=8) == (1, 1), 'the staged ring renders one frame per launch'
-    assert shape({'W': 512, 'H': 512, 'N': 300000, 'cloud_focal': 512.0}, still) == (3 << 1, 4)
-    assert shape({'W': 768, 'H': 768, 'N': 700000, 'cloud_focal': 512.0}, still) == (1 << 1, 2)
+    inpainted = {'W': 1024, 'H': 1024, 'N': 1137109, 'cloud_focal': 512.0, 'fused': True}
+    raw = {'W': 1024, 'H': 1024, 'N': 1048576, 'cloud_focal': 512.0, 'fused': True}
+    # the fused route: two frames per launch left in HBM, four where the link binds; a zoom-out takes the bucket route
+    assert shape(inpainted, still) == (1 << 1, 2, True) and shape(inpainted, still, to_host=True) == (3 << 1, 4, True)
+    assert shape(inpainted, zoom) == (0, 1, False)
+    assert shape(raw, still) == (1 << 1, 2, True)
+    assert shape(raw, zoom) == (1 | (3 << 1), 4, False)
+    assert shape(raw, zoom, batch=8) == (1, 1, False), 'the staged ring renders one frame per launch'
+    assert shape({'W': 512, 'H': 512, 'N': 300000, 'cloud_focal': 512.0, 'fused': True}, still) == (3 << 1, 4, True)
+    # the bucket route (a cloud denser than the raster: prepare_cloud leaves `fused` off)
+    dense = lambda size, n: {'W': size, 'H': size, 'N': n, 'cloud_focal': 512.0, 'fused': False}    # noqa: E731
+    assert shape(dense(1024, 4 << 20), still) == (0, 1, False)
+    assert shape(dense(512, 1 << 20), still) == (3 << 1, 4, False)
+    assert shape(dense(768, 2 << 20), still) == (1 << 1, 2, False)
     monkeypatch.setenv('KBE_FILL_GROUP', '3')
-    assert shape(inpainted, still) == (2 << 1, 3)
+    assert shape(inpainted, still) == (2 << 1, 3, True)
     monkeypatch.setenv('KBE_FILL_DIST', '0')
-    assert shape(raw, zoom) == (2 << 1, 3)
+    assert shape(raw, zoom) == (2 << 1, 3, False)
+    monkeypatch.setenv('KBE_FUSED', '1')
+    assert shape(raw, zoom) == (2 << 1, 3, True), 'KBE_FUSED=1 forces the route'
