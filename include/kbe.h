@@ -281,8 +281,8 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  * frame has landed and every lane is idle.
  * Hand-off to pinned (device-visible) host memory happens in the lanes' own streams (no copy stream, no event), the
  * lanes taking turns on the PCIe link (a bounded, advisory device-side wait), by `batch`:
- *   batch < 0: groups of G = -batch consecutive frames are rendered by one lane into its own G buffers and leave
- *       with ONE hipMemcpyAsync per group (the runtime's transfer engine).  The default of the Python host side:
+ *   batch < 0: groups of up to G = -batch consecutive frames (the first ones smaller: 1, 2, 4, ...; KBE_VIDEO_EVEN_GROUPS) are
+ *       rendered by one lane into its own G buffers and leave with ONE hipMemcpyAsync per group (the runtime's transfer engine).  The default of the Python host side:
  *       G = 16 on 2 lanes keeps the link busy back to back (58 us per 1024^2 frame, 54 GB/s of PCIe Gen5 x16; G = 8: 59 us).
  *   batch == 0: per frame, by a small copy kernel (k_deliver: 16 workgroups, 16-byte stores, throttled).
  *   batch <= 0 with host_out = DEVICE memory: every frame's last kernel stores straight into host_out[i]
@@ -308,6 +308,9 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 /* batch <= 0, frames to host memory: the lanes do not take turns on the PCIe link (for videos whose rendering binds, not the
  * link: a lane waiting for its turn would only idle) */
 #define KBE_VIDEO_FREE_TRANSFERS 8
+/* batch < 0: every transfer group has G = -batch frames.  Default: the groups ramp -- 1, 2, 4, ... frames up to G, then G -- so
+ * that the link starts after the first frame and a short video does not wait for G frames before its first byte moves. */
+#define KBE_VIDEO_EVEN_GROUPS 16
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

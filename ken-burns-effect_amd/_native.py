@@ -417,7 +417,9 @@ class HipKernels:
                     batch = int(env)
                 except ValueError:
                     raise KbeError('KBE_DELIVERY_BATCH=%r is not an integer (frames per transfer: < 0 groups per lane, > 0 staged ring)' % env)
-                batch = batch or -max(1, min(16, n // (4 * lanes)))
+                # groups of up to 16 frames per transfer (the first ones ramp 1, 2, 4, 8: include/kbe.h); a short video's groups stay
+                # small enough for each lane to have two of full size
+                batch = batch or -max(1, min(16, n // (2 * lanes)))
         # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
         batch = int(batch)
         batch = -min(-batch, max(n, 1), 64) if batch < 0 else min(batch, max(n, 1), 64)
@@ -441,6 +443,8 @@ class HipKernels:
         free = os.environ.get('KBE_FREE_TRANSFERS', 'auto')
         if not host_out.is_cuda and (free == '1' or (free == 'auto' and flags & 1)):
             flags |= 8
+        if os.environ.get('KBE_EVEN_GROUPS') == '1':        # (dev) transfer groups of one size instead of the ramp 1, 2, 4, ...
+            flags |= 16
         scratch = state['scratch']
         if group > 1:
             scratch, _ = self.group_scratch(state, group * state['lanes'])      # n * lanes sets, allocated on first use

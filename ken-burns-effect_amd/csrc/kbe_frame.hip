@@ -33,6 +33,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "kbe_cloud.h"
 #include "kbe_tiles.h"
 
@@ -46,6 +48,12 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
     for (size_t i = gtid; i < hw; i += stride) { zkeys[i] = KBE_ZKEY_EMPTY; if (zkeys_b) zkeys_b[i] = KBE_ZKEY_EMPTY; }
     for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
     if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; hole_count[2] = 0; hole_count[3] = 0; }
+}
+
+// the hole counters / list totals (4 ints) of `n` scratch sets `stride` bytes apart
+__global__ void k_zero_counters(int* first, size_t stride, int n)
+{
+    for (int k = threadIdx.x; k < 4 * n; k += blockDim.x) ((int*) ((char*) first + (size_t) (k >> 2) * stride))[k & 3] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1001,6 +1009,10 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
     return launched("kbe_render_pointcloud_tiled/reset");
 }
 
+#if defined(KBE_VIDEO_TRACE)
+#include <time.h>
+static double trace_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#endif
 constexpr int KBE_VIDEO_STAGES = KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL;
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
@@ -1030,6 +1042,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     hipStream_t ls[KBE_MAX_LANES], ds[1];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? cs : (hipStream_t) lane_streams[l];
     ds[0] = copy_stream ? (hipStream_t) copy_stream : cs;        // only the staged ring (batch > 0) uses it
+#if defined(KBE_VIDEO_TRACE)
+    const double t_call = trace_now();
+#endif
     const int fin = (int) stage_fin_per_lane(batch);                    // finished-frame buffers per lane
     const int slots = fin * lanes;
     uint8_t* const finished = stage + (size_t) KBE_FILL_JOBS * lanes * fb;
@@ -1078,11 +1093,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
     }
     if (packed) {
-        // every lane starts the call on hole counter 0: both of its counters are zeroed here, on `stream`, before the lanes start
-        for (int l = 0; l < group * lanes; l++) {
-            const hipError_t e = hipMemsetAsync(carve((char*) scratch + (size_t) l * sb, W, H).hole_count, 0, 4 * sizeof(int), cs);
-            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_video: hipMemsetAsync", e);
-        }
+        // every scratch set starts the call on hole counter 0: its counters (and list totals) are zeroed here, on `stream`, before
+        // the lanes start -- by ONE small launch for all sets (a memset per set was eight launches in front of a video's first frame)
+        hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, cs, carve(scratch, W, H).hole_count, sb, group * lanes);
+        if (int rc0 = launched("kbe_render_video/counters")) return rc0;
     }
     hipEvent_t start = lanes > 1 || (ringed && ds[0] != cs) ? make() : nullptr;
     // the other streams start once everything enqueued on `stream` so far (the cloud) is done
@@ -1094,9 +1108,24 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     // which lane renders frame i with one frame per launch (render() below): whole groups of G = -batch consecutive frames when
     // they are handed to pinned host memory per group, round-robin otherwise; a lane's frame count tells its LAST frame
     const bool by_groups = batch < 0 && host_dev != nullptr;
-    auto lane_of = [&](int i) { return by_groups ? (i / -batch) % lanes : i % lanes; };
+    // The transfer groups of the hand-off by groups: sizes 1, 2, 4, ... up to G = -batch, then G.  The link is idle until the
+    // first group has been rendered, and a transfer costs ~25 us whatever its size: a video of 20 frames in groups of 2 ran at
+    // 41 GB/s, in groups of 16 it would wait for 16 frames before the first byte moves.  Small groups first start the link
+    // after one frame; the groups double while it is busy.  Group g goes to lane g % lanes.
+    std::vector<int> group_start;                               // group_start[g] .. group_start[g + 1]: the frames of group g
+    if (by_groups) {
+        const int G = -batch;
+        for (int i0 = 0, size = (flags & KBE_VIDEO_EVEN_GROUPS) ? G : 1; i0 < n_frames; ) {
+            group_start.push_back(i0);
+            i0 += size < n_frames - i0 ? size : n_frames - i0;
+            size = size * 2 < G ? size * 2 : G;
+        }
+        group_start.push_back(n_frames);
+    }
+    const int n_groups = by_groups ? (int) group_start.size() - 1 : 0;
     int lane_frames[KBE_MAX_LANES] = {}, lane_total[KBE_MAX_LANES] = {};
-    for (int i = 0; i < n_frames; i++) lane_total[lane_of(i)]++;
+    if (by_groups) for (int g = 0; g < n_groups; g++) lane_total[g % lanes] += group_start[g + 1] - group_start[g];
+    else for (int i = 0; i < n_frames; i++) lane_total[i % lanes]++;
     auto render = [&](int i, int l, uint8_t* out) {
         uint8_t* raw = stage + (size_t) l * fb;
         const int fill_flags = lanes >= KBE_FILL_BY_COUNT_MIN_LANES ? (KBE_STAGE_FILL_BY_COUNT | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0)) : 0;
@@ -1220,14 +1249,17 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             const int turn_polls = (int) fmin(fmax(3.0 * lanes * group_us, (double) DELIVER_MAX_POLLS), 1.0e6);
             if (pairs) {                                                // the frames of every scratch set, counted first
                 counting = true;
-                for (int i0 = 0, g = 0; i0 < n_frames; i0 += G, g++) {
-                    const int l = g % lanes, nb = n_frames - i0 < G ? n_frames - i0 : G;
+                for (int g = 0; g < n_groups; g++) {
+                    const int l = g % lanes, nb = group_start[g + 1] - group_start[g];
                     for (int k = 0; k < nb; k += group) (void) render_group(l, nb - k < group ? nb - k : group, nullptr, nullptr);
                 }
                 counting = false;
             }
-            for (int i0 = 0, g = 0; i0 < n_frames && rc == KBE_OK; i0 += G, g++) {
-                const int l = g % lanes, nb = n_frames - i0 < G ? n_frames - i0 : G;
+            for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
+                const int l = g % lanes, i0 = group_start[g], nb = group_start[g + 1] - i0;
+#if defined(KBE_VIDEO_TRACE)
+                const double t_g = trace_now();
+#endif
                 uint8_t* base = finished + (size_t) l * fin * fb;
                 if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
                     int idx[KBE_FILL_JOBS], count = 0;
@@ -1237,11 +1269,24 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 }
                 else for (int k = 0; k < nb && rc == KBE_OK; k++) rc = render(i0 + k, l, base + (size_t) k * fb);
                 if (rc != KBE_OK) break;
+#if defined(KBE_VIDEO_TRACE)     // dev build only (tools/handoff_trace.py): where does the host spend the call?
+                const double t_r = trace_now();
+#endif
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls);
+#if defined(KBE_VIDEO_TRACE)
+                const double t_t = trace_now();
+#endif
                 const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
+#if defined(KBE_VIDEO_TRACE)
+                const double t_c = trace_now();
+#endif
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 1, 0);
                 rc = launched("kbe_render_video/turn");
+#if defined(KBE_VIDEO_TRACE)
+                fprintf(stderr, "group %3d lane %d frames %3d..%3d: t=%8.1f us  render-enqueue %7.1f  turn %6.1f  hipMemcpyAsync %7.1f  turn %6.1f\n", g, l, i0, i0 + nb - 1,
+                        (t_g - t_call) * 1e6, (t_r - t_g) * 1e6, (t_t - t_r) * 1e6, (t_c - t_t) * 1e6, (trace_now() - t_c) * 1e6);
+#endif
             }
         }
     } else {
