@@ -38,3 +38,23 @@ def assert_bits_equal(a, b, what=''):
     bad = int((bits(a) != bits(b)).sum())
     assert bad == 0, '%s: %d of %d elements differ bitwise (max abs %g)' % (
         what, bad, a.size, float(np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))))
+
+
+def at_size_scene(z, device, depth_to_points):
+    """(settings, objectCommon) of a tests/golden/kenburns_at_size_*.npz fixture: the inputs are regenerated from its seed."""
+    from ken_burns_effect_amd import synthetic
+    H, W, dolly = int(z['H']), int(z['W']), bool(z['dolly'])
+    image, disp = synthetic.make_rgbd(H, W, int(z['seed']), 'smooth')
+    depth = (512.0 * 120) / (disp + 1e-7)
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H, 'dblDispmin': disp.min().item(), 'dblDispmax': disp.max().item(),
+          'objectDepthrange': synthetic.depthrange_of(depth), 'tensorRawImage': image.to(device), 'tensorRawDisparity': disp.to(device),
+          'tensorRawDepth': depth.to(device)}
+    oc['tensorRawPoints'] = depth_to_points(oc['tensorRawDepth'], 512.0).view(1, 3, -1)
+    ofrom, oto = synthetic.default_windows(H, W, dolly)
+    settings = {'dblSteps': [float(s) for s in z['steps']], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly, 'boolCrop': False}
+    return settings, oc
+
+
+def psnr_u8(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 200.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)

@@ -522,6 +522,32 @@ def gen_kenburns():
         save('kenburns_' + tag, **arrays)
 
 
+def gen_kenburns_at_size():
+    """process_kenburns of the reference at 256 x 320 on a smooth scene (KBE path with two Inpaint passes, and a dolly zoom):
+    only the seed, the steps and the reference's pre-crop uint8 FRAMES are kept (the inputs are regenerated from the seed by
+    ken_burns_effect_amd.synthetic; the Inpaint weights from seeded_fill_).  What the product route -- Jacobi degrid, its own
+    accumulation order, its own MIOpen Inpaint -- delivers is measured against these frames (tests/test_hip_reference.py)."""
+    h = HARNESS
+    net = h.PI.Inpaint().eval()
+    synthetic.seeded_fill_(net, 3)
+    H, W = 256, 320
+    for tag, (seed, dolly, steps) in {'kbe': (61, False, [0.0, 0.35, 0.7, 1.0]), 'dolly': (62, True, [0.0, 0.4, 0.8])}.items():
+        image, disp = synthetic.make_rgbd(H, W, seed, 'smooth')
+        depth = (512.0 * 120) / (disp + 1e-7)
+        pts = h.C.depth_to_points(depth, 512.0)
+        common = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H,
+                  'dblDispmin': disp.min().item(), 'dblDispmax': disp.max().item(),
+                  'objectDepthrange': synthetic.depthrange_of(depth),
+                  'tensorRawPoints': pts.view(1, 3, -1), 'tensorRawImage': image,
+                  'tensorRawDisparity': disp, 'tensorRawDepth': depth}
+        ofrom, oto = synthetic.default_windows(H, W, dolly)
+        settings = {'dblSteps': steps, 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
+        with torch.no_grad():
+            frames, _ = h.traced(h.C.process_kenburns, settings, common, net)
+        save('kenburns_at_size_' + tag, frames=np.stack(frames), steps=np.array(steps, np.float64), dolly=np.bool_(dolly), seed=np.int64(seed),
+             H=np.int64(H), W=np.int64(W), n_points=np.int64(common['tensorInpaPoints'].shape[-1]))
+
+
 def gen_generate_mask():
     """generate_mask (common.py:689-830): per-point ownership mask of the z-splat, serial point order.
     Inputs are image rasters (N == H*W, the mask is viewed as an image for the median-5), batch 2, with
@@ -567,6 +593,6 @@ if __name__ == '__main__':
     HARNESS = Harness()
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)   # bit-stable conv results
-    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'disparity', 'generate_mask']
+    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'kenburns_at_size', 'disparity', 'generate_mask']
     for w in which:
         globals()['gen_' + w]()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_bits_equal, load_golden
+from conftest import assert_bits_equal, at_size_scene, load_golden, psnr_u8
 
 
 @pytest.fixture()
@@ -104,6 +104,43 @@ def test_jacobi_schedule_stays_close_to_serial(oracle, monkeypatch):
     # Both schedules are legal outcomes of the reference's racy in-place kernel (common.py:556-566).
     diff = np.mean([np.mean(f != g) for f, g in zip(frames, z['frames'])])
     assert 0.0 < diff < 0.25
+
+
+@pytest.mark.parametrize('tag', ['kbe', 'dolly'])
+def test_reference_frames_at_size_byte_for_byte_and_where_the_jacobi_schedule_moves_them(oracle, monkeypatch, tag):
+    """process_kenburns of the REFERENCE at 256 x 320 (kernel text executed serially; tests/golden/make_golden.py
+    gen_kenburns_at_size) against this package's host logic + its own Inpaint module + the oracle:
+      * serial degrid schedule: every frame byte for byte;
+      * Jacobi schedule (the product's: DESIGN.md section 2, deviation 1) on the SAME cloud: what it costs against those frames
+        on this scene, whose colours are white noise (any pixel that takes another source point moves by up to 255), and
+        WHERE -- only pixels whose degridded z differs between the schedules, and filled holes (a fill depends on validity
+        along its rays); nowhere else."""
+    from ken_burns_effect_amd import common as C, synthetic
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    z = load_golden('kenburns_at_size_' + tag)
+    H, W = int(z['H']), int(z['W'])
+    torch.set_num_threads(1)
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+    settings, oc = at_size_scene(z, 'cpu', oracle.depth_to_points)
+    net = synthetic.seeded_fill_(Inpaint(), 3).eval()
+    with torch.no_grad():
+        frames = C.process_kenburns(settings, oc, net)
+    assert oc['tensorInpaPoints'].shape[-1] == int(z['n_points'])
+    for i, (f, ref) in enumerate(zip(frames, z['frames'])):
+        assert np.array_equal(f, ref), 'frame %d under the serial schedule' % i
+    ks, kj = oracle.OracleKernels('serial'), oracle.OracleKernels('jacobi')
+    st = ks.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H)
+    for i, ((focal, sh), ref) in enumerate(zip(C.frame_cameras(settings, oc), z['frames'])):
+        fs, _, es = ks.render_frame(st, sh, focal, 120, want_float=True)
+        fj, _, ej = kj.render_frame(st, sh, focal, 120, want_float=True)
+        zp, _ = oracle.zsplat(oracle.shift_points(st['points'], torch.tensor(sh, dtype=torch.float32)), W, H, focal, 120)
+        dz = oracle.degrid(zp, 'serial')[0, 0].numpy().view(np.int32) != oracle.degrid(zp, 'jacobi')[0, 0].numpy().view(np.int32)
+        holes = (es[0, 0].numpy() <= 0) | (ej[0, 0].numpy() <= 0)
+        moved = np.abs(fs.numpy().astype(np.int32) - fj.numpy().astype(np.int32)).max(axis=2) > 0
+        assert np.array_equal(fs.numpy(), ref)
+        assert not (moved & ~dz & ~holes).any(), 'frame %d: a pixel moved that is neither a hole nor a pixel whose z the schedules degrid differently' % i
+        # measured: KBE 32.3-36.7 dB with 394-509 of 81 920 pixels moved; dolly 33.9-43.5 dB, 84-175 pixels
+        assert psnr_u8(fj.numpy(), ref) > 30.0 and moved.mean() < 0.01, 'frame %d: %.2f dB, %d pixels' % (i, psnr_u8(fj.numpy(), ref), int(moved.sum()))
 
 
 def test_crop_is_applied_by_default(common):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the round's profile artefacts, written under gpurun_out/$1 (copy what is to be judged into profiles/).
-#   gpurun --timeout 2400 -- 'bash tools/gpu_profile.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/gpu_profile.sh r03'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-prof}
@@ -18,11 +18,13 @@ rm -rf /tmp/ks1
 KBE_LANES=1 KBE_HOST_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks1 -o b --output-format csv -- python $R/bench.py --no-cpu-baseline 2>> $OUT/rocprof.err | tail -1 > $OUT/bench_lanes1_under_rocprof.json
 cp /tmp/ks1/b_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv
 python $R/tools/kernel_times.py /tmp/ks1/b_kernel_trace.csv > $OUT/bench_lanes1_kernel_medians.txt
-# 2c. the other scatter route (KBE_FUSED=1: one launch, packed cloud), one lane
+# 2c. the other scatter route (KBE_FUSED=0: k_project + k_tiles, buckets of records and the z-buffer in HBM), one lane
 rm -rf /tmp/ks2
-KBE_FUSED=1 KBE_LANES=1 KBE_HOST_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o b --output-format csv -- python $R/bench.py --no-cpu-baseline 2>> $OUT/rocprof.err | tail -1 > $OUT/bench_fused_lanes1_under_rocprof.json
-cp /tmp/ks2/b_kernel_stats.csv $OUT/bench_fused_lanes1_kernel_stats.csv
-KBE_FUSED=1 timeout 900 python $R/bench.py --no-cpu-baseline 2>> $OUT/bench.err | tail -1 > $OUT/bench_fused.json
+KBE_FUSED=0 KBE_LANES=1 KBE_HOST_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o b --output-format csv -- python $R/bench.py --no-cpu-baseline 2>> $OUT/rocprof.err | tail -1 > $OUT/bench_bucket_lanes1_under_rocprof.json
+cp /tmp/ks2/b_kernel_stats.csv $OUT/bench_bucket_lanes1_kernel_stats.csv
+KBE_FUSED=0 timeout 900 python $R/bench.py --no-cpu-baseline 2>> $OUT/bench.err | tail -1 > $OUT/bench_bucket.json
+# 2c'. short videos (the driver's --steps 20 / 75)
+for k in 20 75; do timeout 600 python $R/bench.py --no-cpu-baseline --steps $k --warmup 5 2>> $OUT/bench.err | tail -1 > $OUT/bench_steps$k.json; done
 # 2d. multi-rank code path on this one GPU (gloo; ranks share the device: a functional check, not a measurement)
 KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 32 --warmup 4 2>> $OUT/bench.err | tail -1 > $OUT/bench_2ranks_gloo_one_gpu.json
 # 3. HBM traffic: one PMC pass per counter (no trace domains alongside)
@@ -31,6 +33,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c -d /tmp/pm_$c -o c --output-format csv -- python $R/tools/pmc_traffic.py > $OUT/pmc_$c.log 2>&1
 done
 python $R/tools/pmc_report.py /tmp/pm_FETCH_SIZE/c_counter_collection.csv /tmp/pm_WRITE_SIZE/c_counter_collection.csv > $OUT/hbm_traffic.json
+# 3b. wave-level instruction counts of the scatter kernels, one frame per launch, both routes (the VALU-issue roofline of bench.py)
+for fused in 1 0; do
+  rm -rf /tmp/pi_$fused
+  KBE_FUSED=$fused KBE_LANES=1 KBE_FILL_GROUP=1 FRAMES=17 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/pi_$fused -o c --output-format csv -- python $R/tools/frame_once.py > $OUT/pmc_insts_$fused.log 2>&1
+done
+python $R/tools/pmc_insts.py /tmp/pi_1/c_counter_collection.csv /tmp/pi_0/c_counter_collection.csv > $OUT/scatter_insts.json
 # 4. other workloads (device-only and delivered), both routes where it matters
 (
 for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPSAMPLE=2 CLOUD=raw"; do
@@ -40,13 +48,13 @@ for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPS
   done
 done
 ) > $OUT/other_workloads.txt
-# 4b. the bucket route's launches with four frames each (kbe_render_frame_group), alone on a stream: rocprofv3 --stats of exactly those
+# 4b. both routes' scatter launches with 1..4 frames each, alone on a stream: rocprofv3 kernel trace of exactly those, by frames per launch
 rm -rf /tmp/kg
-KBE_FUSED=0 GROUP_ONLY=4 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kg -o b --output-format csv -- python $R/tools/scatter_time.py > $OUT/scatter_group4.txt 2>/dev/null
-if [ -f /tmp/kg/b_kernel_stats.csv ]; then cp /tmp/kg/b_kernel_stats.csv $OUT/scatter_group4_kernel_stats.csv; fi
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kg -o b --output-format csv -- python $R/tools/scatter_time.py > $OUT/scatter_group.txt 2>/dev/null
+if [ -f /tmp/kg/b_kernel_stats.csv ]; then cp /tmp/kg/b_kernel_stats.csv $OUT/scatter_group_kernel_stats.csv; python $R/tools/kernel_times_by_grid.py /tmp/kg/b_kernel_trace.csv k_place k_frame k_project k_tiles > $OUT/scatter_group_by_frames_per_launch.txt; fi
 # 5. the dolly zoom (frames with very many holes: the distance-table fill): per-kernel stats of its frame loop, and what the fill does
 rm -rf /tmp/kd
 DOLLY=1 REPS=2 FRAMES=128 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kd -o b --output-format csv -- python $R/tools/throughput.py > $OUT/dolly_under_rocprof.txt 2>/dev/null
 if [ -f /tmp/kd/b_kernel_stats.csv ]; then cp /tmp/kd/b_kernel_stats.csv $OUT/dolly_kernel_stats.csv; fi
 timeout 600 python $R/tools/fill_stats.py 2>/dev/null | grep "^holes" > $OUT/dolly_fill_stats.txt
-ls -la $OUT; cat $OUT/bench.json; grep -E 'k_tiles|k_project|k_frame|k_fill_holes|k_crop|copy|Copy' $OUT/bench_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv $OUT/bench_fused_lanes1_kernel_stats.csv | cut -c1-220; cat $OUT/hbm_traffic.json; cat $OUT/other_workloads.txt
+ls -la $OUT; cat $OUT/bench.json; grep -E 'k_tiles|k_project|k_place|k_frame|k_fill_holes|k_crop|copy|Copy' $OUT/bench_kernel_stats.csv $OUT/bench_lanes1_kernel_stats.csv $OUT/bench_bucket_lanes1_kernel_stats.csv | cut -c1-220; cat $OUT/hbm_traffic.json; cat $OUT/other_workloads.txt

@@ -8,6 +8,8 @@ bench workload.  tools/pmc_report.py turns the two counter CSVs into per-launch 
 import os
 import sys
 
+os.environ['KBE_FILL_GROUP'] = '1'      # one frame per launch: the per-launch byte counts are per frame
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

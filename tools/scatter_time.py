@@ -20,13 +20,13 @@ oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'in
 cams = common.frame_cameras(settings, oc)
 only = os.environ.get('GROUP_ONLY')          # e.g. 4: only the launches with that many frames each (a clean rocprofv3 --stats of them)
 if not only:
-    kt = bench.time_kernels(oc, cams)
+    kt = bench.time_kernels(oc, cams, 'fused')
     print(' '.join('%s=%.2f' % (k, v * 1e6) for k, v in kt.items() if k != 'route' and k.startswith(('bucket', 'fused'))))
 
 # the bucket route's scatter (k_project + k_tiles) with 1..4 frames per launch, alone on a stream, us per FRAME
 K = _native.kernels()
 state = common._prepared_cloud(K, oc)
-if not state.get('fused') or os.environ.get('KBE_FUSED') == '0':
+if True:
     focal, shift3 = cams[len(cams) // 2]
     out = torch.empty(4, size, size, 3, dtype=torch.uint8, device='cuda')
     for n in ((int(only),) if only else (1, 2, 3, 4)):
