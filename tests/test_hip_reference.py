@@ -144,8 +144,9 @@ def test_product_route_against_reference_run_frames_at_size(K, tag):
     with torch.no_grad():
         frames = common.process_kenburns(settings, oc, net)
     assert len(frames) == len(z['frames'])
-    # the grown cloud: MIOpen's last bits may flip the validity of a borderline pixel (|laplacian| < 0.03, common.py:70)
-    assert abs(oc['tensorInpaPoints'].shape[-1] - int(z['n_points'])) <= 0.002 * int(z['n_points'])
+    # the grown cloud: the set-up's forward warp degrids under the Jacobi schedule too, so its hole mask -- and with it the number
+    # of appended points -- differs slightly from the reference run's (measured: 89 321 against 89 622 points)
+    assert abs(oc['tensorInpaPoints'].shape[-1] - int(z['n_points'])) <= 0.01 * int(z['n_points'])
     for i, (f, ref) in enumerate(zip(frames, z['frames'])):
         moved = (np.abs(f.astype(np.int32) - ref.astype(np.int32)).max(axis=2) > 1).mean()
         db = psnr_u8(f, ref)

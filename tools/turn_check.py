@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""The hand-off's turn-taking under several processes' worth of hardware queues: WORLD_SIZE ranks (gloo) share GPU 0, each
+delivers passes of a video to its own pinned host memory on two lanes whose transfers take turns (k_turn: a bounded, advisory
+device-side wait).  Checks per rank: every pass delivers the bytes of the first, and no pass takes longer than twice the median
+(a wait that ran into its bound -- milliseconds -- in steady state would show as such a pass).
+    python -m torch.distributed.run --nproc-per-node 4 --master-addr 127.0.0.1 tools/turn_check.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('KBE_HOST_LANES', '2')
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from ken_burns_effect_amd import common, synthetic  # noqa: E402
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+size, n, passes = int(os.environ.get('SIZE', '512')), int(os.environ.get('FRAMES', '96')), int(os.environ.get('PASSES', '12'))
+image, disp = synthetic.make_rgbd(size, size, 4 + rank)
+depth = (synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)
+K = common._K()
+oc = {'dblFocal': synthetic.FOCAL, 'dblBaseline': synthetic.BASELINE, 'intWidth': size, 'intHeight': size, 'objectDepthrange': synthetic.depthrange_of(depth),
+      'tensorRawImage': image.to(dev), 'tensorRawDisparity': disp.to(dev), 'tensorRawDepth': depth.to(dev)}
+oc['tensorRawPoints'] = K.depth_to_points(oc['tensorRawDepth'], synthetic.FOCAL).view(1, 3, -1)
+common._reset_inpa(oc)
+ofrom, oto = synthetic.default_windows(size, size, False)
+settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': False, 'dolly': False}
+cams = common.frame_cameras(settings, oc)
+crop = common.crop_size(settings)
+out = torch.zeros(n, size, size, 3, dtype=torch.uint8, pin_memory=True)
+common.render_frames(cams, oc, crop, host_out=out)
+torch.cuda.synchronize()
+first = out.clone()
+times = []
+for k in range(passes + 1):         # the first pass after the ranks have met is not timed: they reach it out of step
+    dist.barrier()
+    out.zero_()
+    t0 = time.perf_counter()
+    common.render_frames(cams, oc, crop, host_out=out)
+    torch.cuda.synchronize()
+    if k > 0:
+        times.append(time.perf_counter() - t0)
+    d = (out.to(torch.int16) - first.to(torch.int16)).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, 'rank %d: a pass delivered other frames' % rank
+med = float(np.median(times))
+worst = torch.tensor([max(times) / med])
+dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+print('rank %d: passes of %d frames: median %.2f ms, max %.2f ms (%.2fx): %s' % (rank, n, med * 1e3, max(times) * 1e3, max(times) / med, ' '.join('%.1f' % (t * 1e3) for t in times)), flush=True)
+dist.barrier()
+if rank == 0:
+    assert float(worst) <= 2.0, 'a pass took %.2fx the median' % float(worst)
+    print('OK (%d ranks on one GPU, worst pass %.2fx its rank\'s median)' % (world, float(worst)))
+dist.destroy_process_group()
