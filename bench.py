@@ -252,6 +252,119 @@ def cpu_baseline(oc, cams, crop, budget_s=20.0):
     return out
 
 
+def pipeline_bench(args, device):
+    """`bench.py --pipeline`: BASELINE.json configs[1] as ONE number -- a 512 x 512 image through the whole Pipeline
+    (/root/reference/utils/pipeline.py:59-116: resize, Semantics + Disparity + Refine, point cloud, two inpaint passes, 64 frames
+    delivered to host memory), networks with seeded random weights (checkpoints are a network download) -- and SURVEY.md 8d's
+    "4b": the partial-convolution Inpaint forward at 1024^2 with PartialConv2d's mask bookkeeping fused into one HIP pass
+    (partial_conv.py) against the reference's formulation (a second convolution on the mask + five element-wise passes,
+    /root/reference/utils/partial_conv.py:62-77).  Prints one JSON line."""
+    import warnings
+
+    import torch.nn.functional as F
+    from torch.utils.flop_counter import FlopCounterMode
+
+    from ken_burns_effect_amd import common, kbe, partial_conv, synthetic
+    from ken_burns_effect_amd.partial_inpainting import Inpaint as PartialInpaint
+    from ken_burns_effect_amd.pipeline import Pipeline
+    size = args.size if args.size != 1024 else 512
+    frames_per_video = 64
+    K, Wm = max(1, min(args.steps, 50)), max(1, min(args.warmup, 5))
+    image, _ = synthetic.make_rgbd(size, size, 9)
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True           # MIOpen's find step with a workspace (the default immediate mode gets none and falls back)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipe = Pipeline(model_paths=None, device=str(device), steps=frames_per_video)
+    zoom = kbe.windows_for(size, size, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    call_s, call_ts = timed(lambda: pipe(image, zoom), K, Wm)
+    # where the call's time goes: its three parts on their own (each synchronised: their sum exceeds the call by the overlap it loses)
+    oc = pipe.objectCommon
+    est_s, _ = timed(lambda: pipe.estimate(image), 5, 1)
+    settings = {'dblSteps': np.linspace(0.0, 1.0, frames_per_video).tolist(), 'objectFrom': zoom['objectFrom'], 'objectTo': zoom['objectTo'], 'boolInpaint': True, 'dolly': False}
+
+    def grow():
+        common._reset_inpa(oc)
+        with torch.no_grad():
+            common.build_pointcloud(settings, oc, pipe.moduleInpaint)
+    grow_s, _ = timed(grow, 5, 1)
+    cams = common.frame_cameras(settings, oc)
+    crop = common.crop_size(settings)
+    host = torch.zeros(frames_per_video, size, size, 3, dtype=torch.uint8, pin_memory=True)
+    loop_s, _ = timed(lambda: common.render_frames(cams, oc, crop, host_out=host), 10, 2)
+
+    # 4b: the partial-convolution Inpaint forward at 1024^2, fused epilogue against the reference's formulation
+    def reference_forward(self, input, mask_in=None):
+        fresh = mask_in is not None or self.last_size != tuple(input.shape)
+        if fresh:
+            self.last_size = tuple(input.shape)
+            mask = mask_in if mask_in is not None else torch.ones(1, 1, *input.shape[2:], device=input.device)
+            if self.multi_channel and mask.shape[1] == 1:
+                mask = mask.expand(-1, self.in_channels, -1, -1)
+            ones = self.weight_maskUpdater.to(input)
+            self.update_mask = F.conv2d(mask, ones, None, self.stride, self.padding)
+            self.mask_ratio = self.slide_winsize / (self.update_mask + 1e-8)
+            self.update_mask = torch.clamp(self.update_mask, 0, 1)
+            self.mask_ratio = self.mask_ratio * self.update_mask
+        raw = F.conv2d(input * mask_in if mask_in is not None else input, self.weight, self.bias, self.stride, self.padding)
+        if self.bias is not None:
+            b = self.bias.view(1, -1, 1, 1)
+            out = ((raw - b) * self.mask_ratio + b) * self.update_mask
+        else:
+            out = raw * self.mask_ratio
+        return (out, self.update_mask) if self.return_mask else out
+    big = 1024
+    net = synthetic.seeded_fill_(PartialInpaint(), 5).to(device).eval()
+    data = torch.randn(1, 68, big, big, device=device)
+    mask = (torch.rand(1, 1, big, big, device=device) > 0.2).float()
+    with torch.no_grad():
+        net.normalize_images_disp(torch.rand(1, 3, big, big, device=device), torch.rand(1, 1, big, big, device=device), not_normed=True)
+        fused_s, _ = timed(lambda: net.forward(tensorData=data, tensorMasks=mask), 5, 2)
+        with FlopCounterMode(display=False) as fc:
+            net.forward(tensorData=data, tensorMasks=mask)
+        fused_flops = fc.get_total_flops()
+        fused_forward = partial_conv.PartialConv2d.forward
+        partial_conv.PartialConv2d.forward = reference_forward
+        for m in net.modules():                                 # the layers' cached mask statistics are the other formulation's
+            if isinstance(m, partial_conv.PartialConv2d):
+                m.last_size = (None, None, None, None)
+        try:
+            ref_s, _ = timed(lambda: net.forward(tensorData=data, tensorMasks=mask), 5, 2)
+            with FlopCounterMode(display=False) as fc:
+                net.forward(tensorData=data, tensorMasks=mask)
+            ref_flops = fc.get_total_flops()
+        finally:
+            partial_conv.PartialConv2d.forward = fused_forward
+    line = {
+        'metric': 'pipeline_frames_per_sec_%dx%d' % (size, size), 'value': frames_per_video / call_s, 'unit': 'frames/s', 'n_gpus': 1, 'steps': K, 'warmup': Wm,
+        'ms_per_step': call_s * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: %dx%d image -> Semantics + Disparity + Refine -> point cloud -> 2 inpaint passes -> %d frames in host memory; '
+                               'a step = one whole video; seeded random weights' % (size, size, frames_per_video),
+                   'miopen_find': bool(args.miopen_find), 'call_ms': {'median': round(call_s * 1e3, 2), 'min': round(min(call_ts) * 1e3, 2), 'max': round(max(call_ts) * 1e3, 2)}},
+        'stages_ms': {'estimate (resize + 3 networks + unprojection)': round(est_s * 1e3, 2), 'point cloud growth (2 x context net, 68-channel warp, Inpaint forward)': round(grow_s * 1e3, 2),
+                      'frame loop (%d frames delivered)' % frames_per_video: round(loop_s * 1e3, 2)},
+        'partial_inpaint_1024': {'what': 'SURVEY 8d "4b": partial-convolution Inpaint.forward at 1024x1024, fp32 on MIOpen',
+                                 'fused_epilogue_ms': round(fused_s * 1e3, 2), 'reference_formulation_ms': round(ref_s * 1e3, 2),
+                                 'fused_conv_tflop': round(fused_flops / 1e12, 3), 'reference_conv_tflop': round(ref_flops / 1e12, 3),
+                                 'fused_tflops': round(fused_flops / fused_s / 1e12, 1), 'reference_tflops': round(ref_flops / ref_s / 1e12, 1),
+                                 'peak_fp32_matrix_tflops': 157.3},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N ranks of this script under torch.distributed.run, one process per
     GPU, rendezvous on 127.0.0.1 -- the same command line the driver uses when it starts the ranks itself.  Rank 0's JSON line
@@ -282,6 +395,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None,
                     help='hand-off (include/kbe.h): default groups of 8 frames per hipMemcpyAsync, the lanes taking turns; 0: per-frame copy kernel; '
                          '> 0: staged ring, one hipMemcpyAsync per BATCH frames on a copy stream')
+    ap.add_argument('--pipeline', action='store_true', help='BASELINE configs[1] as a whole (512^2 image -> nets -> 64 delivered frames) and the 1024^2 partial-conv '
+                                                            'Inpaint forward; a separate line, not the headline metric')
+    ap.add_argument('--miopen-find', action='store_true', help='with --pipeline: torch.backends.cudnn.benchmark = True (MIOpen find step with a workspace)')
     ap.add_argument('--upsample', type=int, default=1, help='cloud of (upsample * size)^2 points (BASELINE configs[4]: 2; implies --cloud raw)')
     ap.add_argument('--cloud', choices=['inpaint', 'raw'], default='inpaint',
                     help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
@@ -352,6 +468,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    if args.pipeline:
+        if world_size > 1:
+            sys.exit('bench.py --pipeline times one video on one GPU')
+        return pipeline_bench(args, device)
 
     from ken_burns_effect_amd import common, sharding, synthetic
     # multi-GPU: every rank's frames land in pinned memory of the NUMA node its GPU hangs off (best effort; the CPU
