@@ -105,7 +105,8 @@ def measured_instructions():
         return {}, None
 
 
-GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group / _fused)
+GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group / _fused) when the timed region uses one
+BUCKET_GROUP_MAX = 4    # kbe_render_frame_group takes up to four frames, kbe_render_frame_group_fused up to eight
 VALU_ISSUE_PER_US = 1024 * 2400.0 / 4.0     # wave-level VALU instructions the chip issues per us: 1024 SIMDs, one per 4 cycles each, 2.4 GHz
 
 
@@ -171,16 +172,17 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
             alternating(3)()
     out['bucket:scatter'] = timed(alternating(3))
     # the same two launches taking FOUR frames each (kbe_render_frame_group: what videos with KBE_VIDEO_FILL_GROUP use), per launch pair
-    group_out = torch.empty(group_frames, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
+    bucket_frames = min(group_frames, BUCKET_GROUP_MAX)
+    group_out = torch.empty(bucket_frames, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
     gflip = [0]
 
     def grouped():
-        K.render_frame_group(state, [(focal, shift3)] * group_frames, Bl, group_out, stages=3, zbuf_flags=[256 if gflip[0] & 1 else 128] * group_frames)
+        K.render_frame_group(state, [(focal, shift3)] * bucket_frames, Bl, group_out, stages=3, zbuf_flags=[256 if gflip[0] & 1 else 128] * bucket_frames)
         gflip[0] += 1
     out['bucket:scatter_group'] = timed(grouped)
     if gflip[0] & 1:
         grouped()
-    K.render_frame_group(state, [(focal, shift3)] * group_frames, Bl, group_out, stages=4, fill_rect=empty)       # leaves the sets clean
+    K.render_frame_group(state, [(focal, shift3)] * bucket_frames, Bl, group_out, stages=4, fill_rect=empty)       # leaves the sets clean
     del group_out
     out['bucket:scatter+fill'] = timed(alternating(7, fill_rect=fill_rect))
     settle()
@@ -595,6 +597,8 @@ def main():
         insts, insts_src = measured_instructions() if default_workload else ({}, None)
 
         def roof(r, frames):
+            if r == 'bucket':
+                frames = min(frames, BUCKET_GROUP_MAX)
             t = kt[r + (':scatter_group' if frames > 1 else ':scatter')]
             names = route_launches[r]
             tr = sum(per_kernel[k] for k in names) if all(k in per_kernel for k in names) else None

@@ -28,6 +28,7 @@ ABI_VERSION = 6
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
+FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
@@ -114,6 +115,10 @@ def _stream():
     tensors live on that device (`_ptr`), so a caller working on cuda:1 without torch.cuda.set_device(1) gets a KbeError
     instead of device-1 pointers launched on device 0's stream."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def stride_of(K, state):
+    return int(K.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
 
 
 class HipKernels:
@@ -345,7 +350,7 @@ class HipKernels:
         """kbe_render_frame_group_fused: the same on the packed cloud (k_place + k_frame + fill, each taking all the frames)."""
         n = len(cameras)
         self._pack(state)
-        scratch, stride = self.group_scratch(state, max(n, 4))
+        scratch, stride = self.group_scratch(state, max(n, 4) if 'scratch_groups' not in state else max(n, state['scratch_groups'].numel() // stride_of(self, state)))
         focals = (ctypes.c_double * n)(*[float(c[0]) for c in cameras])
         shifts = (ctypes.c_float * (3 * n))(*[float(v) for c in cameras for v in c[1]])
         sets = (ctypes.c_void_p * n)(*[scratch.data_ptr() + k * stride for k in range(n)])
@@ -378,18 +383,22 @@ class HipKernels:
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
         fused = bool(state.get('fused')) and (os.environ.get('KBE_FUSED') == '1' or not zooms_out)
         if os.environ.get('KBE_FILL_GROUP'):
-            group = max(1, min(4, int(os.environ['KBE_FILL_GROUP'])))
+            group = max(1, min(8 if fused else 4, int(os.environ['KBE_FILL_GROUP'])))
         elif flags:
             group = DEFAULT_FILL_GROUP
         elif fused:
-            group = 4 if (W * H <= 576 * 576 or to_host) else 2
+            # eight where the link binds (the rendering then only has to stay out of the transfers' way: the fewer, larger
+            # launches the better), four for small frames, two for large frames left in HBM on four lanes
+            group = FUSED_HOST_GROUP if to_host else (4 if W * H <= 576 * 576 else 2)
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
             # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)
             group = 4 if W * H <= 576 * 576 else (2 if W * H <= 900 * 900 else 1)
         if not (batch is None or batch <= 0):
             group = 1
-        return flags | ((group - 1) << 1), group, fused
+        if not fused:
+            group = min(group, 4)
+        return flags | (((group - 1) << 1) if group <= 4 else ((group - 1) << 5)), group, fused
 
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host

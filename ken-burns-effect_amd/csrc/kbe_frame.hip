@@ -777,7 +777,7 @@ static inline size_t stage_fin_per_lane(int batch) { return batch < -2 ? (size_t
 static inline size_t stage_ctl_offset(int W, int H, int lanes, int batch)
 {
     const size_t fb = (size_t) W * H * 3;
-    return (((size_t) lanes * (KBE_FILL_JOBS + stage_fin_per_lane(batch)) + 2 * (size_t) (batch > 0 ? batch : 0)) * fb + 255) & ~(size_t) 255;
+    return (((size_t) lanes * (KBE_FRAME_JOBS + stage_fin_per_lane(batch)) + 2 * (size_t) (batch > 0 ? batch : 0)) * fb + 255) & ~(size_t) 255;
 }
 
 size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch)
@@ -949,12 +949,12 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
                                  const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* parities, int stages,
                                  const int* fill_rect, kbe_stream_t stream)
 {
-    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FILL_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
                 (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_fused: bad arguments");
     static const FillDirs dirs = make_fill_dirs();
     const hipStream_t s = (hipStream_t) stream;
-    FusedTarget ft[KBE_FILL_JOBS];
-    FillTarget targets[KBE_FILL_JOBS];
+    FusedTarget ft[KBE_FRAME_JOBS];
+    FillTarget targets[KBE_FRAME_JOBS];
     int n_tiles = 0, rc = KBE_OK;
     for (int k = 0; k < n_frames; k++) {
         KBE_REQUIRE(scratch[k] && frames_u8[k] && ((uintptr_t) scratch[k] & 15) == 0, "kbe_render_frame_group_fused: bad scratch / frame pointer");
@@ -977,7 +977,8 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
     if (stages & KBE_STAGE_FILL) {
         FillRect rect = { 0, 0, W - 1, H - 1 };
         if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
-        launch_fill(s, n_frames, targets, W, H, stages, dirs, rect, n_tiles);
+        for (int k0 = 0; k0 < n_frames; k0 += KBE_FILL_JOBS)       // the fill takes KBE_FILL_JOBS frames per launch
+            launch_fill(s, n_frames - k0 < KBE_FILL_JOBS ? n_frames - k0 : KBE_FILL_JOBS, targets + k0, W, H, stages, dirs, rect, n_tiles);
         rc = launched("kbe_render_frame_group_fused/fill");
     }
     return rc;
@@ -1032,13 +1033,16 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     // scratch set of its own, and fills them in the same launches.  The table-driven fill is bound by its own chain of
     // dependent look-ups, not by the chip (272 us alone, 352 us with four of them overlapping), and more than four
     // streams do not overlap any better (the hardware queues): two frames per launch are the way to have eight in flight.
-    const int group = batch <= 0 ? ((flags >> 1) & 3) + 1 : 1;         // KBE_VIDEO_FILL_GROUP(n)
-    KBE_REQUIRE(group <= KBE_FILL_JOBS, "kbe_render_video: KBE_VIDEO_FILL_GROUP beyond the library's KBE_FILL_JOBS");
+    // KBE_VIDEO_FILL_GROUP(n), n <= 4; KBE_VIDEO_GROUP(n), n <= 8, for the fused route, whose scatter launches take up to
+    // KBE_FRAME_JOBS frames (fill and crop launches then take them four at a time)
+    const int wide_group = ((flags >> 5) & 7) + 1;
+    const int group = batch <= 0 ? (wide_group > 1 ? wide_group : ((flags >> 1) & 3) + 1) : 1;
+    KBE_REQUIRE(group <= (packed ? KBE_FRAME_JOBS : KBE_FILL_JOBS), "kbe_render_video: more frames per launch than the route's launches take");
     const bool pairs = group > 1;
     // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
     // frame: the fixed cost of a kernel boundary on this chip (launch ramp, tail, and the L2 write-back between
     // dependent kernels) is then paid while another frame's kernels run.
-    // stage = [KBE_FILL_JOBS * lanes raw frames][lanes * fin finished frames][ring half 0: batch frames][ring half 1: batch frames].
+    // stage = [KBE_FRAME_JOBS * lanes raw frames][lanes * fin finished frames][ring half 0: batch frames][ring half 1: batch frames].
     hipStream_t ls[KBE_MAX_LANES], ds[1];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? cs : (hipStream_t) lane_streams[l];
     ds[0] = copy_stream ? (hipStream_t) copy_stream : cs;        // only the staged ring (batch > 0) uses it
@@ -1047,7 +1051,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #endif
     const int fin = (int) stage_fin_per_lane(batch);                    // finished-frame buffers per lane
     const int slots = fin * lanes;
-    uint8_t* const finished = stage + (size_t) KBE_FILL_JOBS * lanes * fb;
+    uint8_t* const finished = stage + (size_t) KBE_FRAME_JOBS * lanes * fb;
     uint8_t* ring[2] = { finished + (size_t) slots * fb, finished + ((size_t) slots + (size_t) (batch > 0 ? batch : 0)) * fb };
     // where do the frames go?  (a pointer the runtime does not know is taken for device memory, as before)
     uint8_t* host_dev = nullptr;                // host_out as the device sees it, when it is pinned host memory
@@ -1153,12 +1157,12 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     };
     // up to `group` frames of lane l: each scattered into a scratch set of its own, filled together, cropped
     static const FillDirs fill_dirs = make_fill_dirs();
-    int set_frames[KBE_MAX_LANES][KBE_FILL_JOBS] = {}, set_total[KBE_MAX_LANES][KBE_FILL_JOBS] = {};
+    int set_frames[KBE_MAX_LANES][KBE_FRAME_JOBS] = {}, set_total[KBE_MAX_LANES][KBE_FRAME_JOBS] = {};
     bool counting = false;
     auto render_group = [&](int l, int count, const int* idx, uint8_t* const* outs) {
         if (counting) { for (int j = 0; j < count; j++) set_total[l][j]++; return (int) KBE_OK; }
         const int fill_flags = (lanes * group >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0) | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0);
-        uint8_t* raws[KBE_FILL_JOBS];
+        uint8_t* raws[KBE_FRAME_JOBS];
         int rc = KBE_OK;
         if (!packed) {
             // bucket route: every launch (projection, tiles, fill) takes the whole group
@@ -1166,7 +1170,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             for (int j = 0; j < count; j++) {
                 const int i = idx[j], k = set_frames[l][j]++;
                 const bool last_of_set = k + 1 == set_total[l][j];
-                raws[j] = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
+                raws[j] = stage + (size_t) (KBE_FRAME_JOBS * l + j) * fb;
                 jobs[j] = FrameJob{ focals[i], shifts + 3 * (size_t) i, (char*) scratch + (size_t) (group * l + j) * sb, crop ? raws[j] : outs[j], nullptr, nullptr,
                                     nullptr, nullptr, (k & 1) ? KBE_STAGE_ZBUF_B : (last_of_set ? 0 : KBE_STAGE_ZBUF_A) };
             }
@@ -1174,12 +1178,12 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                              crop ? rect : nullptr, raster_w, raster_n, ls[l]);
         } else {
             // fused route: the binning launch, the tile launch and the fill each take the whole group
-            FillTarget targets[KBE_FILL_JOBS];
-            FusedTarget ft[KBE_FILL_JOBS];
+            FillTarget targets[KBE_FRAME_JOBS];
+            FusedTarget ft[KBE_FRAME_JOBS];
             for (int j = 0; j < count; j++) {
                 const int i = idx[j], k = set_frames[l][j]++;
                 char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
-                raws[j] = stage + (size_t) (KBE_FILL_JOBS * l + j) * fb;
+                raws[j] = stage + (size_t) (KBE_FRAME_JOBS * l + j) * fb;
                 uint8_t* const target = crop ? raws[j] : outs[j];
                 const Scratch sc = carve(scr, W, H);
                 ft[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), sc, scratch_place(scr, W, H), k & 1, target, nullptr, nullptr, nullptr, nullptr };
@@ -1190,11 +1194,13 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };
             if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
-            launch_fill(ls[l], count, targets, W, H, KBE_STAGE_FILL | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0), fill_dirs, fr,
-                        targets[0].sc.tiles_x * targets[0].sc.tiles_y);
+            for (int j0 = 0; j0 < count; j0 += KBE_FILL_JOBS)
+                launch_fill(ls[l], count - j0 < KBE_FILL_JOBS ? count - j0 : KBE_FILL_JOBS, targets + j0, W, H,
+                            KBE_STAGE_FILL | ((fill_flags & KBE_STAGE_FILL_BY_COUNT) ? fill_flags : 0), fill_dirs, fr, targets[0].sc.tiles_x * targets[0].sc.tiles_y);
             rc = launched("kbe_render_video/fill");
         }
-        if (rc == KBE_OK && crop) rc = crop_resize_group(count, raws, W, H, crop_w, crop_h, outs, ls[l]);
+        for (int j0 = 0; j0 < count && rc == KBE_OK && crop; j0 += KBE_FILL_JOBS)
+            rc = crop_resize_group(count - j0 < KBE_FILL_JOBS ? count - j0 : KBE_FILL_JOBS, raws + j0, W, H, crop_w, crop_h, outs + j0, ls[l]);
         return rc;
     };
     // whoever synchronises `stream` afterwards also sees every frame delivered and every other stream idle
@@ -1212,8 +1218,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 counting = pass == 0;
                 for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes)
                     for (int l = 0; l < lanes && rc == KBE_OK; l++) {
-                        int idx[KBE_FILL_JOBS], count = 0;
-                        uint8_t* outs[KBE_FILL_JOBS];
+                        int idx[KBE_FRAME_JOBS], count = 0;
+                        uint8_t* outs[KBE_FRAME_JOBS];
                         for (int m = 0; m < group; m++) {
                             const int i = base + m * lanes + l;
                             if (i < n_frames) { idx[count] = i; outs[count++] = host_out + (size_t) i * fb; }
@@ -1262,8 +1268,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #endif
                 uint8_t* base = finished + (size_t) l * fin * fb;
                 if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
-                    int idx[KBE_FILL_JOBS], count = 0;
-                    uint8_t* outs[KBE_FILL_JOBS];
+                    int idx[KBE_FRAME_JOBS], count = 0;
+                    uint8_t* outs[KBE_FRAME_JOBS];
                     for (int m = 0; m < group && k + m < nb; m++) { idx[count] = i0 + k + m; outs[count++] = base + (size_t) (k + m) * fb; }
                     rc = render_group(l, count, idx, outs);
                 }

@@ -152,7 +152,6 @@ __device__ unsigned long long g_frame_stats[8];     // tiles, list entries writt
 // take no part in the box.  The order of a list's entries is the order the atomics retire in: it only decides the order of
 // the fp32 sums, as the bucket order does on the other route.
 // ---------------------------------------------------------------------------------------
-constexpr int KBE_FRAME_JOBS = KBE_FILL_JOBS;
 struct PlaceJobs { PlaceArgs a[KBE_FRAME_JOBS]; };
 
 // minimum over the 16 lanes of a DPP row, left in every lane of the row: four v_min_i32 that read their second operand
@@ -630,7 +629,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) 
 }  // namespace
 
 namespace kbe {
-// the scatter of n <= KBE_FILL_JOBS frames of the same packed cloud and frame size: one placement launch and one tile launch,
+// the scatter of n <= KBE_FRAME_JOBS frames of the same packed cloud and frame size: one placement launch and one tile launch,
 // each taking all n frames (frame k: its camera, scratch set, placement array, and hole counter / list total pair by parity)
 void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t)
 {

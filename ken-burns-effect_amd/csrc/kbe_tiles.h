@@ -123,6 +123,10 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 // KBE_STAGE_FILL_DIST the tables (k_hole_dist) and the table-driven fill (k_fill_tables) in front of k_fill_holes; each
 // returns at once when a frame has fewer holes than its schedule asks for
 constexpr int KBE_FILL_JOBS = 4;
+#ifndef KBE_FRAME_JOBS_MAX
+#define KBE_FRAME_JOBS_MAX 8
+#endif
+constexpr int KBE_FRAME_JOBS = KBE_FRAME_JOBS_MAX;      // frames a launch of the fused scatter (k_place, k_frame) takes at most
 struct FillTarget {                 // a frame to be filled, on the host
     Scratch sc;
     const int* hole_count;
@@ -140,7 +144,7 @@ struct FillJobs { FillJob j[KBE_FILL_JOBS]; };
 void launch_fill(hipStream_t s, int n_jobs, const FillTarget* targets, int W, int H, int stages, const FillDirs& dirs, const FillRect& rect, int n_tiles);
 // kbe_hip.hip: kbe_crop_resize_u8 for n <= 4 frames of the same size in one launch
 int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int crop_w, int crop_h, uint8_t* const* outs, hipStream_t stream);
-// kbe_fused.hip: the scatter of 1..KBE_FILL_JOBS frames from the packed cloud (k_bin + k_frame, each launch taking all the frames)
+// kbe_fused.hip: the scatter of 1..KBE_FRAME_JOBS frames from the packed cloud (k_place + k_frame, each launch taking all the frames)
 struct FusedTarget {
     Camera cam;
     Scratch sc;
