@@ -251,7 +251,7 @@ KBE_API int kbe_render_frame_fused(const void* packed, int N, double cloud_focal
                                    float* existing_f32, float* zee_f32, float* zee_pre_f32, int stages,
                                    const int* fill_rect, int parity, kbe_stream_t stream);
 
-/* ... and for a GROUP of 1..8 frames of the same packed cloud and size: the placement launch, the tile launch and the fill
+/* ... and for a GROUP of 1..12 frames of the same packed cloud and size: the placement launch, the tile launch and the fill
  * each take all the frames (as kbe_render_frame_group on the other route).  scratch [n]: one initialised scratch set per
  * frame (kbe_frame_scratch_bytes(W, H, N) each); parities [n] (or NULL: all -1): as kbe_render_frame_fused, per scratch set. */
 KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
@@ -305,9 +305,9 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * and loses 3-7 %.  `scratch` must then hold n * lanes sets (n * lanes * kbe_video_scratch_stride bytes, every set
  * initialised with kbe_frame_scratch_init); same frames. */
 #define KBE_VIDEO_FILL_GROUP(n) (((n) - 1) << 1)
-/* the same for n = 1..8 frames at a time on the fused route (`packed`): the placement and tile launches take all n, the fill and
+/* the same for n = 1..12 frames at a time on the fused route (`packed`): the placement and tile launches take all n, the fill and
  * the crop four at a time.  A launch on its own pays its ramp and its tail once whatever it holds: the fused scatter of a
- * 1024 x 1024 frame costs 35 / 27 / 23 / 20.8 us per frame with 1 / 2 / 4 / 8 frames per launch. */
+ * 1024 x 1024 frame costs 35 / 27 / 23 / 20.8 / 20.1 us per frame with 1 / 2 / 4 / 8 / 12 frames per launch (bits 5-8 of `flags`). */
 #define KBE_VIDEO_GROUP(n) (((n) - 1) << 5)
 /* batch <= 0, frames to host memory: the lanes do not take turns on the PCIe link (for videos whose rendering binds, not the
  * link: a lane waiting for its turn would only idle) */

@@ -28,7 +28,7 @@ ABI_VERSION = 6
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
-FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP)
+FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
@@ -383,7 +383,7 @@ class HipKernels:
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
         fused = bool(state.get('fused')) and (os.environ.get('KBE_FUSED') == '1' or not zooms_out)
         if os.environ.get('KBE_FILL_GROUP'):
-            group = max(1, min(8 if fused else 4, int(os.environ['KBE_FILL_GROUP'])))
+            group = max(1, min(12 if fused else 4, int(os.environ['KBE_FILL_GROUP'])))
         elif flags:
             group = DEFAULT_FILL_GROUP
         elif fused:

@@ -1033,9 +1033,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     // scratch set of its own, and fills them in the same launches.  The table-driven fill is bound by its own chain of
     // dependent look-ups, not by the chip (272 us alone, 352 us with four of them overlapping), and more than four
     // streams do not overlap any better (the hardware queues): two frames per launch are the way to have eight in flight.
-    // KBE_VIDEO_FILL_GROUP(n), n <= 4; KBE_VIDEO_GROUP(n), n <= 8, for the fused route, whose scatter launches take up to
+    // KBE_VIDEO_FILL_GROUP(n), n <= 4; KBE_VIDEO_GROUP(n), n <= KBE_FRAME_JOBS, for the fused route, whose scatter launches take up to
     // KBE_FRAME_JOBS frames (fill and crop launches then take them four at a time)
-    const int wide_group = ((flags >> 5) & 7) + 1;
+    const int wide_group = ((flags >> 5) & 15) + 1;
     const int group = batch <= 0 ? (wide_group > 1 ? wide_group : ((flags >> 1) & 3) + 1) : 1;
     KBE_REQUIRE(group <= (packed ? KBE_FRAME_JOBS : KBE_FILL_JOBS), "kbe_render_video: more frames per launch than the route's launches take");
     const bool pairs = group > 1;

@@ -124,7 +124,7 @@ struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are 
 // returns at once when a frame has fewer holes than its schedule asks for
 constexpr int KBE_FILL_JOBS = 4;
 #ifndef KBE_FRAME_JOBS_MAX
-#define KBE_FRAME_JOBS_MAX 8
+#define KBE_FRAME_JOBS_MAX 12        // (12 x sizeof(FrameArgs) = 3.8 KB of kernel arguments: the launch takes 4 KB)
 #endif
 constexpr int KBE_FRAME_JOBS = KBE_FRAME_JOBS_MAX;      // frames a launch of the fused scatter (k_place, k_frame) takes at most
 struct FillTarget {                 // a frame to be filled, on the host

@@ -47,9 +47,9 @@ if True:
 # the fused route's scatter (k_place + k_frame) with 1..4 frames per launch, alone on a stream, us per FRAME
 K._pack(state)
 focal, shift3 = cams[len(cams) // 2]
-out = torch.empty(8, size, size, 3, dtype=torch.uint8, device='cuda')
-K.group_scratch(state, 8)
-for n in (1, 2, 4, 6, 8):
+out = torch.empty(12, size, size, 3, dtype=torch.uint8, device='cuda')
+K.group_scratch(state, 12)
+for n in (1, 2, 4, 8, 12):
     group = [(focal, shift3)] * n
     par = [0]
 
@@ -65,4 +65,4 @@ for n in (1, 2, 4, 6, 8):
     e1.record()
     torch.cuda.synchronize()
     print('fused scatter with %d frame(s) per launch: %.2f us per frame' % (n, e0.elapsed_time(e1) * 1e3 / 40 / n))
-K.render_frame_group_fused(state, [(focal, shift3)] * 8, oc['dblBaseline'], out, stages=6)     # parity -1: leaves the sets' counters zeroed
+K.render_frame_group_fused(state, [(focal, shift3)] * 12, oc['dblBaseline'], out, stages=6)     # parity -1: leaves the sets' counters zeroed
