@@ -575,7 +575,7 @@ def main():
     if rank == 0:
         from ken_burns_effect_amd import _native
         lanes = max(1, min(_native.MAX_LANES, int(os.environ.get('KBE_LANES', _native.DEFAULT_LANES))))
-        host_lanes = _native.host_lanes(lanes, n_points, size, size, 3 * size * size)
+        host_lanes = _native.kernels().delivery_lanes(common._prepared_cloud(_native.kernels(), oc), cams, oc['dblBaseline'], crop)   # measured once per cloud
         # the route and the frames per launch of the timed region (_native.video_launch_shape: the fused route with four frames
         # per launch where the frames are delivered to host memory; a zoom-out or a cloud denser than the raster: the bucket route)
         state = common._prepared_cloud(_native.kernels(), oc)

@@ -33,8 +33,18 @@ DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fi
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
 
+LINK_BYTES_PER_US = 53.0e3     # what the PCIe link moves for this loop (measured: 53-54.5 GB/s of the 63 GB/s Gen5 x16)
+
+
+def lanes_for_delivery(lanes, render_us, frame_bytes):
+    """Two lanes where the link binds (it needs 1.5 x longer per frame than the rendering), all lanes elsewhere."""
+    link_us = frame_bytes / LINK_BYTES_PER_US
+    return min(lanes, DEFAULT_HOST_LANES) if link_us > 1.5 * render_us else lanes
+
+
 def host_lanes(lanes, n_points, W, H, frame_bytes):
-    """Lanes of the frame loop when the frames go to pinned host memory (env KBE_HOST_LANES overrides).  Where the PCIe
+    """The a-priori estimate (HipKernels.delivery_lanes measures instead, once per cloud, when the video is long enough).
+    Lanes of the frame loop when the frames go to pinned host memory (env KBE_HOST_LANES overrides).  Where the PCIe
     link binds, two lanes ping-pong best (one renders its next group while the other's leaves: 59.1 us per 1024^2 frame of
     the bench against 60.7 with four and 84.8 with three); where the rendering binds every lane helps (measured, 2 -> 4
     lanes: 512^2 25.5 -> 18.8 us, dolly 260 -> 155, raw cloud 64 -> 61, 2048^2 raw 305 -> 276, 2048^2 from 16.8 M points
@@ -400,6 +410,35 @@ class HipKernels:
             group = min(group, 4)
         return flags | (((group - 1) << 1) if group <= 4 else ((group - 1) << 5)), group, fused
 
+    def delivery_lanes(self, state, cameras, baseline, crop=None):
+        """Lanes of the frame loop when the frames go to pinned host memory: two where the link binds, all where the rendering
+        does (`host_lanes` has the measurements).  Which it is depends on the cloud, the camera path and the route, so it is
+        MEASURED once per cloud -- twelve of the video's frames rendered into HBM on all lanes, timed with two events (a
+        few hundred microseconds) -- and kept in the cloud's state; videos shorter than that, and the first lookup without a
+        camera path, take the a-priori estimate.  Env KBE_HOST_LANES overrides."""
+        lanes, W, H = state['lanes'], state['W'], state['H']
+        env = os.environ.get('KBE_HOST_LANES')
+        if env:
+            return min(lanes, max(1, int(env)))
+        key = bool(cameras) and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']      # a zoom-out renders differently: its own entry
+        cache = state.setdefault('delivery_lanes', {})
+        if key in cache:
+            return cache[key]
+        if len(cameras) < 24 or lanes == 1:
+            return host_lanes(lanes, state['N'], W, H, 3 * W * H)
+        probe = cameras[::max(1, len(cameras) // 12)][:12]
+        out = torch.empty(len(probe), H, W, 3, dtype=torch.uint8, device=state['points'].device)
+        self.render_video(state, probe, baseline, crop=crop, host_out=out)                          # warm-up: scratch, streams, the packed cloud
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.render_video(state, probe, baseline, crop=crop, host_out=out)
+        e1.record()
+        e1.synchronize()
+        render_us = e0.elapsed_time(e1) * 1e3 / len(probe)
+        cache[key] = lanes_for_delivery(lanes, render_us, 3 * W * H)       # a cropped frame is resized back to W x H (common.py:257)
+        state['delivery_probe_us'] = render_us
+        return cache[key]
+
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
@@ -419,7 +458,7 @@ class HipKernels:
                 raise KbeError('render_video: host_out must be pinned host memory (or a device tensor)')
             # The hand-off (include/kbe.h): < 0 = groups of -batch frames per lane, one hipMemcpyAsync each, the lanes
             # taking turns on the link (default); 0 = per frame by a copy kernel; > 0 = round 1's staged ring.
-            lanes = host_lanes(lanes, state['N'], W, H, 3 * W * H)      # a cropped frame is resized back to W x H (common.py:257)
+            lanes = self.delivery_lanes(state, cameras, baseline, crop)
             if batch is None:
                 env = os.environ.get('KBE_DELIVERY_BATCH', '0')
                 try:

@@ -254,6 +254,18 @@ def test_host_lanes_two_where_the_link_binds_all_where_the_rendering_does(monkey
     assert _native.host_lanes(4, 1137109, 1024, 1024, 3 << 20) == 3
 
 
+def test_lanes_for_delivery_follow_the_measured_render_time():
+    """_native.lanes_for_delivery (what HipKernels.delivery_lanes applies to the render time it measures once per cloud): two
+    lanes where the link needs 1.5 x longer per frame than the rendering, every lane where the rendering binds."""
+    from ken_burns_effect_amd import _native
+    fb = 3 * 1024 * 1024                                            # 59 us on the link
+    assert _native.lanes_for_delivery(4, 25.0, fb) == 2             # the bench workload: the link binds
+    assert _native.lanes_for_delivery(4, 39.0, fb) == 2 and _native.lanes_for_delivery(4, 40.0, fb) == 4
+    assert _native.lanes_for_delivery(4, 98.0, fb) == 4             # a dolly zoom: the fill binds
+    assert _native.lanes_for_delivery(4, 12.0, 3 * 512 * 512) == 4 and _native.lanes_for_delivery(4, 9.0, 3 * 512 * 512) == 2     # 512^2: 14.8 us on the link
+    assert _native.lanes_for_delivery(1, 25.0, fb) == 1 and _native.lanes_for_delivery(8, 5.0, fb) == 2
+
+
 def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     """_native.video_launch_shape: the table-driven fill for clouds without appended points seen by a camera that zooms out;
     frames per launch by what binds the video; the scatter route (a zoom-out piles the points up: the bucket route)."""
