@@ -399,7 +399,9 @@ class HipKernels:
         elif fused:
             # eight where the link binds (the rendering then only has to stay out of the transfers' way: the fewer, larger
             # launches the better), four for small frames, two for large frames left in HBM on four lanes
-            group = FUSED_HOST_GROUP if to_host else (4 if W * H <= 576 * 576 else 2)
+            # (measured, us per frame left in HBM with 2 / 4 frames per launch: 640^2 13.6 / 11.7, 768^2 15.9 / 15.5, 896^2 22.5 / 22.2,
+            # 1024^2 25.3 / 26.7, 1280^2 42.1 / 43.5, 1536^2 61.3 / 62.2; the bucket route: 13.7, 18.8, 25.5, 29.4, 51.7, 72.8)
+            group = FUSED_HOST_GROUP if to_host else (4 if W * H <= 900 * 900 else 2)
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
             # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)
