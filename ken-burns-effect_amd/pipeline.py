@@ -28,8 +28,18 @@ from .utils import load_models, resize_image
 
 class Pipeline():
     def __init__(self, model_paths=None, partial_inpainting=False, dolly=False, output_frames=False, pretrain=False, d2=False,
-                 device='cuda:0', steps=75, inpaint_dtype=None, semantics_path=None):
+                 device='cuda:0', steps=75, inpaint_dtype=None, semantics_path=None, miopen_find=None):
         self.objectCommon = {'dblFocal': 1024.0 / 2, 'dblBaseline': 120}       # pipeline.py:26-27
+        # The networks are four fifths of a video's time.  PyTorch's default (immediate) MIOpen mode hands the library no
+        # workspace, and MIOpen then falls back to slower convolution solvers (its `IsEnoughWorkspace ... size: 0` warnings):
+        # with the find step -- ``miopen_find=True`` / env KBE_MIOPEN_FIND=1, i.e. torch.backends.cudnn.benchmark -- a 512^2 video
+        # takes 23.0 instead of 24.9 ms and the 1024^2 partial-convolution Inpaint forward 19.3 instead of 26.7 ms
+        # (bench.py --pipeline).  Off by default: the find step costs seconds the first time a shape is seen, which a process
+        # that renders one video never earns back; a server that renders many should switch it on.
+        if miopen_find is None:
+            miopen_find = os.environ.get('KBE_MIOPEN_FIND') == '1'
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
         self.partial_inpainting, self.dolly, self.output_frames, self.d2 = partial_inpainting, dolly, output_frames, d2
         self.device, self.steps = torch.device(device), steps
         self.moduleSemantics = Semantics().to(self.device).eval()
