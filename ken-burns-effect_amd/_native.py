@@ -497,7 +497,7 @@ class HipKernels:
             flags |= 16
         scratch = state['scratch']
         if group > 1:
-            scratch, _ = self.group_scratch(state, group * state['lanes'])      # n * lanes sets, allocated on first use
+            scratch, _ = self.group_scratch(state, group * lanes)      # n sets per lane in use, allocated on first use (224 MB each at 1024^2)
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
