@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 6
+#define KBE_ABI_VERSION 7
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -258,11 +258,28 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
                                          const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
                                          const int* parities, int stages, const int* fill_rect, kbe_stream_t stream);
 
+/* ... and PIPELINED: a sequence of groups on one stream in which the tile launch of a group also makes the placements of the
+ * NEXT group -- k_place's work spread over the tile launch's waves, whose waits for memory it fills -- so that the scatter
+ * of a group is ONE launch.  A scratch set holds two banks of placements, lists and counters; the k-th use of a set in the
+ * sequence (turns [n]: k >= 0, counted per set; a set on turn 0 has its counters zeroed in front of the launch that first
+ * names it) renders from bank k & 1 and uses hole counter k & 1; a sequence must END with a call that places nothing ahead
+ * (the banks are then empty again).  placed != 0: the group's placements exist (the previous call named these frames, sets and turns as its
+ * `next`), else a placement launch is made in front of the tile launch.  n_next > 0: the tile launch makes the placements
+ * of the frames next_* (the cameras, sets and turns the next call will render with; a set that both groups use has
+ * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
+ * than the raster keeps its placement launch).  Everything else as kbe_render_frame_group_fused; same results. */
 /* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
  * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
  * z-tested gather four channels at a time.  data [C,N]; render [C,H,W] normalised (:686), existing [H*W] the
  * weight sum; shift3 as in kbe_zsplat (NULL: none); scratch as kbe_render_frame (left clean).  Same results
  * as kbe_render_pointcloud up to the order of the fp32 sums. */
+KBE_API int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_next);
+KBE_API int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
+                                         const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
+                                         const int* turns, int placed, int n_next, const double* next_focals, const float* next_shifts,
+                                         void* const* next_scratch, const int* next_turns, int stages, const int* fill_rect,
+                                         kbe_stream_t stream);
+
 KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
                                         double baseline, const float* shift3, void* scratch, float* render,
                                         float* existing, kbe_stream_t stream);
@@ -315,6 +332,10 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 /* batch < 0: every transfer group has G = -batch frames.  Default: the groups ramp -- 1, 2, 4, ... frames up to G, then G -- so
  * that the link starts after the first frame and a short video does not wait for G frames before its first byte moves. */
 #define KBE_VIDEO_EVEN_GROUPS 16
+/* fused route (`packed`): every group keeps a placement launch of its own in front of its tile launch.  Default: the tile launch
+ * of a lane's group also makes the placements of the lane's NEXT group (kbe_render_frame_group_ahead), so that the scatter of
+ * a group is one launch. */
+#define KBE_VIDEO_NO_AHEAD 512
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

@@ -20,11 +20,11 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
-    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
+    'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
@@ -372,6 +372,32 @@ class HipKernels:
                                                           _stream()), 'kbe_render_frame_group_fused')
         return out
 
+    def render_frame_group_ahead(self, state, cameras, baseline, out, turn, placed, next_cameras=None, stages=6, fill_rect=None, next_turn=None):
+        """kbe_render_frame_group_ahead: frame k on scratch set k of the group scratch, on the set's turn `turn` (an int for all, or
+        one per frame); the tile launch makes the placements of `next_cameras` when given (frame k on set k, turn `next_turn`:
+        default turn + 1)."""
+        n = len(cameras)
+        m = len(next_cameras) if next_cameras else 0
+        self._pack(state)
+        scratch, stride = self.group_scratch(state, max(n, m, 4) if 'scratch_groups' not in state else max(n, m, state['scratch_groups'].numel() // stride_of(self, state)))
+
+        def arrays(cams, k):
+            return ((ctypes.c_double * k)(*[float(c[0]) for c in cams]), (ctypes.c_float * (3 * k))(*[float(v) for c in cams for v in c[1]]),
+                    (ctypes.c_void_p * k)(*[scratch.data_ptr() + j * stride for j in range(k)]))
+        focals, shifts, sets = arrays(cameras, n)
+        nf, ns, nsets = arrays(next_cameras, m) if m else (None, None, None)
+        frames = (ctypes.c_void_p * n)(*[out[k].data_ptr() for k in range(n)])
+        turn = [int(turn)] * n if isinstance(turn, int) else [int(t) for t in turn]
+        if next_turn is None:
+            next_turn = [(turn[k] if k < n else turn[0]) + 1 for k in range(m)]
+        turns = (ctypes.c_int * n)(*turn)
+        nturns = (ctypes.c_int * m)(*[int(t) for t in next_turn]) if m else None
+        rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
+        self._check(self.lib.kbe_render_frame_group_ahead(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']),
+                                                          _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, turns, _i(1 if placed else 0),
+                                                          _i(m), nf, ns, nsets, nturns, _i(int(stages)), rect, _stream()), 'kbe_render_frame_group_ahead')
+        return out
+
     def video_launch_shape(self, state, cameras, batch, to_host=False):
         """(flags of kbe_render_video, frames per launch, fused route?) for a video of `cameras`.
         KBE_VIDEO_FILL_DIST, the table-driven hole fill: for videos whose frames have hundreds of thousands of holes -- a
@@ -495,6 +521,8 @@ class HipKernels:
             flags |= 8
         if os.environ.get('KBE_EVEN_GROUPS') == '1':        # (dev) transfer groups of one size instead of the ramp 1, 2, 4, ...
             flags |= 16
+        if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
+            flags |= 512
         scratch = state['scratch']
         if group > 1:
             scratch, _ = self.group_scratch(state, group * lanes)      # n sets per lane in use, allocated on first use (224 MB each at 1024^2)

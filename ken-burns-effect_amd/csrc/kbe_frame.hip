@@ -47,13 +47,14 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += stride) { zkeys[i] = KBE_ZKEY_EMPTY; if (zkeys_b) zkeys_b[i] = KBE_ZKEY_EMPTY; }
     for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
-    if (gtid == 0) { hole_count[0] = 0; hole_count[1] = 0; hole_count[2] = 0; hole_count[3] = 0; }
+    if (gtid < (size_t) HOLE_COUNT_INTS) hole_count[gtid] = 0;
 }
 
-// the hole counters / list totals (4 ints) of `n` scratch sets `stride` bytes apart
+// the hole counters / list totals (HOLE_COUNT_INTS ints) of `n` scratch sets `stride` bytes apart
 __global__ void k_zero_counters(int* first, size_t stride, int n)
 {
-    for (int k = threadIdx.x; k < 4 * n; k += blockDim.x) ((int*) ((char*) first + (size_t) (k >> 2) * stride))[k & 3] = 0;
+    static_assert(HOLE_COUNT_INTS == 8, "k >> 3, k & 7");
+    for (int k = threadIdx.x; k < HOLE_COUNT_INTS * n; k += blockDim.x) ((int*) ((char*) first + (size_t) (k >> 3) * stride))[k & 7] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -790,8 +791,9 @@ int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
 {
     KBE_REQUIRE(scratch && W > 0 && H > 0 && ((uintptr_t) scratch & 15) == 0, "kbe_frame_scratch_init: bad arguments");
     const Scratch sc = carve(scratch, W, H);
+    // (both banks of counters: 4 * n_tiles * CNT_STRIDE bytes is a multiple of 16, so the banks are contiguous)
     hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, (hipStream_t) stream, sc.zkeys, sc.zkeys_b, (size_t) W * H, sc.tile_count,
-                       sc.tiles_x * sc.tiles_y, sc.hole_count);
+                       2 * sc.tiles_x * sc.tiles_y, sc.hole_count);
     return launched("kbe_frame_scratch_init");
 }
 
@@ -926,11 +928,11 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     if (parity < 0 && !(stages & KBE_STAGE_KEEP_HOLE_COUNT)) {
         // a frame on its own: the caller keeps no frame parity, so the hole counters (and the binning launch's flags behind
         // them) are zeroed in front of the launch
-        const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 4 * sizeof(int), s);
+        const hipError_t e = hipMemsetAsync(sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
         if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_fused: hipMemsetAsync", e);
     }
     if (stages & KBE_STAGE_TILES) {
-        const FusedTarget t = { cam, sc, scratch_place(scratch, W, H), parity, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32 };
+        const FusedTarget t = { cam, sc, scratch_place(scratch, W, H), parity, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32, -1 };
         launch_frames_fused(s, 1, packed, N, cloud_focal, &t);
         if ((rc = launched("kbe_render_frame_fused/scatter"))) return rc;
     }
@@ -964,10 +966,10 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
         const Scratch sc = carve(scratch[k], W, H);
         n_tiles = sc.tiles_x * sc.tiles_y;
         if (par < 0 && !(stages & KBE_STAGE_KEEP_HOLE_COUNT)) {
-            const hipError_t e = hipMemsetAsync(sc.hole_count, 0, 4 * sizeof(int), s);
+            const hipError_t e = hipMemsetAsync(sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_fused: hipMemsetAsync", e);
         }
-        ft[k] = FusedTarget{ make_camera(W, H, focals[k], baseline, shifts + 3 * (size_t) k), sc, scratch_place(scratch[k], W, H), par, frames_u8[k], nullptr, nullptr, nullptr, nullptr };
+        ft[k] = FusedTarget{ make_camera(W, H, focals[k], baseline, shifts + 3 * (size_t) k), sc, scratch_place(scratch[k], W, H), par, frames_u8[k], nullptr, nullptr, nullptr, nullptr, -1 };
         targets[k] = FillTarget{ sc, sc.hole_count + (par == 1 ? 1 : 0), frames_u8[k], nullptr, 0, par >= 0 ? sc.hole_count + (par == 1 ? 0 : 1) : nullptr };
     }
     if (stages & KBE_STAGE_TILES) {
@@ -980,6 +982,66 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
         for (int k0 = 0; k0 < n_frames; k0 += KBE_FILL_JOBS)       // the fill takes KBE_FILL_JOBS frames per launch
             launch_fill(s, n_frames - k0 < KBE_FILL_JOBS ? n_frames - k0 : KBE_FILL_JOBS, targets + k0, W, H, stages, dirs, rect, n_tiles);
         rc = launched("kbe_render_frame_group_fused/fill");
+    }
+    return rc;
+}
+
+int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_next)
+{
+    return (N >= 0 && W > 0 && H > 0 && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && n_next >= 1 && n_next <= KBE_FRAME_JOBS &&
+            fused_can_place_ahead(N, W, H, n_frames, n_next)) ? 1 : 0;
+}
+
+int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames, const double* focals,
+                                 const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* turns, int placed, int n_next,
+                                 const double* next_focals, const float* next_shifts, void* const* next_scratch, const int* next_turns, int stages,
+                                 const int* fill_rect, kbe_stream_t stream)
+{
+    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && turns && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+                (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_ahead: bad arguments");
+    KBE_REQUIRE(n_next >= 0 && n_next <= KBE_FRAME_JOBS && (n_next == 0 || (next_focals && next_shifts && next_scratch && next_turns)), "kbe_render_frame_group_ahead: bad next group");
+    KBE_REQUIRE(n_next == 0 || fused_can_place_ahead(N, W, H, n_frames, n_next), "kbe_render_frame_group_ahead: too many placements for the tile launch (kbe_render_frame_group_ahead_ok)");
+    static const FillDirs dirs = make_fill_dirs();
+    const hipStream_t s = (hipStream_t) stream;
+    FusedTarget ft[KBE_FRAME_JOBS], nt[KBE_FRAME_JOBS];
+    FillTarget targets[KBE_FRAME_JOBS];
+    int n_tiles = 0, rc = KBE_OK;
+    for (int k = 0; k < n_frames; k++) {
+        KBE_REQUIRE(scratch[k] && frames_u8[k] && ((uintptr_t) scratch[k] & 15) == 0 && turns[k] >= 0, "kbe_render_frame_group_ahead: bad scratch / frame pointer / turn");
+        for (int j = 0; j < k; j++) KBE_REQUIRE(scratch[j] != scratch[k], "kbe_render_frame_group_ahead: the frames of a group need scratch sets of their own");
+        const Scratch sc = carve(scratch[k], W, H);
+        n_tiles = sc.tiles_x * sc.tiles_y;
+        const int par = turns[k] & 1;
+        if (turns[k] == 0 && !placed) {
+            // a set's first turn: its hole counters and list totals start from zero (as a frame on its own zeroes them)
+            const hipError_t e = hipMemsetAsync(sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
+        }
+        ft[k] = FusedTarget{ make_camera(W, H, focals[k], baseline, shifts + 3 * (size_t) k), sc, scratch_place(scratch[k], W, H), par, frames_u8[k], nullptr, nullptr, nullptr, nullptr, turns[k] };
+        targets[k] = FillTarget{ sc, sc.hole_count + par, frames_u8[k], nullptr, 0, sc.hole_count + (par ^ 1) };
+    }
+    for (int k = 0; k < n_next; k++) {
+        KBE_REQUIRE(next_scratch[k] && ((uintptr_t) next_scratch[k] & 15) == 0 && next_turns[k] >= 0, "kbe_render_frame_group_ahead: bad scratch / turn of the next group");
+        for (int j = 0; j < k; j++) KBE_REQUIRE(next_scratch[j] != next_scratch[k], "kbe_render_frame_group_ahead: the frames of a group need scratch sets of their own");
+        for (int j = 0; j < n_frames; j++)
+            KBE_REQUIRE(next_scratch[k] != scratch[j] || next_turns[k] == turns[j] + 1, "kbe_render_frame_group_ahead: a set used by both groups takes consecutive turns");
+        nt[k] = FusedTarget{ make_camera(W, H, next_focals[k], baseline, next_shifts + 3 * (size_t) k), carve(next_scratch[k], W, H), scratch_place(next_scratch[k], W, H),
+                             next_turns[k] & 1, nullptr, nullptr, nullptr, nullptr, nullptr, next_turns[k] };
+        if (next_turns[k] == 0) {       // a set that joins the sequence with the next group: zeroed before its placements count in it
+            const hipError_t e = hipMemsetAsync(nt[k].sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
+        }
+    }
+    if (stages & KBE_STAGE_TILES) {
+        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt);
+        if ((rc = launched("kbe_render_frame_group_ahead/scatter"))) return rc;
+    }
+    if (stages & KBE_STAGE_FILL) {
+        FillRect rect = { 0, 0, W - 1, H - 1 };
+        if (fill_rect) { rect.x0 = fill_rect[0]; rect.y0 = fill_rect[1]; rect.x1 = fill_rect[2]; rect.y1 = fill_rect[3]; }
+        for (int k0 = 0; k0 < n_frames; k0 += KBE_FILL_JOBS)
+            launch_fill(s, n_frames - k0 < KBE_FILL_JOBS ? n_frames - k0 : KBE_FILL_JOBS, targets + k0, W, H, stages, dirs, rect, n_tiles);
+        rc = launched("kbe_render_frame_group_ahead/fill");
     }
     return rc;
 }
@@ -1038,7 +1100,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     const int wide_group = ((flags >> 5) & 15) + 1;
     const int group = batch <= 0 ? (wide_group > 1 ? wide_group : ((flags >> 1) & 3) + 1) : 1;
     KBE_REQUIRE(group <= (packed ? KBE_FRAME_JOBS : KBE_FILL_JOBS), "kbe_render_video: more frames per launch than the route's launches take");
-    const bool pairs = group > 1;
+    // the fused route always takes the group form (one frame per launch is a group of one): its tile launches also make the
+    // placements of the lane's NEXT group (launch_frames_fused) unless KBE_VIDEO_NO_AHEAD says otherwise
+    const bool pairs = group > 1 || (packed && batch <= 0);
     // Frames are independent, so consecutive frames go to `lanes` HIP streams, each with its own scratch and raw
     // frame: the fixed cost of a kernel boundary on this chip (launch ramp, tail, and the L2 write-back between
     // dependent kernels) is then paid while another frame's kernels run.
@@ -1159,8 +1223,20 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     static const FillDirs fill_dirs = make_fill_dirs();
     int set_frames[KBE_MAX_LANES][KBE_FRAME_JOBS] = {}, set_total[KBE_MAX_LANES][KBE_FRAME_JOBS] = {};
     bool counting = false;
+    // the calls of every lane in order (noted by the counting pass): the fused route's tile launch of a group also makes the
+    // placements of the lane's next group
+    struct GroupCall { int count; int idx[KBE_FRAME_JOBS]; };
+    std::vector<GroupCall> lane_calls[KBE_MAX_LANES];
+    size_t lane_pos[KBE_MAX_LANES] = {};
+    bool lane_placed[KBE_MAX_LANES] = {};
     auto render_group = [&](int l, int count, const int* idx, uint8_t* const* outs) {
-        if (counting) { for (int j = 0; j < count; j++) set_total[l][j]++; return (int) KBE_OK; }
+        if (counting) {
+            GroupCall c = {};
+            c.count = count;
+            for (int j = 0; j < count; j++) { set_total[l][j]++; c.idx[j] = idx[j]; }
+            lane_calls[l].push_back(c);
+            return (int) KBE_OK;
+        }
         const int fill_flags = (lanes * group >= KBE_FILL_BY_COUNT_MIN_LANES ? KBE_STAGE_FILL_BY_COUNT : 0) | ((flags & KBE_VIDEO_FILL_DIST) ? KBE_STAGE_FILL_DIST : 0);
         uint8_t* raws[KBE_FRAME_JOBS];
         int rc = KBE_OK;
@@ -1186,11 +1262,25 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 raws[j] = stage + (size_t) (KBE_FRAME_JOBS * l + j) * fb;
                 uint8_t* const target = crop ? raws[j] : outs[j];
                 const Scratch sc = carve(scr, W, H);
-                ft[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), sc, scratch_place(scr, W, H), k & 1, target, nullptr, nullptr, nullptr, nullptr };
+                ft[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), sc, scratch_place(scr, W, H), k & 1, target, nullptr, nullptr, nullptr, nullptr, k };
                 targets[j] = FillTarget{ sc, sc.hole_count + (k & 1), target, nullptr, 0, sc.hole_count + ((k & 1) ^ 1) };
             }
             if (count == 0) return rc;
-            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft);
+            // the lane's next group: its placements ride in this group's tile launch (set j then takes its next turn)
+            FusedTarget nt[KBE_FRAME_JOBS];
+            int n_next = 0;
+            const size_t pos = lane_pos[l]++;
+            if (!(flags & KBE_VIDEO_NO_AHEAD) && pos + 1 < lane_calls[l].size() && fused_can_place_ahead(N, W, H, count, lane_calls[l][pos + 1].count)) {
+                const GroupCall& nc = lane_calls[l][pos + 1];
+                n_next = nc.count;
+                for (int j = 0; j < n_next; j++) {
+                    const int i = nc.idx[j], k = set_frames[l][j];
+                    char* const scr = (char*) scratch + (size_t) (group * l + j) * sb;
+                    nt[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), carve(scr, W, H), scratch_place(scr, W, H), k & 1, nullptr, nullptr, nullptr, nullptr, nullptr, k };
+                }
+            }
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt);
+            lane_placed[l] = n_next > 0;
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };
             if (crop) { fr.x0 = rect[0]; fr.y0 = rect[1]; fr.x1 = rect[2]; fr.y1 = rect[3]; }
@@ -1257,7 +1347,11 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 counting = true;
                 for (int g = 0; g < n_groups; g++) {
                     const int l = g % lanes, nb = group_start[g + 1] - group_start[g];
-                    for (int k = 0; k < nb; k += group) (void) render_group(l, nb - k < group ? nb - k : group, nullptr, nullptr);
+                    for (int k = 0; k < nb; k += group) {
+                        int idx[KBE_FRAME_JOBS], count = 0;
+                        for (int m = 0; m < group && k + m < nb; m++) idx[count++] = group_start[g] + k + m;
+                        (void) render_group(l, count, idx, nullptr);
+                    }
                 }
                 counting = false;
             }

@@ -52,15 +52,14 @@ struct Placement { float ox, oy, err; };     // 12 bytes per point and frame; ox
 static_assert(sizeof(Placement) == 12, "placement record");
 constexpr float PLACE_NONE = -1.0e9f;        // no image position is that large (project_xy drops |ox| >= 1e9)
 
-struct FrameArgs {
-    PackedCloud pc;
+struct FrameArgs {          // a frame of a tile launch (the cloud is the launch's: FrameJobsT::pc)
     Camera cam;
     int tiles_x, tiles_y;
-    const Placement* place; // [Np]  this frame's placements (k_place)
-    int* tile_count;        // [n_tiles * CNT_STRIDE]: candidates listed per tile (k_place counts, k_frame zeroes its own)
+    const Placement* place; // [Np]  this frame's placements (k_place, or the previous tile launch on the set: place_ahead)
+    int* tile_count;        // [n_tiles * CNT_STRIDE]: candidates listed per tile (the placement counts, k_frame zeroes its own)
     const int* cand;        // [n_tiles][LIST_CAP]
-    const unsigned* bin_flag;       // this frame's total of wide list entries (k_place; beyond the budget the lists are not complete) ...
-    unsigned* bin_flag_next;        // ... and the next frame's, zeroed here
+    const unsigned* bin_flag;       // this frame's total of wide list entries (beyond the budget the lists are not complete) ...
+    unsigned* bin_flag_next;        // ... and the total a LATER frame of the set will count in, zeroed here
     uint8_t* frame;         // [H,W,3]
     float* depth;           // [H*W]
     uint32_t* mask;         // [H][ceil(W/32)]
@@ -75,15 +74,23 @@ struct FrameArgs {
     float4* spill;          // [n_tiles][BUCKET_STRIDE]: where a tile's records beyond REC_CAP wait for their round
 };
 
-struct PlaceArgs {
-    PackedCloud pc;
+struct PlaceArgs {          // the placement of one frame: its camera, and where its placements and candidate lists go
     Camera cam;
-    int tiles_x, tiles_y;
     Placement* place;
     int* tile_count;
     int* cand;
     unsigned* bin_flag;     // running total of the wide sub-blocks' list entries (beyond the budget: the lists are abandoned)
 };
+
+// what a tile launch takes: the cloud, up to J frames to render, and up to J frames whose placements it makes AHEAD -- the
+// work of k_place for the frames the NEXT tile launch on this stream renders (they use the other bank of their scratch sets)
+template <int J> struct FrameJobsT {
+    PackedCloud pc;
+    int n_next, pad_;
+    FrameArgs a[J];
+    PlaceArgs nx[J];
+};
+static_assert(sizeof(FrameJobsT<KBE_FRAME_JOBS>) <= 4096, "a launch takes 4 KB of kernel arguments");
 
 struct FrameLds {
     TileLds T;
@@ -152,7 +159,7 @@ __device__ unsigned long long g_frame_stats[8];     // tiles, list entries writt
 // take no part in the box.  The order of a list's entries is the order the atomics retire in: it only decides the order of
 // the fp32 sums, as the bucket order does on the other route.
 // ---------------------------------------------------------------------------------------
-struct PlaceJobs { PlaceArgs a[KBE_FRAME_JOBS]; };
+struct PlaceJobs { PackedCloud pc; int tiles_x, tiles_y; PlaceArgs a[KBE_FRAME_JOBS]; };
 
 // minimum over the 16 lanes of a DPP row, left in every lane of the row: four v_min_i32 that read their second operand
 // through the DPP cross-lane path (the compiler's own rendering of the same steps is a copy, a DPP copy and a min each).
@@ -166,14 +173,14 @@ __device__ __forceinline__ int row_min(int v)
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
+// one point of a frame's placement, lane `lane` of a wave whose 64 lanes hold 64 consecutive points (four sub-blocks): point i = `p`.
+// In two steps, so that a caller can do other work while the list atomic is under way: place_point_begin returns the list entry
+// the lane owes -- the tile and the slot its atomic returned -- and place_point_end writes it.
+struct ListSlot { int t, pos; };
+__device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
+                                                      int* tile_count, int* cand_lists, unsigned* bin_flag)
 {
-    const PlaceArgs& a = jobs.a[blockIdx.y];
-    const Camera& cam = a.cam;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // Np is a multiple of 64: whole waves only
-    if (i >= a.pc.Np) return;
-    const int lane = threadIdx.x & 63;
-    const CloudPoint p = a.pc.pd[i];
+    ListSlot owed = { -1, 0 };
     float x = p.x, y = p.y, z = p.z, ox = 0.0f, oy = 0.0f;
     apply_shift(cam, x, y, z);
     bool ok = project_xy(cam, x, y, z, ox, oy);
@@ -183,21 +190,21 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
     pl.ox = ok ? ox : PLACE_NONE;
     pl.oy = ok ? oy : PLACE_NONE;
     pl.err = project_err_fast(cam, ok ? z : 1024.0f);
-    a.place[i] = pl;
+    place[i] = pl;
 
     // the tiles the sub-block reaches: per lane the first and last tile its point matters to (monotone in the corner, so the
     // minimum / maximum over the row are those of the box); lanes that are out take no part
     static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "tile sizes are powers of two");
     constexpr int BIG = 1 << 24;
-    const int tx0 = max(row_min(ok ? (nwx - 1) >> __builtin_ctz(TW) : BIG), 0), tx1 = min(-row_min(ok ? -((nwx + 2) >> __builtin_ctz(TW)) : BIG), a.tiles_x - 1);
-    const int ty0 = max(row_min(ok ? (nwy - 1) >> __builtin_ctz(TH) : BIG), 0), ty1 = min(-row_min(ok ? -((nwy + 2) >> __builtin_ctz(TH)) : BIG), a.tiles_y - 1);
+    const int tx0 = max(row_min(ok ? (nwx - 1) >> __builtin_ctz(TW) : BIG), 0), tx1 = min(-row_min(ok ? -((nwx + 2) >> __builtin_ctz(TW)) : BIG), tiles_x - 1);
+    const int ty0 = max(row_min(ok ? (nwy - 1) >> __builtin_ctz(TH) : BIG), 0), ty1 = min(-row_min(ok ? -((nwy + 2) >> __builtin_ctz(TH)) : BIG), tiles_y - 1);
     const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;               // uniform over the row; no point in: tx0 = BIG, w < 0
     const bool some = w > 0 && h > 0;
     const int sub = i / kCloudSub, j = lane & (kCloudSub - 1);
     auto list_for = [&](int tx, int ty) {
-        const int t = __mul24(ty, a.tiles_x) + tx;
-        const int pos = atomicAdd(&a.tile_count[(uint32_t) t * CNT_STRIDE], 1);
-        if (pos < LIST_CAP) a.cand[(size_t) t * LIST_CAP + pos] = sub;         // beyond: the tile sees count > LIST_CAP and scans
+        const int t = __mul24(ty, tiles_x) + tx;
+        const int pos = atomicAdd(&tile_count[(uint32_t) t * CNT_STRIDE], 1);
+        if (pos < LIST_CAP) cand_lists[(size_t) t * LIST_CAP + pos] = sub;     // beyond: the tile sees count > LIST_CAP and scans
     };
     if (some && w <= 4 && h <= 4) {
         // the usual box of one to four tiles (at most 4 x 4): lane j of the row takes tile (j & 3, j >> 2) of it -- one
@@ -205,7 +212,10 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
 #if defined(KBE_FRAME_STATS)
         if (j == 0) atomicAdd(&g_frame_stats[1], (unsigned long long) (w * h));
 #endif
-        if ((j & 3) < w && (j >> 2) < h) list_for(tx0 + (j & 3), ty0 + (j >> 2));
+        if ((j & 3) < w && (j >> 2) < h) {
+            owed.t = __mul24(ty0 + (j >> 2), tiles_x) + tx0 + (j & 3);
+            owed.pos = atomicAdd(&tile_count[(uint32_t) owed.t * CNT_STRIDE], 1);
+        }
     } else if (some) {
         // a larger box: its points scatter.  Beyond BIN_WIDE_FAN tiles it is counted against the frame's budget by the row's
         // first lane (the look first keeps the total from running away once it is spent); beyond the budget the lists are
@@ -213,10 +223,10 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
         const int fan = w * h;
         bool listing = true;
         if (fan > BIN_WIDE_FAN) {
-            const unsigned budget = bin_budget(a.tiles_x, a.tiles_y);
+            const unsigned budget = bin_budget(tiles_x, tiles_y);
             int go = 0;
-            if (j == 0 && __hip_atomic_load(a.bin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= budget)
-                go = atomicAdd(a.bin_flag, (unsigned) fan) + (unsigned) fan <= budget;
+            if (j == 0 && __hip_atomic_load(bin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= budget)
+                go = atomicAdd(bin_flag, (unsigned) fan) + (unsigned) fan <= budget;
             listing = __shfl(go, lane & ~(kCloudSub - 1)) != 0;
         }
 #if defined(KBE_FRAME_STATS)
@@ -225,6 +235,24 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
         if (listing)
             for (int k = j; k < fan; k += kCloudSub) { const int r = k / w; list_for(tx0 + (k - r * w), ty0 + r); }
     }
+    return owed;
+}
+__device__ __forceinline__ void place_point_end(const ListSlot& owed, int i, int* cand_lists)
+{
+    if (owed.t >= 0 && owed.pos < LIST_CAP) cand_lists[(size_t) owed.t * LIST_CAP + owed.pos] = i / kCloudSub;     // beyond: the tile sees count > LIST_CAP and scans
+}
+__device__ __forceinline__ void place_point(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
+                                            int* tile_count, int* cand_lists, unsigned* bin_flag)
+{
+    place_point_end(place_point_begin(p, i, lane, cam, tiles_x, tiles_y, place, tile_count, cand_lists, bin_flag), i, cand_lists);
+}
+
+__global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
+{
+    const PlaceArgs& a = jobs.a[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // Np is a multiple of 64: whole waves only
+    if (i >= jobs.pc.Np) return;
+    place_point(jobs.pc.pd[i], i, threadIdx.x & 63, a.cam, jobs.tiles_x, jobs.tiles_y, a.place, a.tile_count, a.cand, a.bin_flag);
 }
 
 // what a pass over candidate blocks does with each point
@@ -259,9 +287,63 @@ struct TileOut {
 // parked sixteen of them in a vector register and fetched them back in every trip of the splat loop.  Making the pointer
 // opaque between the phases has each phase load what it needs when it starts.
 typedef const __attribute__((address_space(4))) FrameArgs* FrameArgsPtr;
+typedef const __attribute__((address_space(4))) PlaceArgs* PlaceArgsPtr;
+typedef const __attribute__((address_space(4))) PackedCloud* PackedCloudPtr;
 
-__device__ __forceinline__ void frame_body(FrameArgsPtr ap)
+// where in the tile's life its share of the NEXT frames' placements is made (place_ahead below): 0 = at the end, behind the
+// epilogue's stores; 1 = behind the splat, in front of the barrier that ends it; 2, 3 = the first KBE_AHEAD_UNITS units of a
+// wave up front -- their points requested with the tile's list, placed while the tile's own points are under way, the list
+// entries written in front of (2) or behind (3) the splat -- and what is left at the end
+#ifndef KBE_AHEAD_AT
+#define KBE_AHEAD_AT 3
+#endif
+#ifndef KBE_AHEAD_UNITS
+#define KBE_AHEAD_UNITS 3
+#endif
+constexpr int AHEAD_UNITS = KBE_AHEAD_AT >= 2 ? KBE_AHEAD_UNITS : 0;
+
+__device__ __forceinline__ Camera load_camera(const __attribute__((address_space(4))) Camera* c)
 {
+    Camera cam;
+    cam.focal_f = c->focal_f; cam.fb_f = c->fb_f; cam.fb = c->fb; cam.half_w = c->half_w; cam.half_h = c->half_h;
+    cam.cx_f = c->cx_f; cam.cy_f = c->cy_f; cam.fp32_centre = c->fp32_centre; cam.W = c->W; cam.H = c->H;
+    cam.has_shift = c->has_shift; cam.sx = c->sx; cam.sy = c->sy; cam.sz = c->sz;
+    return cam;
+}
+
+// The placements of the frames the NEXT tile launch renders -- k_place's work -- spread over the waves of this launch: row
+// blockIdx.y takes frames blockIdx.y, blockIdx.y + gridDim.y, ... of `nx`, its waves the frames' units of 64 points in turn.
+// k_place alone is a streaming launch that waits for memory 70 % of its life (the point, then its list slots); k_frame is bound
+// by instruction issue: one launch lets the one's waits hide under the other's arithmetic whatever else the chip is doing.
+__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane)
+{
+    const CloudPoint* const pd = pcp->pd;
+    const int n_units = pcp->Np / kCloudBlock;
+    const int first = blockIdx.x * (TILE_THREADS / 64) + wave, step = gridDim.x * (TILE_THREADS / 64);
+    for (int j = blockIdx.y; j < n_next; j += gridDim.y) {             // uniform
+        PlaceArgsPtr a = nx + j;
+        const Camera cam = load_camera(&a->cam);
+        Placement* const place = a->place;
+        int* const tile_count = a->tile_count;
+        int* const cand = a->cand;
+        unsigned* const bin_flag = a->bin_flag;
+        const int u0 = first + (j == (int) blockIdx.y ? AHEAD_UNITS * step : 0);      // (the row's first frame: its first units were placed up front)
+        if (u0 >= n_units) continue;
+        CloudPoint p = pd[u0 * kCloudBlock + lane];
+        for (int u = u0; u < n_units; u += step) {                      // wave-uniform; the next unit's point requested before this one is worked on
+            const CloudPoint q = p;
+            const int un = u + step < n_units ? u + step : u;
+            p = pd[un * kCloudBlock + lane];
+            place_point(q, u * kCloudBlock + lane, lane, cam, tiles_x, tiles_y, place, tile_count, cand, bin_flag);
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void frame_body(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
+{
+    FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
+    PackedCloudPtr pcp = &jp->pc;
     __shared__ FrameLds F;
     TileLds& L = F.T;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -288,8 +370,8 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
     const bool wide = *ap->bin_flag > bin_budget(tiles_x, tiles_y);
     const int* const my_list = ap->cand + (size_t) tile * LIST_CAP;
     const Placement* const place = ap->place;
-    const CloudColour* const colours = ap->pc.col;
-    const uint32_t last_sub = (uint32_t) (ap->pc.Np / kCloudSub) - 1u;
+    const CloudColour* const colours = pcp->col;
+    const uint32_t last_sub = (uint32_t) (pcp->Np / kCloudSub) - 1u;
     float4* const spill = ap->spill + (size_t) tile * BUCKET_STRIDE;
     Placement pl[DEPTH]; CloudColour cc[DEPTH]; int ix[DEPTH], ent[DEPTH];
     auto fetch_entries = [&](int st0) {
@@ -305,6 +387,25 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
         }
     };
     fetch_entries(wave);
+#if KBE_AHEAD_AT >= 2
+    // the points of this wave's first units of the NEXT frame's placement, requested with the list (unconditionally, the
+    // addresses clamped: a launch that places nothing reads the cloud's first block)
+    const int n_next = jp->n_next;
+    const bool ahead = (int) blockIdx.y < n_next;                       // uniform: this row has a frame to place
+    const int a_units = ahead ? pcp->Np / kCloudBlock : 1;
+    const int a_first = blockIdx.x * WAVES + wave, a_step = gridDim.x * WAVES;
+    CloudPoint a_pt[AHEAD_UNITS];
+    ListSlot a_owed[AHEAD_UNITS];
+#pragma unroll
+    for (int d = 0; d < AHEAD_UNITS; d++) a_pt[d] = pcp->pd[min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane];
+    auto ahead_finish = [&]() {
+        if (ahead) {
+            int* const cand_next = ((PlaceArgsPtr) jp->nx + blockIdx.y)->cand;
+#pragma unroll
+            for (int d = 0; d < AHEAD_UNITS; d++) place_point_end(a_owed[d], (a_first + d * a_step) * kCloudBlock + lane, cand_next);
+        }
+    };
+#endif
     for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
     for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
     if (tid == 0) {
@@ -314,8 +415,24 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
         if (blockIdx.x == 0) *ap->bin_flag_next = 0;
     }
     fetch_points();                                     // in flight across the barrier
+#if KBE_AHEAD_AT >= 2
+    // ... and placed while the tile's own points are under way; the list atomics return during the splat
+#pragma unroll
+    for (int d = 0; d < AHEAD_UNITS; d++) a_owed[d] = ListSlot{ -1, 0 };
+    if (ahead) {
+        PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
+        const Camera ncam = load_camera(&na->cam);
+#pragma unroll
+        for (int d = 0; d < AHEAD_UNITS; d++)
+            if (a_first + d * a_step < a_units)
+                a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag);
+    }
+#endif
     const bool listed = !wide & (count <= LIST_CAP);            // uniform
     __syncthreads();
+#if KBE_AHEAD_AT == 2
+    ahead_finish();
+#endif
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
     KBE_STOP_AFTER(1);                                          // (dev) the list
@@ -399,6 +516,12 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
             if (more) fetch_points();
         }
     }
+#if KBE_AHEAD_AT == 1
+    { const int n_next = jp->n_next; if (n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane); }
+#endif
+#if KBE_AHEAD_AT == 3
+    ahead_finish();
+#endif
     __syncthreads();
     KBE_STOP_AFTER(3);                                          // (dev) + the splat
 
@@ -489,7 +612,7 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
         // prefix sums, and runs of at most REC_CAP records: insert, colours, gather.
         const FrameArgs* const gp = (const FrameArgs*) ap;      // (struct copies want a generic pointer)
         const Camera cam = gp->cam;
-        const PackedCloud pc = gp->pc;
+        const PackedCloud pc = *(const PackedCloud*) pcp;
         const int n_blocks = pc.count[0];
         CullView q;
         q.g = cam.focal_f / pc.fd;
@@ -604,9 +727,14 @@ __device__ __forceinline__ void frame_body(FrameArgsPtr ap)
     (void) total;
 #endif
     tile_epilogue(a, L, acc, tile, x0, y0);
+#if KBE_AHEAD_AT != 1
+    asm volatile("" : "+s"(jp) :: "memory");
+    { const int n_next = jp->n_next; if (n_next > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_next, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane); }
+#endif
 }
 
-struct FrameJobs { FrameArgs a[KBE_FRAME_JOBS]; };
+typedef FrameJobsT<1> FrameJob1;
+typedef FrameJobsT<KBE_FRAME_JOBS> FrameJobs;
 
 // five workgroups per CU (32 KB of LDS each; 96 registers per lane, a few of the gather's spilled): with the tile's list read
 // straight into registers the LDS allows it, and a fifth wave per SIMD covers more of the others' waits than the spills cost
@@ -615,45 +743,77 @@ struct FrameJobs { FrameArgs a[KBE_FRAME_JOBS]; };
 #endif
 #define KBE_FRAME_ATTR amdgpu_waves_per_eu(KBE_FRAME_WAVES, KBE_FRAME_WAVES)
 
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame(FrameArgs)
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame(FrameJob1)
 {
-    frame_body((FrameArgsPtr) __builtin_amdgcn_kernarg_segment_ptr());                          // the one argument, at offset 0
+    frame_body<1>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);    // the one argument, at offset 0
 }
 
 // several frames of the same cloud and size per launch (blockIdx.y = the frame), as the bucket route's grouped launches
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group(FrameJobs)
 {
-    frame_body((FrameArgsPtr) __builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y);
+    frame_body<KBE_FRAME_JOBS>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
 }
 
 }  // namespace
 
 namespace kbe {
-// the scatter of n <= KBE_FRAME_JOBS frames of the same packed cloud and frame size: one placement launch and one tile launch,
-// each taking all n frames (frame k: its camera, scratch set, placement array, and hole counter / list total pair by parity)
-void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t)
+// Can the tile launch of n frames make the placements of n_next frames without outliving its own work?  Its waves share them:
+// up to a few units of 64 points per wave.  (A cloud much denser than the raster keeps the placement launch of its own.)
+#ifndef KBE_AHEAD_MAX_UNITS
+#define KBE_AHEAD_MAX_UNITS 6
+#endif
+bool fused_can_place_ahead(int N, int W, int H, int n, int n_next)
+{
+    if (n < 1 || n_next < 1) return false;
+    const size_t units = (size_t) cloud_layout_base(N).Np / kCloudBlock * (size_t) n_next;
+    const size_t waves = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * (TILE_THREADS / 64) * (size_t) n;
+    return units <= (size_t) KBE_AHEAD_MAX_UNITS * waves;
+}
+
+// the scatter of n <= KBE_FRAME_JOBS frames of the same packed cloud and frame size: one placement launch (unless the frames are
+// `placed`: the previous tile launch made their placements ahead) and one tile launch, each taking all n frames (frame k: its
+// camera, scratch set, and by `parity` / `turn` the set's bank of placements and lists, hole counter and list total); the tile
+// launch also makes the placements of `next` (n_next frames: the ones the next tile launch on this stream renders)
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t, bool placed, int n_next, const FusedTarget* next)
 {
     PlaceJobs pj;
     FrameJobs fj;
     const PackedCloud pc = cloud_open(packed, N, cloud_focal);
     unsigned n_tiles = 0;
+    auto bank_of = [](const FusedTarget& f) { return f.parity == 1 ? 1 : 0; };
+    // the set's list totals: frames with placements in front of them alternate between two (read [par], zero [par ^ 1] for the
+    // next); in a sequence that places ahead the frame of turn k reads [k % 3], the placement for turn k + 1 counts in
+    // [(k + 1) % 3] during the same launch, and [(k + 2) % 3] -- read last by turn k - 1 -- is zeroed
+    auto flag_of = [](const FusedTarget& f) { return 2 + (f.turn >= 0 ? f.turn % 3 : (f.parity == 1 ? 1 : 0)); };
+    auto flag_zeroed_by = [](const FusedTarget& f) { return 2 + (f.turn >= 0 ? (f.turn + 2) % 3 : (f.parity == 1 ? 0 : 1)); };
+    auto place_args = [&](const FusedTarget& f) {
+        PlaceArgs b;
+        b.cam = f.cam; b.place = (Placement*) bank_place(f.place, N, bank_of(f)); b.tile_count = bank_tile_count(f.sc, bank_of(f)); b.cand = bank_cand(f.sc, bank_of(f));
+        b.bin_flag = (unsigned*) f.sc.hole_count + flag_of(f);
+        return b;
+    };
+    pj.pc = pc; fj.pc = pc; fj.n_next = n_next; fj.pad_ = 0;
     for (int k = 0; k < KBE_FRAME_JOBS; k++) {
         const FusedTarget& f = t[k < n ? k : 0];
         const Scratch& sc = f.sc;
         n_tiles = (unsigned) (sc.tiles_x * sc.tiles_y);
+        pj.tiles_x = sc.tiles_x; pj.tiles_y = sc.tiles_y;
         const int par = f.parity == 1 ? 1 : 0;
-        PlaceArgs& b = pj.a[k];
-        b.pc = pc; b.cam = f.cam; b.tiles_x = sc.tiles_x; b.tiles_y = sc.tiles_y; b.place = (Placement*) f.place; b.tile_count = sc.tile_count; b.cand = sc.cand;
-        b.bin_flag = (unsigned*) sc.hole_count + 2 + par;
+        pj.a[k] = place_args(f);
         FrameArgs& a = fj.a[k];
-        a.pc = pc; a.cam = f.cam; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y; a.place = (const Placement*) f.place;
-        a.tile_count = sc.tile_count; a.cand = sc.cand; a.bin_flag = (const unsigned*) sc.hole_count + 2 + par; a.bin_flag_next = (unsigned*) sc.hole_count + 2 + (par ^ 1);
+        a.cam = f.cam; a.tiles_x = sc.tiles_x; a.tiles_y = sc.tiles_y; a.place = pj.a[k].place;
+        a.tile_count = pj.a[k].tile_count; a.cand = pj.a[k].cand; a.bin_flag = pj.a[k].bin_flag; a.bin_flag_next = (unsigned*) sc.hole_count + flag_zeroed_by(f);
         a.frame = f.frame_u8; a.depth = sc.depth; a.mask = sc.mask; a.holes = sc.holes; a.hole_count = sc.hole_count + par; a.bbox = sc.bbox; a.coarse = sc.coarse;
         a.render = f.render_f32; a.existing = f.existing_f32; a.zee = f.zee_f32; a.zee_pre = f.zee_pre_f32; a.spill = sc.buckets;
+        fj.nx[k] = place_args(n_next > 0 ? next[k < n_next ? k : 0] : f);
     }
-    hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
-    if (n == 1) hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, fj.a[0]);
-    else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+    if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
+    if (n == 1) {
+        FrameJob1 f1;
+        f1.pc = pc; f1.n_next = n_next > 1 ? 1 : n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
+        if (n_next > 1) hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, 1), dim3(TILE_THREADS), 0, s, fj);       // one frame that places several: the group form
+        else hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
+    } else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe

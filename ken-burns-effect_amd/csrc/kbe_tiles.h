@@ -60,14 +60,16 @@ struct Scratch {                            // carve-out of the caller's scratch
     uint8_t* dist;          // [H*W]  Chebyshev distance to the nearest valid pixel, capped (frames with very many holes: k_hole_dist)
     float2* strips;         // [16][W + H + 8]  per fill direction and line across the image: where along it valid pixels can be (k_hole_dist)
     uint8_t* dist_blocks;   // [tiles_y * TH / 8][tiles_x * TW / 8]  the same distance between 8 x 8 blocks, in blocks
-    int* tile_count;        // [n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames
-    int* hole_count;        // [4]  two hole counters (the fused route alternates them), then the fused route's two "a sub-block was too wide to list" words
+    int* tile_count;        // [2][n_tiles * CNT_STRIDE]  records appended to each bucket; 0 between frames (the second bank: fused route, below)
+    int* hole_count;        // [8]  two hole counters (the fused route alternates them), then the fused route's three "wide list entries" totals (FLAG_*)
     int4* bbox;             // [n_tiles]: per tile, x0, y0, x1, y1 of its valid pixels (inclusive; empty: x0 > x1); plain stores
     uint32_t* coarse;       // [n_tiles]: bit (cy * (TW/8) + cx) = the 8x8 block (cx, cy) of the tile holds a valid pixel
     int* holes;             // [H*W]
     float* depth;           // [H*W]  render[3] * (existing > 0): the fill compares the two ends of a ray with it
     uint32_t* mask;         // [H][ceil(W/32)]  bit = depth > 0: what the fill walks on (32x smaller than the plane)
-    int* cand;              // [n_tiles][KBE_CAND_CAP]  fused route: the sub-blocks of the packed cloud that can reach each tile (k_place)
+    int* cand;              // [2][n_tiles][KBE_CAND_CAP]  fused route: the sub-blocks of the packed cloud that can reach each tile (k_place).
+                            // TWO banks of lists, counters and placements: a tile launch can make the placements of the set's NEXT frame
+                            // (the other bank) while it renders this one (kbe_fused.hip)
     float4* buckets;        // [n_tiles][BUCKET_STRIDE]  {ox, oy, dblError, point index}
     int tiles_x, tiles_y;
 };
@@ -83,8 +85,8 @@ inline Scratch carve(void* base, int W, int H)
     s.tiles_y = (H + TH - 1) / TH;
     const size_t n_tiles = (size_t) s.tiles_x * s.tiles_y;
     s.zkeys = (uint32_t*) p;      p += align16(4 * hw);
-    s.tile_count = (int*) p;      p += align16(4 * n_tiles * CNT_STRIDE);
-    s.hole_count = (int*) p;      p += 16;
+    s.tile_count = (int*) p;      p += 2 * align16(4 * n_tiles * CNT_STRIDE);
+    s.hole_count = (int*) p;      p += 32;
     s.bbox = (int4*) p;           p += align16(16 * n_tiles);
     s.coarse = (uint32_t*) p;     p += align16(4 * n_tiles);
     s.holes = (int*) p;           p += align16(4 * hw);
@@ -94,7 +96,7 @@ inline Scratch carve(void* base, int W, int H)
     s.dist = (uint8_t*) p;        p += align16(hw);
     s.strips = (float2*) p;       p += align16(8 * 16 * (size_t) (W + H + 8));
     s.dist_blocks = (uint8_t*) p; p += align16(n_tiles * (TW / 8) * (TH / 8));
-    s.cand = (int*) p;            p += align16(4 * n_tiles * KBE_CAND_CAP);
+    s.cand = (int*) p;            p += 2 * align16(4 * n_tiles * KBE_CAND_CAP);
     s.buckets = (float4*) p;
     return s;
 }
@@ -104,14 +106,19 @@ inline size_t scratch_bytes(int W, int H)
 {
     const size_t hw = (size_t) W * H;
     const size_t n_tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return align16(4 * hw) + align16(4 * n_tiles * CNT_STRIDE) + 16 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
-           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + align16(hw) + align16(8 * 16 * (size_t) (W + H + 8)) + align16(n_tiles * (TW / 8) * (TH / 8)) + align16(4 * n_tiles * KBE_CAND_CAP) + n_tiles * BUCKET_STRIDE * sizeof(float4);
+    return align16(4 * hw) + 2 * align16(4 * n_tiles * CNT_STRIDE) + 32 + align16(16 * n_tiles) + align16(4 * n_tiles) + align16(4 * hw) + align16(4 * hw) +
+           align16(4 * (size_t) H * ((W + 31) / 32)) + align16(4 * hw) + align16(hw) + align16(8 * 16 * (size_t) (W + H + 8)) + align16(n_tiles * (TW / 8) * (TH / 8)) + 2 * align16(4 * n_tiles * KBE_CAND_CAP) + n_tiles * BUCKET_STRIDE * sizeof(float4);
 }
 
 
 size_t fused_place_bytes(int N);    // kbe_fused.hip: 12 bytes per packed point, a frame's placements {ox, oy, dblError}
-inline size_t scratch_set_bytes(int W, int H, int N) { return align16(scratch_bytes(W, H)) + (N >= 0 ? align16(fused_place_bytes(N)) : 0); }
+inline size_t scratch_set_bytes(int W, int H, int N) { return align16(scratch_bytes(W, H)) + (N >= 0 ? 2 * align16(fused_place_bytes(N)) : 0); }
 inline void* scratch_place(void* base, int W, int H) { return (char*) base + align16(scratch_bytes(W, H)); }
+// the fused route's banks of a scratch set (bank 0 / 1): counters, lists, placements
+inline int* bank_tile_count(const Scratch& s, int bank) { return (int*) ((char*) s.tile_count + (size_t) bank * align16(4 * (size_t) s.tiles_x * s.tiles_y * CNT_STRIDE)); }
+inline int* bank_cand(const Scratch& s, int bank) { return (int*) ((char*) s.cand + (size_t) bank * align16(4 * (size_t) s.tiles_x * s.tiles_y * KBE_CAND_CAP)); }
+inline void* bank_place(void* place, int N, int bank) { return (char*) place + (size_t) bank * align16(fused_place_bytes(N)); }
+constexpr int HOLE_COUNT_INTS = 8;          // ints of Scratch::hole_count: [0], [1] hole counters, [2..4] the fused route's list totals
 
 struct FillRect { int x0, y0, x1, y1; };    // inclusive; only holes inside are filled
 
@@ -148,12 +155,18 @@ int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int cro
 struct FusedTarget {
     Camera cam;
     Scratch sc;
-    void* place;            // the scratch set's placement array (fused_place_bytes(N) bytes behind its fixed part)
-    int parity;             // which of the scratch set's hole counters / list totals the frame uses (-1 = 0)
+    void* place;            // the scratch set's placement arrays (two banks of fused_place_bytes(N) bytes behind its fixed part)
+    int parity;             // which of the scratch set's hole counters and banks the frame uses (-1 = 0)
     uint8_t* frame_u8;
     float* render_f32; float* existing_f32; float* zee_f32; float* zee_pre_f32;
+    int turn;               // -1: a frame whose placements are made in front of it, list totals alternating with `parity`; k >= 0: the
+                            // k-th use of the set in a sequence that may place AHEAD (list total k % 3; parity must be k & 1)
 };
-void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* targets);
+// `placed`: the frames' placements and lists exist (made ahead by the previous tile launch on the same sets); n_next > 0: this tile
+// launch also makes those of `next` (frames that use the other bank of their sets; turn >= 0 everywhere)
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* targets, bool placed = false, int n_next = 0,
+                         const FusedTarget* next = nullptr);
+bool fused_can_place_ahead(int N, int W, int H, int n, int n_next);
 
 // blockIdx -> tile id such that each XCD (block b runs on XCD b % 8) owns a contiguous band of
 // tile rows: the records of neighbouring tiles reference neighbouring points (shared L2 lines).

@@ -457,6 +457,90 @@ def test_video_that_fills_several_frames_per_launch_equals_frames_on_their_own(K
     same(again, alone[0], 'a frame on its own after the videos')
 
 
+def test_pipelined_groups_equal_groups_with_their_placements_in_front(K):
+    """kbe_render_frame_group_ahead: the tile launch of a group makes the placements of the NEXT group (the other bank of the
+    sets' placements, lists and counters; list totals rotating over three words).  A sequence of groups of changing sizes --
+    ramping up, a set sitting out, a lone frame, twelve frames -- renders the frames of the same groups with their placement
+    launches in front (within the accumulation order), and leaves the sets clean for frames on their own."""
+    from ken_burns_effect_amd import common
+    size = (200, 312)
+    settings, oc = _scene(size, 21, 'smooth', True)
+    settings = dict(settings, dblSteps=[i / 39 for i in range(40)])
+    cams = common.frame_cameras(settings, oc)
+    state = common._prepared_cloud(K, oc)
+    K._pack(state)
+    Bl = oc['dblBaseline']
+    sizes = [1, 2, 4, 3, 12, 1, 5]
+    groups, at = [], 0
+    for n in sizes:
+        groups.append([cams[(at + k) % len(cams)] for k in range(n)])
+        at += n
+    want = []
+    for g in groups:
+        buf = torch.zeros(len(g), size[0], size[1], 3, dtype=torch.uint8, device='cuda')
+        K.render_frame_group_fused(state, g, Bl, buf)
+        want.append(buf.cpu().numpy())
+    for rep in range(2):
+        turns = [0] * 12                    # per scratch set: how often the sequence has used it
+        placed = False
+        for i, g in enumerate(groups):
+            n = len(g)
+            nxt = groups[i + 1] if i + 1 < len(groups) else None
+            ok = nxt is not None and bool(K.lib.kbe_render_frame_group_ahead_ok(state['N'], size[1], size[0], n, len(nxt)))
+            now = turns[:n]
+            for k in range(n):
+                turns[k] += 1
+            buf = torch.zeros(n, size[0], size[1], 3, dtype=torch.uint8, device='cuda')
+            K.render_frame_group_ahead(state, g, Bl, buf, turn=now, placed=placed, next_cameras=nxt if ok else None, next_turn=turns[:len(nxt)] if ok else None)
+            placed = ok
+            d = np.abs(buf.cpu().numpy().astype(np.int32) - want[i].astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, 'pass %d group %d (%d frames): max %d, %.2e differ' % (rep, i, n, d.max(), (d > 0).mean())
+        # the sets are clean: frames on their own (parity -1 zeroes the counters; the banks must be empty)
+        buf = torch.zeros(12, size[0], size[1], 3, dtype=torch.uint8, device='cuda')
+        K.render_frame_group_fused(state, groups[4], Bl, buf)
+        d = np.abs(buf.cpu().numpy().astype(np.int32) - want[4].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    with pytest.raises(Exception):          # a set used by both groups must take consecutive turns
+        K.render_frame_group_ahead(state, groups[1], Bl, torch.zeros(2, size[0], size[1], 3, dtype=torch.uint8, device='cuda'), turn=[0, 0], placed=False,
+                                   next_cameras=groups[1], next_turn=[1, 2])
+
+
+@pytest.mark.parametrize('group,n_frames,lanes', [('1', 9, '4'), ('2', 7, '2'), ('12', 30, '2'), ('5', 23, '3')])
+def test_video_whose_tile_launches_place_ahead_equals_the_video_with_placement_launches(K, monkeypatch, group, n_frames, lanes):
+    """kbe_render_video on the fused route: by default a lane's tile launch makes the placements of the lane's next group;
+    KBE_AHEAD=0 (KBE_VIDEO_NO_AHEAD) keeps a placement launch per group.  Same frames, left in HBM and delivered (transfer
+    groups ramping 1, 2, 4, ...: the groups of a lane change size), cropped and not, twice in a row, and the frames equal
+    frames rendered on their own."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '1')
+    monkeypatch.setenv('KBE_LANES', lanes)
+    monkeypatch.setenv('KBE_HOST_LANES', lanes)
+    monkeypatch.setenv('KBE_FILL_GROUP', group)
+    size = (224, 288)
+    settings, oc = _scene(size, 17, 'smooth', True)
+    settings = dict(settings, dblSteps=[i / max(n_frames - 1, 1) for i in range(n_frames)])
+    cams = common.frame_cameras(settings, oc)
+    crop = common.crop_size(settings)
+    state = common._prepared_cloud(K, oc)
+    assert state['fused']
+
+    def same(a, b, what=''):
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, '%s: max %d, %.2e of the values differ' % (what, d.max(), (d > 0).mean())
+
+    alone = np.stack([K.render_frame(state, sh, f, oc['dblBaseline']).cpu().numpy() for f, sh in cams])
+    monkeypatch.setenv('KBE_AHEAD', '0')
+    plain = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+    plain_crop = common.render_frames(cams, oc, crop)
+    same(plain, alone, 'placement launches, frames left in HBM')
+    monkeypatch.delenv('KBE_AHEAD')
+    for _ in range(2):
+        same(common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy(), plain, 'frames left in HBM')
+        same(common.render_frames(cams, oc, None), plain, 'delivered to host memory')
+        same(common.render_frames(cams, oc, crop), plain_crop, 'cropped and delivered')
+    same(K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy(), alone[0], 'a frame on its own after the videos')
+
+
 @pytest.mark.parametrize('size', [(50, 37), (33, 64)])
 def test_frame_hand_off_with_unaligned_frame_sizes(K, size):
     """W*H*3 not a multiple of 16: the frames of a video start at unaligned host addresses (k_deliver's byte path)."""

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The fused scatter alone on a stream, us per frame by frames per launch: the two launches of a group (k_place, k_frame_group:
+kbe_render_frame_group_fused) against the pipelined form (kbe_render_frame_group_ahead: ONE launch per group in steady state,
+the tile launch making the next group's placements), and a check that both render the same frames.  KBE_LIB_PATH: a variant
+build (dev aid)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
+
+if os.environ.get('KBE_LIB_PATH'):
+    _native._lib, _native._kernels, _native.LIB_PATH = None, None, os.environ['KBE_LIB_PATH']
+size = int(os.environ.get('SIZE', '1024'))
+reps = int(os.environ.get('REPS', '40'))
+ofrom, oto = synthetic.default_windows(size, size, False)
+settings = {'dblSteps': [i / 63 for i in range(64)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False}
+oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint', settings, 1)
+cams = common.frame_cameras(settings, oc)
+K = _native.kernels()
+state = common._prepared_cloud(K, oc)
+K._pack(state)
+Bl = oc['dblBaseline']
+out = torch.empty(12, size, size, 3, dtype=torch.uint8, device='cuda')
+ref = torch.empty_like(out)
+K.group_scratch(state, 12)
+
+
+def timed(fn, n):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps / n
+
+
+# correctness: a sequence of four different groups, pipelined, against the same groups with their placement launches in front
+for n in (1, 5, 12):
+    groups = [[cams[(7 * g + k) % len(cams)] for k in range(n)] for g in range(4)]
+    want = []
+    for group in groups:
+        K.render_frame_group_fused(state, group, Bl, ref[:n], stages=6)          # parity -1: counters zeroed in front, left zeroed
+        want.append(ref[:n].clone())
+    # control: the same classic call again (the order of the list atomics differs from run to run)
+    K.render_frame_group_fused(state, groups[0], Bl, ref[:n], stages=6)
+    dc = (ref[:n].int() - want[0].int()).abs()
+    print('frames per launch %2d: control (placed-in-front twice), max |diff| %d, differing values %.2e' % (n, int(dc.max()), float((dc > 0).float().mean())))
+    worst, frac = 0, 0.0
+    for g, group in enumerate(groups):
+        K.render_frame_group_ahead(state, group, Bl, out[:n], turn=g, placed=g > 0, next_cameras=groups[g + 1] if g + 1 < len(groups) else None, stages=6)
+        d = (out[:n].int() - want[g].int()).abs()
+        worst = max(worst, int(d.max()))
+        frac = max(frac, float((d > 0).float().mean()))
+    print('frames per launch %2d: pipelined vs placed-in-front, max |diff| %d, differing values at most %.2e' % (n, worst, frac))
+    del want
+torch.cuda.synchronize()
+
+focal, shift3 = cams[len(cams) // 2]
+for n in (1, 2, 4, 8, 12):
+    group = [(focal, shift3)] * n
+    par = [0]
+
+    def classic():
+        K.render_frame_group_fused(state, group, Bl, out[:n], stages=2, parities=[par[0] & 1] * n)
+        par[0] += 1
+    t_classic = timed(classic, n)
+    K.render_frame_group_fused(state, group, Bl, out[:n], stages=6)        # parity -1: leaves the sets' counters zeroed
+    turn = [0]
+
+    def ahead():
+        K.render_frame_group_ahead(state, group, Bl, out[:n], turn=turn[0], placed=turn[0] > 0, next_cameras=group, stages=2)
+        turn[0] += 1
+    t_ahead = timed(ahead, n)
+    K.render_frame_group_ahead(state, group, Bl, out[:n], turn=turn[0], placed=True, next_cameras=None, stages=6)      # the sequence ends: nothing placed ahead
+    torch.cuda.synchronize()
+    K.render_frame_group_fused(state, group, Bl, out[:n], stages=6)
+    print('%2d frame(s) per launch: k_place + k_frame %.2f us per frame, pipelined (one launch) %.2f us per frame' % (n, t_classic, t_ahead))
