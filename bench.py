@@ -152,7 +152,19 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
         K.render_frame_group_fused(state, [(focal, shift3)] * group_frames, Bl, fgroup_out, stages=2, parities=[gpar[0] & 1] * group_frames)
         gpar[0] += 1
     out['fused:scatter_group'] = timed(fused_grouped)
-    K.render_frame_group_fused(state, [(focal, shift3)] * group_frames, Bl, fgroup_out, stages=6, fill_rect=empty)    # parity -1: leaves the sets' counters zeroed
+    K.render_frame_group_fused(state, [(focal, shift3)] * group_frames, Bl, fgroup_out, stages=6, fill_rect=empty)    # parity -1: the sets' counters zeroed in front
+    # the scatter as the video loop launches it (kbe_render_frame_group_ahead): ONE launch per group in steady state -- the tile
+    # launch of a group (k_frame_group_ahead) also makes the placements of the next group, here the same frames again; the sets
+    # take turn after turn (banks and counters alternate)
+    for key, n_ahead in (('fused:scatter_ahead', 1), ('fused:scatter_group_ahead', group_frames)):
+        group = [(focal, shift3)] * n_ahead
+        turn = [0]
+
+        def fused_ahead():
+            K.render_frame_group_ahead(state, group, Bl, fgroup_out[:n_ahead], turn=turn[0], placed=turn[0] > 0, next_cameras=group, stages=2)
+            turn[0] += 1
+        out[key] = timed(fused_ahead)
+        K.render_frame_group_ahead(state, group, Bl, fgroup_out[:n_ahead], turn=turn[0], placed=True, next_cameras=None, stages=6, fill_rect=empty)  # the sequence ends
     del fgroup_out
     out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
     # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM.  In a video consecutive frames alternate
@@ -590,7 +602,9 @@ def main():
         # number of frames per launch the timed region took (fused: k_place + k_frame; bucket: k_project + k_tiles, the tile
         # launch clearing the other frame's z-buffer), with the one-frame launches and the other route beside it.
         scatter_bytes = 28 * n_points + 20 * HW
-        route_launches = {'fused': ['k_place', 'k_frame'], 'bucket': ['k_project', 'k_tiles']}
+        # (the fused route's tile launch also makes the next group's placements -- k_frame_ahead / k_frame_group_ahead -- unless KBE_AHEAD=0)
+        ahead = os.environ.get('KBE_AHEAD') != '0'
+        route_launches = {'fused': ['k_frame_ahead'] if ahead else ['k_place', 'k_frame'], 'bucket': ['k_project', 'k_tiles'], 'fused:two_launches': ['k_place', 'k_frame']}
         # the committed PMC passes are of the default workload only
         default_workload = size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1
         per_kernel, traffic_src = measured_traffic() if default_workload else ({}, None)
@@ -599,10 +613,13 @@ def main():
         def roof(r, frames):
             if r == 'bucket':
                 frames = min(frames, BUCKET_GROUP_MAX)
-            t = kt[r + (':scatter_group' if frames > 1 else ':scatter')]
             names = route_launches[r]
+            one_launch = names == ['k_frame_ahead']
+            r = r.split(':')[0]
+            t = kt[r + (':scatter_group' if frames > 1 else ':scatter') + ('_ahead' if one_launch else '')]
             tr = sum(per_kernel[k] for k in names) if all(k in per_kernel for k in names) else None
-            out = {'route': r, 'kernel': ' + '.join(n + ('_group' if frames > 1 and n != 'k_place' else '') for n in names), 'frames_per_launch': frames,
+            out = {'route': r, 'kernel': ' + '.join(n.replace('k_frame', 'k_frame_group').replace('k_tiles', 'k_tiles_group').replace('k_project', 'k_project_group')
+                                                    if frames > 1 else n for n in names), 'frames_per_launch': frames,
                    'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / frames, 2), 'algorithmic_bytes': frames * scatter_bytes,
                    'achieved': frames * scatter_bytes / t / 1e9, 'frac': frames * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
                    'traffic': None if tr is None else frames * tr}
@@ -617,6 +634,7 @@ def main():
         single = roof(route, 1)
         grouped = roof(route, group_frames)
         other = roof('bucket' if route == 'fused' else 'fused', group_frames)
+        two_launches = roof('fused:two_launches', group_frames) if route == 'fused' and ahead else None
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
@@ -638,9 +656,11 @@ def main():
                          'frames_per_launch': frames_per_launch, 'us': main['us'], 'us_per_frame': main['us_per_frame'],
                          'formula': '28 N + 20 HW per frame (SURVEY.md 8d)',
                          'valu_issue': main.get('valu_issue'), 'valu_issue_source': insts_src,
-                         'one_frame_per_launch': single, 'grouped': grouped, 'other_route': other,
+                         'one_frame_per_launch': single, 'grouped': grouped, 'other_route': other, 'placement_launch_in_front': two_launches,
                          'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions), with the number of frames per '
-                                 'launch the timed region uses; the matching rocprofv3 --stats summary is profiles/*scatter_group*_kernel_stats.csv '
+                                 'launch the timed region uses; fused route: ONE launch per group -- the tile launch of a group also makes the placements '
+                                 'of the next group (here: of the same frames again), so a launch holds all of the scatter\'s work for its frames; '
+                                 'the matching rocprofv3 --stats summary is profiles/*scatter_group*_kernel_stats.csv '
                                  '(in the timed region the kernels of several lanes overlap and per-kernel durations stretch)',
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }

@@ -333,8 +333,8 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * that the link starts after the first frame and a short video does not wait for G frames before its first byte moves. */
 #define KBE_VIDEO_EVEN_GROUPS 16
 /* fused route (`packed`): every group keeps a placement launch of its own in front of its tile launch.  Default: the tile launch
- * of a lane's group also makes the placements of the lane's NEXT group (kbe_render_frame_group_ahead), so that the scatter of
- * a group is one launch. */
+ * of a lane's group also makes the placements of the lane's NEXT group (kbe_render_frame_group_ahead) unless that group is
+ * larger (the ramp at the start of a delivered video), so that the scatter of a group is one launch. */
 #define KBE_VIDEO_NO_AHEAD 512
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,

@@ -28,7 +28,8 @@ ABI_VERSION = 7
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
-FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP)
+FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP): transfer groups
+                       # of 16 frames are then two EQUAL launches, and equal groups place ahead (the scatter alone: 19.4 us per frame with 8 or 12)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
@@ -424,10 +425,12 @@ class HipKernels:
             group = DEFAULT_FILL_GROUP
         elif fused:
             # eight where the link binds (the rendering then only has to stay out of the transfers' way: the fewer, larger
-            # launches the better), four for small frames, two for large frames left in HBM on four lanes
-            # (measured, us per frame left in HBM with 2 / 4 frames per launch: 640^2 13.6 / 11.7, 768^2 15.9 / 15.5, 896^2 22.5 / 22.2,
-            # 1024^2 25.3 / 26.7, 1280^2 42.1 / 43.5, 1536^2 61.3 / 62.2; the bucket route: 13.7, 18.8, 25.5, 29.4, 51.7, 72.8)
-            group = FUSED_HOST_GROUP if to_host else (4 if W * H <= 900 * 900 else 2)
+            # launches the better), four for frames left in HBM on four lanes -- since a group's tile launch also makes the next
+            # group's placements (one scatter launch per group) four frames per launch are as good as or better than two at every
+            # size (measured, us per frame left in HBM with 2 / 4 / 8 frames per launch: 640^2 12.2 / 11.3 / 11.4, 896^2 20.3 / 20.9 / 21.3,
+            # 1024^2 25.5 / 24.9 / 25.0, 1280^2 41.4 / 40.5 / 41.2, 1536^2 59.3 / 58.4 / 58.5; with a placement launch per group, round
+            # 3's first half: 1024^2 25.3 / 26.7; the bucket route: 13.7, 18.8, 25.5, 29.4, 51.7, 72.8)
+            group = FUSED_HOST_GROUP if to_host else 4
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
             # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)

@@ -161,6 +161,15 @@ __device__ unsigned long long g_frame_stats[8];     // tiles, list entries writt
 // ---------------------------------------------------------------------------------------
 struct PlaceJobs { PackedCloud pc; int tiles_x, tiles_y; PlaceArgs a[KBE_FRAME_JOBS]; };
 
+// a * b + c on the low 24 bits of a and b, as the instruction: the compiler renders __umul24(x, constant) with a value whose
+// range it cannot see as v_mul_lo_u32 -- a quarter-rate instruction, twice in every step of the splat
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // minimum over the 16 lanes of a DPP row, left in every lane of the row: four v_min_i32 that read their second operand
 // through the DPP cross-lane path (the compiler's own rendering of the same steps is a copy, a DPP copy and a min each).
 // A DPP read needs two wait states behind the VALU write of its source; inline asm gets no hazard handling, hence the s_nop.
@@ -202,7 +211,7 @@ __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i
     const bool some = w > 0 && h > 0;
     const int sub = i / kCloudSub, j = lane & (kCloudSub - 1);
     auto list_for = [&](int tx, int ty) {
-        const int t = __mul24(ty, tiles_x) + tx;
+        const int t = (int) mad_u24((uint32_t) ty, (uint32_t) tiles_x, (uint32_t) tx);
         const int pos = atomicAdd(&tile_count[(uint32_t) t * CNT_STRIDE], 1);
         if (pos < LIST_CAP) cand_lists[(size_t) t * LIST_CAP + pos] = sub;     // beyond: the tile sees count > LIST_CAP and scans
     };
@@ -213,7 +222,7 @@ __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i
         if (j == 0) atomicAdd(&g_frame_stats[1], (unsigned long long) (w * h));
 #endif
         if ((j & 3) < w && (j >> 2) < h) {
-            owed.t = __mul24(ty0 + (j >> 2), tiles_x) + tx0 + (j & 3);
+            owed.t = (int) mad_u24((uint32_t) (ty0 + (j >> 2)), (uint32_t) tiles_x, (uint32_t) (tx0 + (j & 3)));
             owed.pos = atomicAdd(&tile_count[(uint32_t) owed.t * CNT_STRIDE], 1);
         }
     } else if (some) {
@@ -298,7 +307,7 @@ typedef const __attribute__((address_space(4))) PackedCloud* PackedCloudPtr;
 #define KBE_AHEAD_AT 3
 #endif
 #ifndef KBE_AHEAD_UNITS
-#define KBE_AHEAD_UNITS 3
+#define KBE_AHEAD_UNITS 2
 #endif
 constexpr int AHEAD_UNITS = KBE_AHEAD_AT >= 2 ? KBE_AHEAD_UNITS : 0;
 
@@ -339,7 +348,9 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
     }
 }
 
-template <int J>
+// AHEAD: a launch that also makes placements (k_frame_ahead, k_frame_group_ahead: kernels of their own, so that a launch
+// that places nothing carries none of it and profiles tell the two apart)
+template <int J, bool AHEAD>
 __device__ __forceinline__ void frame_body(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
 {
     FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
@@ -387,25 +398,24 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         }
     };
     fetch_entries(wave);
-#if KBE_AHEAD_AT >= 2
     // the points of this wave's first units of the NEXT frame's placement, requested with the list (unconditionally, the
-    // addresses clamped: a launch that places nothing reads the cloud's first block)
-    const int n_next = jp->n_next;
-    const bool ahead = (int) blockIdx.y < n_next;                       // uniform: this row has a frame to place
+    // addresses clamped: a row with no frame to place reads the cloud's first block)
+    constexpr int NU = AHEAD ? AHEAD_UNITS : 0;
+    const int n_next = AHEAD ? jp->n_next : 0;
+    const bool ahead = NU > 0 && (int) blockIdx.y < n_next;             // uniform: this row has a frame to place
     const int a_units = ahead ? pcp->Np / kCloudBlock : 1;
     const int a_first = blockIdx.x * WAVES + wave, a_step = gridDim.x * WAVES;
-    CloudPoint a_pt[AHEAD_UNITS];
-    ListSlot a_owed[AHEAD_UNITS];
+    CloudPoint a_pt[NU > 0 ? NU : 1];
+    ListSlot a_owed[NU > 0 ? NU : 1];
 #pragma unroll
-    for (int d = 0; d < AHEAD_UNITS; d++) a_pt[d] = pcp->pd[min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane];
+    for (int d = 0; d < NU; d++) a_pt[d] = pcp->pd[min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane];
     auto ahead_finish = [&]() {
         if (ahead) {
             int* const cand_next = ((PlaceArgsPtr) jp->nx + blockIdx.y)->cand;
 #pragma unroll
-            for (int d = 0; d < AHEAD_UNITS; d++) place_point_end(a_owed[d], (a_first + d * a_step) * kCloudBlock + lane, cand_next);
+            for (int d = 0; d < NU; d++) place_point_end(a_owed[d], (a_first + d * a_step) * kCloudBlock + lane, cand_next);
         }
     };
-#endif
     for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
     for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
     if (tid == 0) {
@@ -415,24 +425,20 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         if (blockIdx.x == 0) *ap->bin_flag_next = 0;
     }
     fetch_points();                                     // in flight across the barrier
-#if KBE_AHEAD_AT >= 2
     // ... and placed while the tile's own points are under way; the list atomics return during the splat
 #pragma unroll
-    for (int d = 0; d < AHEAD_UNITS; d++) a_owed[d] = ListSlot{ -1, 0 };
+    for (int d = 0; d < NU; d++) a_owed[d] = ListSlot{ -1, 0 };
     if (ahead) {
         PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
         const Camera ncam = load_camera(&na->cam);
 #pragma unroll
-        for (int d = 0; d < AHEAD_UNITS; d++)
+        for (int d = 0; d < NU; d++)
             if (a_first + d * a_step < a_units)
                 a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag);
     }
-#endif
     const bool listed = !wide & (count <= LIST_CAP);            // uniform
     __syncthreads();
-#if KBE_AHEAD_AT == 2
-    ahead_finish();
-#endif
+    if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
     KBE_STOP_AFTER(1);                                          // (dev) the list
@@ -465,7 +471,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             // (byte offset from a 24-bit multiply-add: written on the element index the compiler folded the x 4 into a
             // quarter-rate 32-bit multiply)
             if (inside(cx, cy, W, H) & ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
-                atomicMin((uint32_t*) ((char*) zk + (__umul24((uint32_t) ly, KW * 4u) + ((uint32_t) lx << 2))), zkey_encode(err));
+                atomicMin((uint32_t*) ((char*) zk + mad_u24((uint32_t) ly, KW * 4u, (uint32_t) lx << 2)), zkey_encode(err));
         }
         if (flags & (PASS_COUNT | PASS_INSERT)) {
             const unsigned long long m = __ballot(in_r);
@@ -478,7 +484,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 const int limit = REC_CAP;
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (in_r && slot < limit) {
-                    const int next = atomicExch((int*) ((char*) L.head + (__umul24((uint32_t) (ry - 1), BW * 4u) + ((uint32_t) (rx - 1) << 2))), slot << 4);
+                    const int next = atomicExch((int*) ((char*) L.head + mad_u24((uint32_t) (ry - 1), BW * 4u, (uint32_t) (rx - 1) << 2)), slot << 4);
                     L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
                     if (flags & PASS_COLOUR) L.rgbd[slot] = col;
                     else L.rgbd[slot].x = __int_as_float(idx);                      // the point, until its colours arrive
@@ -516,12 +522,8 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             if (more) fetch_points();
         }
     }
-#if KBE_AHEAD_AT == 1
-    { const int n_next = jp->n_next; if (n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane); }
-#endif
-#if KBE_AHEAD_AT == 3
-    ahead_finish();
-#endif
+    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane);
+    if (KBE_AHEAD_AT == 3) ahead_finish();
     __syncthreads();
     KBE_STOP_AFTER(3);                                          // (dev) + the splat
 
@@ -727,10 +729,12 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     (void) total;
 #endif
     tile_epilogue(a, L, acc, tile, x0, y0);
-#if KBE_AHEAD_AT != 1
-    asm volatile("" : "+s"(jp) :: "memory");
-    { const int n_next = jp->n_next; if (n_next > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_next, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane); }
-#endif
+    if (AHEAD && KBE_AHEAD_AT != 1) {
+        // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
+        asm volatile("" : "+s"(jp) :: "memory");
+        const int n_left = jp->n_next;
+        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane);
+    }
 }
 
 typedef FrameJobsT<1> FrameJob1;
@@ -745,13 +749,22 @@ typedef FrameJobsT<KBE_FRAME_JOBS> FrameJobs;
 
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame(FrameJob1)
 {
-    frame_body<1>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);    // the one argument, at offset 0
+    frame_body<1, false>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);    // the one argument, at offset 0
+}
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_ahead(FrameJob1)
+{
+    frame_body<1, true>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);
 }
 
 // several frames of the same cloud and size per launch (blockIdx.y = the frame), as the bucket route's grouped launches
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group(FrameJobs)
 {
-    frame_body<KBE_FRAME_JOBS>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
+    frame_body<KBE_FRAME_JOBS, false>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
+}
+// ... that also make the placements of the frames the next tile launch renders
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_ahead(FrameJobs)
+{
+    frame_body<KBE_FRAME_JOBS, true>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
 }
 
 }  // namespace
@@ -808,12 +821,13 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         fj.nx[k] = place_args(n_next > 0 ? next[k < n_next ? k : 0] : f);
     }
     if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
-    if (n == 1) {
+    if (n == 1 && n_next <= 1) {
         FrameJob1 f1;
-        f1.pc = pc; f1.n_next = n_next > 1 ? 1 : n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
-        if (n_next > 1) hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, 1), dim3(TILE_THREADS), 0, s, fj);       // one frame that places several: the group form
+        f1.pc = pc; f1.n_next = n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
+        if (n_next) hipLaunchKernelGGL(k_frame_ahead, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
         else hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
-    } else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+    } else if (n_next) hipLaunchKernelGGL(k_frame_group_ahead, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);        // (also: one frame that places several)
+    else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe

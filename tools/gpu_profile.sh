@@ -52,6 +52,10 @@ done
 rm -rf /tmp/kg
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kg -o b --output-format csv -- python $R/tools/scatter_time.py > $OUT/scatter_group.txt 2>/dev/null
 if [ -f /tmp/kg/b_kernel_stats.csv ]; then cp /tmp/kg/b_kernel_stats.csv $OUT/scatter_group_kernel_stats.csv; python $R/tools/kernel_times_by_grid.py /tmp/kg/b_kernel_trace.csv k_place k_frame k_project k_tiles > $OUT/scatter_group_by_frames_per_launch.txt; fi
+# 4c. the same for the one-launch scatter (k_frame_group_ahead: the tiles of a group + the placements of the next), against the two launches
+rm -rf /tmp/ka
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ka -o b --output-format csv -- python $R/tools/ahead_time.py > $OUT/scatter_ahead.txt 2>/dev/null
+if [ -f /tmp/ka/b_kernel_stats.csv ]; then cp /tmp/ka/b_kernel_stats.csv $OUT/scatter_ahead_kernel_stats.csv; python $R/tools/kernel_times_by_grid.py /tmp/ka/b_kernel_trace.csv k_place k_frame > $OUT/scatter_ahead_by_frames_per_launch.txt; fi
 # 5. the dolly zoom (frames with very many holes: the distance-table fill): per-kernel stats of its frame loop, and what the fill does
 rm -rf /tmp/kd
 DOLLY=1 REPS=2 FRAMES=128 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kd -o b --output-format csv -- python $R/tools/throughput.py > $OUT/dolly_under_rocprof.txt 2>/dev/null

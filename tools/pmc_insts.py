@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KEYS = ('k_place', 'k_frame', 'k_project', 'k_tiles')
+KEYS = ('k_place', 'k_frame', 'k_frame_ahead', 'k_project', 'k_tiles')
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):

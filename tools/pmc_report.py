@@ -38,7 +38,7 @@ cal_w = CAL_BYTES / (sum(pick(write, 'k_zkeys_decode')) / len(pick(write, 'k_zke
 cal_w_fill = CAL_BYTES / (sum(pick(write, 'k_fill_u32')[-3:]) / 3)
 out = {'bytes_per_FETCH_SIZE_unit': cal_f, 'bytes_per_WRITE_SIZE_unit': cal_w, 'bytes_per_WRITE_SIZE_unit_constant_fill': cal_w_fill,
        'kernels': {}}
-for key in ('k_project', 'k_tiles', 'k_place', 'k_frame', 'k_fill_holes', 'k_crop_resize_u8'):
+for key in ('k_project', 'k_tiles', 'k_place', 'k_frame', 'k_frame_ahead', 'k_fill_holes', 'k_crop_resize_u8'):
     f, w = pick(fetch, key), pick(write, key)
     if f and w:
         out['kernels'][key] = {'launches': len(f), 'fetch_bytes': cal_f * sum(f) / len(f), 'write_bytes': cal_w * sum(w) / len(w)}
