@@ -122,3 +122,33 @@ def test_rasters_beyond_4096_tile_renderers_against_the_atomic_kernels(K, size, 
             filled_by.append(buf)
         assert torch.equal(filled_by[0], filled_by[1]), 'table-driven fill at %d^2 (fused=%s)' % (size, fused)
         del rf, ex, unfilled, filled_by
+
+
+def test_one_launch_scatter_at_1024_equals_the_two_launches(K, dense_cloud):
+    """kbe_render_frame_group_ahead at BASELINE's frame size: a sequence of 8-frame groups along a camera path, every tile launch
+    also making the next group's placements, against the same groups with their placement launches in front (frames within the
+    accumulation order); and the rule that keeps a cloud much denser than the raster on its placement launch."""
+    from ken_burns_effect_amd import synthetic
+    size = 1024
+    image, disp = synthetic.make_rgbd(size, size, 3)
+    depth = ((synthetic.FOCAL * synthetic.BASELINE) / (disp + 1e-7)).cuda()
+    pts = K.depth_to_points(depth, synthetic.FOCAL).view(1, 3, -1)
+    state = K.prepare_cloud(pts, image.cuda().reshape(1, 3, -1), depth.reshape(1, 1, -1), size, size, synthetic.FOCAL, raster=(size, size * size))
+    K._pack(state)
+    Bl = synthetic.BASELINE
+    cams = [(synthetic.FOCAL * (1.0 + 0.002 * i), (0.9 * i - 10.0, 4.0 - 0.4 * i, -1.1 * i)) for i in range(24)]
+    groups = [cams[0:8], cams[8:16], cams[16:24]]
+    want = []
+    buf = torch.zeros(8, size, size, 3, dtype=torch.uint8, device='cuda')
+    for g in groups:
+        K.render_frame_group_fused(state, g, Bl, buf)
+        want.append(buf.clone())
+    assert K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 8, 8) == 1
+    for i, g in enumerate(groups):
+        K.render_frame_group_ahead(state, g, Bl, buf, turn=i, placed=i > 0, next_cameras=groups[i + 1] if i + 1 < len(groups) else None)
+        d = (buf.int() - want[i].int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-4, 'group %d: max %d, %.2e differ' % (i, int(d.max()), float((d > 0).float().mean()))
+        assert float((buf == 0).all(dim=3).float().mean()) < 0.2, 'frames are rendered'
+    # 16.8 M points on a 2048^2 raster: eight units of 64 points per wave of the tile launch -- too many to ride along
+    assert K.lib.kbe_render_frame_group_ahead_ok(dense_cloud[1].shape[2], 2048, 2048, 4, 4) == 0
+    assert K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 1, 12) == 0 and K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 8, 0) == 0
