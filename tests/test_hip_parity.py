@@ -505,6 +505,64 @@ def test_pipelined_groups_equal_groups_with_their_placements_in_front(K):
                                    next_cameras=groups[1], next_turn=[1, 2])
 
 
+@pytest.mark.parametrize('kind', ['incoherent', 'pile_up', 'tiny', 'empty'])
+def test_pipelined_groups_through_the_slow_paths(K, kind):
+    """The one-launch scatter on clouds that leave the normal path: a cloud in random order (every sub-block is wide: the list
+    totals -- which rotate over three words in a pipelined sequence -- exceed their budget and every tile scans the cloud), four
+    points per pixel (records spill), a 37 x 50 frame (partial tiles, fewer tiles than waves have units), no points at all.
+    Five groups of changing size, pipelined, against the same groups with their placement launches in front."""
+    g0 = torch.Generator().manual_seed(11)
+    if kind == 'incoherent':
+        W, H, N = 200, 136, 6000
+        pts = torch.rand(1, 3, N, generator=g0) * torch.tensor([1600.0, 1200.0, 900.0]).view(1, 3, 1) - torch.tensor([800.0, 600.0, -100.0]).view(1, 3, 1)
+        pts[0, 2, :50] = 0.0
+        pts[0, 2, 50:100] = -30.0
+    elif kind == 'pile_up':
+        W, H = 96, 64
+        N = 4 * W * H
+        u = torch.rand(N, generator=g0) * (W + 8) - 4 - W / 2 + 0.5
+        v = torch.rand(N, generator=g0) * (H + 8) - 4 - H / 2 + 0.5
+        z = torch.rand(N, generator=g0) * 400 + 600
+        pts = torch.stack([u * z / 512.0, v * z / 512.0, z]).unsqueeze(0)
+    elif kind == 'tiny':
+        W, H, N = 50, 37, 50 * 37
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+        z = 700.0 + 200.0 * torch.rand(H, W, generator=g0)
+        pts = torch.stack([(xs - W / 2 + 0.5) * z / 512.0, (ys - H / 2 + 0.5) * z / 512.0, z]).reshape(1, 3, -1)
+    else:
+        W, H, N = 64, 48, 0
+        pts = torch.zeros(1, 3, 0)
+    img, dep = torch.rand(1, 3, N, generator=g0), torch.rand(1, 1, N, generator=g0) * 500 + 100
+    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+    K._pack(state)
+    cams = [(512.0 - 6.0 * i, (1.5 * i - 4.0, 2.0 - 0.7 * i, -3.0 * i)) for i in range(14)]
+    sizes = [2, 3, 3, 1, 5]
+    groups, at = [], 0
+    for n in sizes:
+        groups.append(cams[at:at + n])
+        at += n
+    want = []
+    for g in groups:
+        buf = torch.zeros(len(g), H, W, 3, dtype=torch.uint8, device='cuda')
+        K.render_frame_group_fused(state, g, 120, buf)
+        want.append(c(buf))
+    for rep in range(2):
+        turns, placed = [0] * 12, False
+        for i, g in enumerate(groups):
+            n = len(g)
+            nxt = groups[i + 1] if i + 1 < len(groups) else None
+            ok = nxt is not None and bool(K.lib.kbe_render_frame_group_ahead_ok(N, W, H, n, len(nxt)))
+            now = turns[:n]
+            for k in range(n):
+                turns[k] += 1
+            buf = torch.zeros(n, H, W, 3, dtype=torch.uint8, device='cuda')
+            K.render_frame_group_ahead(state, g, 120, buf, turn=now, placed=placed, next_cameras=nxt if ok else None, next_turn=turns[:len(nxt)] if ok else None)
+            placed = ok
+            d = np.abs(c(buf).astype(np.int32) - want[i].astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, '%s, pass %d group %d: max %d, %.2e differ' % (kind, rep, i, d.max(), (d > 0).mean())
+    assert kind == 'empty' or any(w.any() for w in want), 'the frames show something'
+
+
 @pytest.mark.parametrize('group,n_frames,lanes', [('1', 9, '4'), ('2', 7, '2'), ('12', 30, '2'), ('5', 23, '3')])
 def test_video_whose_tile_launches_place_ahead_equals_the_video_with_placement_launches(K, monkeypatch, group, n_frames, lanes):
     """kbe_render_video on the fused route: by default a lane's tile launch makes the placements of the lane's next group;

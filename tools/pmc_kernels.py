@@ -7,7 +7,7 @@ import collections
 import csv
 import sys
 
-KEYS = ('k_project', 'k_tiles', 'k_place', 'k_frame', 'k_fill_holes', 'k_crop_resize_u8', 'k_deliver')
+KEYS = ('k_project', 'k_tiles', 'k_place', 'k_frame', 'k_frame_ahead', 'k_frame_group_ahead', 'k_fill_holes', 'k_crop_resize_u8', 'k_deliver')
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
