@@ -399,6 +399,37 @@ class HipKernels:
                                                           _i(m), nf, ns, nsets, nturns, _i(int(stages)), rect, _stream()), 'kbe_render_frame_group_ahead')
         return out
 
+    def prepared_group_ahead(self, state, cameras, baseline, out, next_cameras, stages=2):
+        """A closure that makes the launch of :meth:`render_frame_group_ahead` for a FIXED group -- frame k on scratch set k, the next
+        group the same sets -- with every argument array built once: ``launch(turn, placed, place_next=True)`` only writes the turn
+        numbers.  For timing loops: building the ctypes arrays of two groups of eight cameras costs the host about as long as the
+        GPU works on the launch, and a measurement through the ordinary wrapper then reads the host's speed."""
+        n, m = len(cameras), len(next_cameras)
+        self._pack(state)
+        scratch, stride = self.group_scratch(state, max(n, m, 4) if 'scratch_groups' not in state else max(n, m, state['scratch_groups'].numel() // stride_of(self, state)))
+
+        def arrays(cams, k):
+            return ((ctypes.c_double * k)(*[float(c[0]) for c in cams]), (ctypes.c_float * (3 * k))(*[float(v) for c in cams for v in c[1]]),
+                    (ctypes.c_void_p * k)(*[scratch.data_ptr() + j * stride for j in range(k)]))
+        focals, shifts, sets = arrays(cameras, n)
+        nf, ns, nsets = arrays(next_cameras, m)
+        frames = (ctypes.c_void_p * n)(*[out[k].data_ptr() for k in range(n)])
+        turns, nturns = (ctypes.c_int * n)(), (ctypes.c_int * m)()
+        fixed = (_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']), _i(state['H']), _d(float(baseline)), _i(n),
+                 focals, shifts, sets, frames, turns)
+        tail = (nf, ns, nsets, nturns, _i(int(stages)), None)
+        fn, check, zero = self.lib.kbe_render_frame_group_ahead, self._check, _i(0)
+        keep = (scratch, out)          # (the arrays hold raw addresses)
+
+        def launch(turn, placed, place_next=True):
+            for k in range(n):
+                turns[k] = turn
+            for k in range(m):
+                nturns[k] = turn + 1
+            check(fn(*fixed, _i(1 if placed else 0), _i(m) if place_next else zero, *tail, _stream()), 'kbe_render_frame_group_ahead')
+        launch.keep = keep
+        return launch
+
     def video_launch_shape(self, state, cameras, batch, to_host=False):
         """(flags of kbe_render_video, frames per launch, fused route?) for a video of `cameras`.
         KBE_VIDEO_FILL_DIST, the table-driven hole fill: for videos whose frames have hundreds of thousands of holes -- a

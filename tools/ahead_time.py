@@ -79,7 +79,14 @@ for n in (1, 2, 4, 8, 12):
         K.render_frame_group_ahead(state, group, Bl, out[:n], turn=turn[0], placed=turn[0] > 0, next_cameras=group, stages=2)
         turn[0] += 1
     t_ahead = timed(ahead, n)
+    # ... and with the argument arrays built once (bench.py's way: the wrapper above costs the host ~100 us per call)
+    launch = K.prepared_group_ahead(state, group, Bl, out[:n], group, stages=2)
+
+    def ahead_prepared():
+        launch(turn[0], True)
+        turn[0] += 1
+    t_prepared = timed(ahead_prepared, n)
     K.render_frame_group_ahead(state, group, Bl, out[:n], turn=turn[0], placed=True, next_cameras=None, stages=6)      # the sequence ends: nothing placed ahead
     torch.cuda.synchronize()
     K.render_frame_group_fused(state, group, Bl, out[:n], stages=6)
-    print('%2d frame(s) per launch: k_place + k_frame %.2f us per frame, pipelined (one launch) %.2f us per frame' % (n, t_classic, t_ahead))
+    print('%2d frame(s) per launch: k_place + k_frame %.2f us per frame, pipelined (one launch) %.2f us per frame (arguments prepared: %.2f)' % (n, t_classic, t_ahead, t_prepared))
