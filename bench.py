@@ -157,6 +157,8 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
     # launch of a group (k_frame_group_ahead) also makes the placements of the next group, here the same frames again; the sets
     # take turn after turn (banks and counters alternate)
     for key, n_ahead in (('fused:scatter_ahead', 1), ('fused:scatter_group_ahead', group_frames)):
+        if not K.lib.kbe_render_frame_group_ahead_ok(state['N'], W, H, n_ahead, n_ahead):
+            continue            # a cloud much denser than the raster keeps its placement launch (the video loop decides the same way)
         group = [(focal, shift3)] * n_ahead
         turn = [0]
         # (the argument arrays built once: through the ordinary wrapper the host needs about as long per call as the GPU per launch,
@@ -606,7 +608,7 @@ def main():
         # launch clearing the other frame's z-buffer), with the one-frame launches and the other route beside it.
         scatter_bytes = 28 * n_points + 20 * HW
         # (the fused route's tile launch also makes the next group's placements -- k_frame_ahead / k_frame_group_ahead -- unless KBE_AHEAD=0)
-        ahead = os.environ.get('KBE_AHEAD') != '0'
+        ahead = os.environ.get('KBE_AHEAD') != '0' and 'fused:scatter_group_ahead' in kt and 'fused:scatter_ahead' in kt
         route_launches = {'fused': ['k_frame_ahead'] if ahead else ['k_place', 'k_frame'], 'bucket': ['k_project', 'k_tiles'], 'fused:two_launches': ['k_place', 'k_frame']}
         # the committed PMC passes are of the default workload only
         default_workload = size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1
