@@ -14,8 +14,11 @@
  * Conventions
  *   - All pointers are DEVICE pointers to contiguous fp32 (unless typed otherwise) in the
  *     reference's layouts: points [B,3,N], data [B,C,N], z-buffer [B,1,H,W], images [B,C,H,W].
- *   - The caller owns every buffer, including scratch; nothing here allocates, frees or
+ *   - The caller owns every buffer, including scratch; nothing here allocates or frees device memory or
  *     synchronises.  All launches are asynchronous on `stream` (a hipStream_t; NULL = default).
+ *     ONE exception, stated here so that no caller is surprised: kbe_render_video with lanes > 1 creates
+ *     (and destroys before it returns) the HIP events that fork its lane streams from `stream` and join
+ *     them back -- host-side objects, no device memory, no blocking wait.
  *   - Return value: KBE_OK, or a negative KBE_E_* for invalid arguments / launch failures
  *     (hipGetLastError after the launch).  Nothing throws across this boundary.
  *   - Re-entrant, no global state: safe with one process per GPU or one stream per thread.
@@ -268,11 +271,6 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
  * of the frames next_* (the cameras, sets and turns the next call will render with; a set that both groups use has
  * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
  * than the raster keeps its placement launch).  Everything else as kbe_render_frame_group_fused; same results. */
-/* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
- * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
- * z-tested gather four channels at a time.  data [C,N]; render [C,H,W] normalised (:686), existing [H*W] the
- * weight sum; shift3 as in kbe_zsplat (NULL: none); scratch as kbe_render_frame (left clean).  Same results
- * as kbe_render_pointcloud up to the order of the fp32 sums. */
 KBE_API int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_next);
 KBE_API int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
                                          const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
@@ -280,6 +278,11 @@ KBE_API int kbe_render_frame_group_ahead(const void* packed, int N, double cloud
                                          void* const* next_scratch, const int* next_turns, int stages, const int* fill_rect,
                                          kbe_stream_t stream);
 
+/* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
+ * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
+ * z-tested gather four channels at a time.  data [C,N]; render [C,H,W] normalised (:686), existing [H*W] the
+ * weight sum; shift3 as in kbe_zsplat (NULL: none); scratch as kbe_render_frame (left clean).  Same results
+ * as kbe_render_pointcloud up to the order of the fp32 sums. */
 KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, int C, int W, int H, double focal,
                                         double baseline, const float* shift3, void* scratch, float* render,
                                         float* existing, kbe_stream_t stream);

@@ -150,6 +150,13 @@ __device__ __forceinline__ bool node_hits(const CloudNode& n, const CullView& q)
 #if defined(KBE_FRAME_STATS)     // dev build only (tools/frame_stats.py): what k_place and the tiles of k_frame did, summed over launches
 __device__ unsigned long long g_frame_stats[8];     // tiles, list entries written, candidate sub-blocks, points in z reach, records, slow tiles, spilling tiles, wide sub-blocks
 #endif
+#if defined(KBE_FRAME_PROBE)     // dev build only (tools/frame_probe.py): the shader clock at the phase boundaries of every wave of a tile launch
+constexpr int PROBE_STAMPS = 14, PROBE_WAVES = 1 << 17;
+__device__ unsigned long long g_frame_probe[PROBE_WAVES * PROBE_STAMPS];
+#define KBE_PROBE(k) do { probe_t[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KBE_PROBE(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // k_place: the placements and the candidate lists of one frame.  A point matters to tile (tx, ty) when its north-west
@@ -366,6 +373,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     const int W = ap->cam.W, H = ap->cam.H;
     uint32_t* const zk = (uint32_t*) L.zpre;            // the tile's z-buffer as keys until the splat is complete
     constexpr int WAVES = TILE_THREADS / 64;
+#if defined(KBE_FRAME_PROBE)
+    unsigned long long probe_t[PROBE_STAMPS] = {};
+#endif
+    KBE_PROBE(0);
 
     // The candidate list first (everything else waits for it).  A wave takes four sub-blocks per step -- sixteen lanes each, a
     // lane one point -- and the steps go round the waves; the operands of FOUR steps are requested before the first is
@@ -424,20 +435,25 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         lds_dummy_record(L);
         if (blockIdx.x == 0) *ap->bin_flag_next = 0;
     }
+    KBE_PROBE(10);
     fetch_points();                                     // in flight across the barrier
+    KBE_PROBE(11);
     // ... and placed while the tile's own points are under way; the list atomics return during the splat
 #pragma unroll
     for (int d = 0; d < NU; d++) a_owed[d] = ListSlot{ -1, 0 };
     if (ahead) {
         PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
         const Camera ncam = load_camera(&na->cam);
+        KBE_PROBE(12);
 #pragma unroll
         for (int d = 0; d < NU; d++)
             if (a_first + d * a_step < a_units)
                 a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag);
     }
     const bool listed = !wide & (count <= LIST_CAP);            // uniform
+    KBE_PROBE(1);
     __syncthreads();
+    KBE_PROBE(2);
     if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
@@ -523,8 +539,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         }
     }
     if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane);
+    KBE_PROBE(3);
     if (KBE_AHEAD_AT == 3) ahead_finish();
     __syncthreads();
+    KBE_PROBE(4);
     KBE_STOP_AFTER(3);                                          // (dev) + the splat
 
     // ---- the second phase reads its arguments now
@@ -576,10 +594,13 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         __syncthreads();
         fast = tile_is_fast();
         tile_degrid(a, L, tid, x0, y0, fast);
+        KBE_PROBE(5);
         __syncthreads();                                        // the epilogue stages its bytes where the degrid still reads its neighbours' z
+        KBE_PROBE(6);
         KBE_STOP_AFTER(4);                                      // (dev) + degrid
         if (fast) gather<true>(a, L, tid, x0, y0, acc);
         else gather<false>(a, L, tid, x0, y0, acc);
+        KBE_PROBE(7);
         KBE_STOP_AFTER(5);                                      // (dev) + gather
         // further rounds: the spilled records, REC_CAP at a time (already projected: only lists, colours and the walk)
         for (int r0 = 0; r0 < n_spill; r0 += REC_CAP) {         // uniform
@@ -729,12 +750,25 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     (void) total;
 #endif
     tile_epilogue(a, L, acc, tile, x0, y0);
+    KBE_PROBE(8);
     if (AHEAD && KBE_AHEAD_AT != 1) {
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");
         const int n_left = jp->n_next;
         if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane);
     }
+    KBE_PROBE(9);
+#if defined(KBE_FRAME_PROBE)
+    {
+        const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave;
+        if (lane < PROBE_STAMPS && w < (unsigned) PROBE_WAVES) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int k = 0; k < PROBE_STAMPS; k++) if (lane == k) v = probe_t[k];
+            g_frame_probe[(size_t) w * PROBE_STAMPS + lane] = v;
+        }
+    }
+#endif
 }
 
 typedef FrameJobsT<1> FrameJob1;
@@ -832,6 +866,12 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe
 
+#if defined(KBE_FRAME_PROBE)
+extern "C" __attribute__((visibility("default"))) int kbe_debug_frame_probe(unsigned long long* out, size_t n_words)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frame_probe), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(KBE_FRAME_STATS)
 extern "C" __attribute__((visibility("default"))) int kbe_debug_frame_stats(unsigned long long* out8, int reset)
 {

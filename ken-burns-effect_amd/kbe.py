@@ -4,6 +4,7 @@
         [--inpaint-path P] [--refine-path P] [--estim-path P] [--inpaint-depth P] [--pretrained-refine]
         [--pretrained-estim] [--2d] [--startU/--startV/--endU/--endV/--startW/--startH/--endW/--endH N]
         [--semantics-path vgg19_bn_state_dict.pth]     (new: the reference downloads these weights through torchvision)
+        [--allow-random-weights]                       (new: render with seeded weights where a checkpoint is missing instead of failing)
 
 Images are read with PIL (OpenCV is not a dependency); like ``cv2.imread`` the pixels are handed to the
 networks in BGR order unless ``--pretrained-estim`` is given (kbe.py:96-98).
@@ -16,12 +17,12 @@ import numpy as np
 import torch
 
 LONG_OPTIONS = ['in=', 'out=', 'dolly', 'write-frames', 'inpaint-path=', 'refine-path=', 'estim-path=', 'startU=', 'startV=', 'endU=',
-                'endV=', 'startW=', 'startH=', 'endW=', 'endH=', 'pretrained-refine', 'pretrained-estim', 'inpaint-depth=', '2d', 'semantics-path=']
+                'endV=', 'startW=', 'startH=', 'endW=', 'endH=', 'pretrained-refine', 'pretrained-estim', 'inpaint-depth=', '2d', 'semantics-path=', 'allow-random-weights']
 
 
 def parse(argv):
     cfg = {'in': 'images/doublestrike.jpg', 'out': 'images/kbe', 'dolly': False, 'write-frames': False, 'pretrained-refine': False,
-           'pretrained-estim': False, '2d': False, 'inpaint-depth': None, 'semantics-path': None,
+           'pretrained-estim': False, '2d': False, 'inpaint-depth': None, 'semantics-path': None, 'allow-random-weights': False,
            'inpaint-path': './models/trained/inpainting-color.tar', 'refine-path': './models/trained/disparity-refinement.tar',
            'estim-path': './models/trained/disparity-estimation-no-mask.tar'}
     window = dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH'))
@@ -30,7 +31,7 @@ def parse(argv):
         if name in window:
             if argument != '':
                 window[name] = int(argument)
-        elif name in ('dolly', 'write-frames', 'pretrained-refine', 'pretrained-estim', '2d'):
+        elif name in ('dolly', 'write-frames', 'pretrained-refine', 'pretrained-estim', '2d', 'allow-random-weights'):
             cfg[name] = True
         elif argument != '':
             cfg[name] = argument
@@ -83,7 +84,7 @@ def main(argv=None):
     zoom = windows_for(image.shape[3], image.shape[2], window, cfg['dolly'])
     paths = [cfg['estim-path'], cfg['refine-path'], cfg['inpaint-path']] + ([cfg['inpaint-depth']] if cfg['inpaint-depth'] else [])
     pipe = Pipeline(model_paths=paths, dolly=cfg['dolly'], output_frames=cfg['write-frames'], pretrain=cfg['pretrained-refine'], d2=cfg['2d'],
-                    semantics_path=cfg['semantics-path'])
+                    semantics_path=cfg['semantics-path'], allow_random_weights=cfg['allow-random-weights'] or None)
     frames = pipe(image, zoom, cfg['out'], pretrained_estim=cfg['pretrained-estim'])
     print('%d frames of %dx%d written to %s' % (len(frames), image.shape[3], image.shape[2], cfg['out']))
 

@@ -28,7 +28,7 @@ from .utils import load_models, resize_image
 
 class Pipeline():
     def __init__(self, model_paths=None, partial_inpainting=False, dolly=False, output_frames=False, pretrain=False, d2=False,
-                 device='cuda:0', steps=75, inpaint_dtype=None, semantics_path=None, miopen_find=None):
+                 device='cuda:0', steps=75, inpaint_dtype=None, semantics_path=None, miopen_find=None, allow_random_weights=None):
         self.objectCommon = {'dblFocal': 1024.0 / 2, 'dblBaseline': 120}       # pipeline.py:26-27
         # The networks are four fifths of a video's time.  PyTorch's default (immediate) MIOpen mode hands the library no
         # workspace, and MIOpen then falls back to slower convolution solvers (its `IsEnoughWorkspace ... size: 0` warnings):
@@ -54,7 +54,12 @@ class Pipeline():
             # broken in the reference (common.py:50-69), so the fourth checkpoint is loaded but unused
             self.moduleInpaintDepth = Inpaint().to(self.device).eval()
             models_list.append({'model': self.moduleInpaintDepth, 'type': 'inpaint'})
-        load_models(models_list, paths)
+        # A missing checkpoint is an ERROR, as in the reference (torch.load of utils.py:206 raises): a video rendered from random
+        # weights is garbage that looks like a result.  Benches, tests and smoke runs, which only need the arithmetic, say so:
+        # ``allow_random_weights=True`` / --allow-random-weights / env KBE_ALLOW_RANDOM_WEIGHTS=1 -> seeded weights and a warning.
+        if allow_random_weights is None:
+            allow_random_weights = os.environ.get('KBE_ALLOW_RANDOM_WEIGHTS') == '1'
+        load_models(models_list, paths, seed_missing=bool(allow_random_weights))
         # optional reduced-precision GridNet (default fp32 = the reference's arithmetic).  ``inpaint_dtype``
         # torch.bfloat16 / torch.float16, or env KBE_INPAINT_DTYPE=bf16|fp16: the two inpaint passes are 80 % of a
         # video's time and run ~4x faster in bf16; the frames then differ visibly in the last bits of the inpainted
@@ -73,6 +78,10 @@ class Pipeline():
         if semantics_path and os.path.exists(semantics_path):
             state = torch.load(semantics_path, map_location='cpu')
             self.moduleSemantics.load_torchvision_state_dict(state.get('model_state_dict', state) if isinstance(state, dict) else state)
+        elif not allow_random_weights:
+            raise FileNotFoundError('semantics (VGG19-bn) weights %r not found: pass semantics_path / --semantics-path / KBE_SEMANTICS_PATH (a torchvision '
+                                    'vgg19_bn state dict), or allow_random_weights=True / --allow-random-weights for runs that only need the arithmetic'
+                                    % (semantics_path,))
         else:
             import warnings
             warnings.warn('checkpoint %r not found: semantics (VGG19-bn) network runs with seeded random weights; pass '

@@ -33,7 +33,8 @@ def load_models(models_list, models_paths, continue_training=False, seed_missing
         entry = models_list[idx]
         if path is None or not os.path.exists(path):
             if not seed_missing:
-                raise FileNotFoundError(path)
+                raise FileNotFoundError('checkpoint %r of the %s network not found (the reference\'s download.sh fetches them); '
+                                        'allow_random_weights=True / --allow-random-weights renders with seeded weights instead' % (path, entry['type']))
             warnings.warn('checkpoint %r not found: %s network runs with seeded random weights' % (path, entry['type']))
             synthetic.seeded_fill_(entry['model'], 1000 + idx)
             continue

@@ -780,7 +780,7 @@ def test_pipeline_on_gpu_config2_shape(K):
     image, _ = synthetic.make_rgbd(256, 256, 9)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        pipe = Pipeline(model_paths=None, device='cuda:0', steps=5)
+        pipe = Pipeline(model_paths=None, allow_random_weights=True, device='cuda:0', steps=5)
     zoom = kbe.windows_for(256, 256, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
     frames = pipe(image, zoom)
     assert len(frames) == 5 and frames[0].shape == (256, 256, 3) and frames[0].dtype == np.uint8
@@ -1232,11 +1232,11 @@ def test_partial_conv_inpainting_pipeline_on_gpu(K):
     zoom = kbe.windows_for(256, 192, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        pipe = Pipeline(model_paths=None, partial_inpainting=True, device='cuda:0', steps=4)
+        pipe = Pipeline(model_paths=None, allow_random_weights=True, partial_inpainting=True, device='cuda:0', steps=4)
         frames = pipe(image, zoom)
         assert len(frames) == 4 and frames[0].shape == (192, 256, 3) and frames[0].dtype == np.uint8
         assert pipe.objectCommon['tensorInpaPoints'].shape[2] > 192 * 256          # the partial-conv net appended points
-        dolly = Pipeline(model_paths=None, partial_inpainting=True, dolly=True, device='cuda:0', steps=4)
+        dolly = Pipeline(model_paths=None, allow_random_weights=True, partial_inpainting=True, dolly=True, device='cuda:0', steps=4)
         zoom_d = kbe.windows_for(256, 192, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), True)
         frames_d = dolly(image, zoom_d)
     assert len(frames_d) == 4 and dolly.objectCommon['tensorInpaPoints'].shape[2] == 192 * 256

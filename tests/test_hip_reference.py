@@ -345,9 +345,9 @@ def test_pipeline_config1_full_size_front_half_and_a_frame_against_the_oracle(K,
     zoom = kbe.windows_for(size, size, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        pipe = Pipeline(model_paths=None, device='cuda:0', steps=steps)
+        pipe = Pipeline(model_paths=None, allow_random_weights=True, device='cuda:0', steps=steps)
         frames = pipe(image, zoom)
-        cpu = Pipeline(model_paths=None, device='cpu', steps=steps)
+        cpu = Pipeline(model_paths=None, allow_random_weights=True, device='cpu', steps=steps)
     assert len(frames) == steps and frames[0].shape == (size, size, 3) and frames[0].dtype == np.uint8
     oc = pipe.objectCommon
     n = oc['tensorInpaPoints'].shape[2]

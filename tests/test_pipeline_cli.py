@@ -23,7 +23,7 @@ def test_pipeline_end_to_end_on_cpu(oracle, monkeypatch, tmp_path, recwarn):
     monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels('jacobi'))
     torch.set_num_threads(2)
     image, _ = synthetic.make_rgbd(64, 96, 5)
-    pipe = Pipeline(model_paths=None, dolly=False, output_frames=True, device='cpu', steps=3)
+    pipe = Pipeline(model_paths=None, allow_random_weights=True, dolly=False, output_frames=True, device='cpu', steps=3)
     zoom = kbe.windows_for(96, 64, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
     frames = pipe(image, zoom, str(tmp_path))
     assert len(frames) == 3 and frames[0].shape == (64, 96, 3) and frames[0].dtype == np.uint8
@@ -46,7 +46,7 @@ def test_semantics_weights_come_from_a_file_when_given(tmp_path, recwarn):
     state = {'features.' + k.split('.', 2)[2]: torch.full_like(v, 0.125) if v.is_floating_point() else v for k, v in ref.state_dict().items()}
     path = str(tmp_path / 'vgg19_bn.pth')
     torch.save(state, path)
-    pipe = Pipeline(model_paths=None, device='cpu', steps=2, semantics_path=path)
+    pipe = Pipeline(model_paths=None, allow_random_weights=True, device='cpu', steps=2, semantics_path=path)
     got = pipe.moduleSemantics.state_dict()
     assert all(bool((v == 0.125).all()) for v in got.values() if v.is_floating_point())
     assert not any('semantics (VGG19-bn)' in str(w.message) for w in recwarn.list)
@@ -79,3 +79,21 @@ def test_writers_frame_order_and_channel_flips(tmp_path, monkeypatch):
         assert [int(f[0, 0, 0 if pretrained_estim else 2]) for f in seen['frames']] == [100, 101, 102, 103, 102, 101, 100] and seen['fps'] == 25
         png = np.asarray(Image.open(out / 'frames' / '3.png'))
         assert png.shape == (4, 6, 3) and int(png[0, 0, 0 if pretrained_estim else 2]) == 103 and int(png[0, 0, 1]) == 3
+
+
+def test_missing_checkpoints_fail_unless_random_weights_are_allowed(tmp_path, monkeypatch):
+    """the reference fails on a missing checkpoint (torch.load, utils.py:206); so does this package, for the three
+    network checkpoints and for the VGG weights, unless the caller asks for seeded weights."""
+    from ken_burns_effect_amd import kbe
+    from ken_burns_effect_amd.pipeline import Pipeline
+    monkeypatch.delenv('KBE_ALLOW_RANDOM_WEIGHTS', raising=False)
+    monkeypatch.delenv('KBE_SEMANTICS_PATH', raising=False)
+    with pytest.raises(FileNotFoundError, match='disparity'):
+        Pipeline(model_paths=[str(tmp_path / 'nope.tar')] * 3, device='cpu', steps=2)
+    with pytest.raises(FileNotFoundError):
+        Pipeline(model_paths=None, device='cpu', steps=2)
+    cfg, _ = kbe.parse(['--allow-random-weights'])
+    assert cfg['allow-random-weights'] is True and kbe.parse([])[0]['allow-random-weights'] is False
+    monkeypatch.setenv('KBE_ALLOW_RANDOM_WEIGHTS', '1')
+    with pytest.warns(UserWarning, match='seeded random weights'):
+        Pipeline(model_paths=None, device='cpu', steps=2)

@@ -11,7 +11,7 @@ Image.fromarray((img[0].numpy().transpose(1, 2, 0) * 255).astype(np.uint8)).save
 PY
 for extra in "" "--dolly" "--2d --write-frames"; do
   rm -rf /tmp/kbe_out
-  python -m ken_burns_effect_amd.kbe --in /tmp/x.png --out /tmp/kbe_out $extra 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -3
+  python -m ken_burns_effect_amd.kbe --in /tmp/x.png --out /tmp/kbe_out --allow-random-weights $extra 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -3
   python -c "
 import numpy as np, glob
 f = glob.glob('/tmp/kbe_out/*.npy'); a = np.load(f[0]); print('$extra ->', f[0], a.shape, a.dtype, 'std %.1f' % a.std(), 'zero frames', int((a.reshape(len(a), -1).max(1) == 0).sum()))"

@@ -10,7 +10,7 @@ size, n = int(os.environ.get('SIZE', '512')), int(os.environ.get('FRAMES', '64')
 image, _ = synthetic.make_rgbd(size, size, 9)
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    pipe = Pipeline(model_paths=None, device='cuda:0', steps=n)
+    pipe = Pipeline(model_paths=None, allow_random_weights=True, device='cuda:0', steps=n)
 zoom = kbe.windows_for(size, size, dict.fromkeys(('startU', 'startV', 'startW', 'startH', 'endU', 'endV', 'endW', 'endH')), False)
 for i in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
