@@ -75,6 +75,13 @@ KBE_API int kbe_device_info(int device, char* name, int cap);
 KBE_API int kbe_selftest_err(const float* z, size_t n, double focal, double baseline, float* fast, float* exact,
                              kbe_stream_t stream);
 
+/* Self-test hook: n quotients num[i] / den[i], once as the compiler's IEEE division (`ieee`) and once through the
+   eight-instruction sequence the frame loop uses where it knows the operands' range (`fast`: the projection's
+   (F - z) / -z of common.py:457-459 and the reciprocal of the weight sum of :686).  For operands with |den| in
+   [2^-100, 2^100] and num = 0 or |num| in the same range the two must agree bit for bit. */
+KBE_API int kbe_selftest_division(const float* num, const float* den, size_t n, float* fast, float* ieee,
+                                  kbe_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * render_pointcloud, stage by stage  (common.py:428-686)
  * ------------------------------------------------------------------------------------- */

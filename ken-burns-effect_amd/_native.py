@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
 
 # every symbol include/kbe.h declares (tests check the library exports exactly these)
 SYMBOLS = (
-    'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
+    'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_selftest_division', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
@@ -151,6 +151,12 @@ class HipKernels:
         self._check(self.lib.kbe_selftest_err(_ptr(z), _z(z.numel()), _d(float(focal)), _d(float(baseline)), _ptr(fast), _ptr(exact),
                                               _stream()), 'kbe_selftest_err')
         return fast, exact
+
+    def selftest_division(self, num, den):
+        num, den = _f32c(num).reshape(-1), _f32c(den).reshape(-1)
+        fast, ieee = torch.empty_like(num), torch.empty_like(num)
+        self._check(self.lib.kbe_selftest_division(_ptr(num), _ptr(den), _z(num.numel()), _ptr(fast), _ptr(ieee), _stream()), 'kbe_selftest_division')
+        return fast, ieee
 
     # -- render_pointcloud and its stages ------------------------------------------------
     def zsplat(self, points, W, H, focal, baseline, shift3=None, want_winner=False):

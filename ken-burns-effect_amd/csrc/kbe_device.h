@@ -45,20 +45,38 @@ struct Camera {
     float sx, sy, sz;
 };
 
+// n / d, correctly rounded, as the instructions the compiler's own expansion of an fp32 division comes down to when neither
+// v_div_scale_f32 rescales an operand nor v_div_fixup_f32 patches the result: the reciprocal estimate, one refinement of it,
+// the quotient and two residual corrections -- eight instructions instead of twelve.  Bit-identical to `n / d` whenever
+// |d| is in [2^-100, 2^100] and n is 0 or |n| in [2^-100, 2^100] (then no scaling condition of v_div_scale_f32 holds: neither operand
+// nor 1 / d nor n / d is near the denormal range, the exponents are < 96 apart, and n's exponent is above 23; v_div_fixup_f32
+// only restores the sign there, which the fmas carry anyway).  CALLERS GUARANTEE THE RANGE.  kbe_selftest_division runs it
+// against `/` on the GPU (tests/test_hip_parity.py).
+__device__ __forceinline__ float div_unscaled(float n, float d)
+{
+    float y = __builtin_amdgcn_rcpf(d);
+    y = __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+    float q = n * y;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), y, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), y, q);
+}
+
 // process_shift's per-point arithmetic: x *= z / (z + 1e-7); y likewise; then += shift.
 __device__ __forceinline__ void apply_shift(const Camera& cam, float& x, float& y, float& z)
 {
     if (cam.has_shift) {
         // z + 1e-7f == z for every z >= 2 (half an ulp is then > 1e-7): the ratio is exactly 1 and the division
-        // (11 instructions) is skipped when that holds for the whole wave
+        // (11 instructions) and the two products with it (x * 1.0f is x) are skipped when that holds for the whole wave
         const float zz = z + 0.0000001f;
-        float r = 1.0f;
         if (__ballot(zz != z) != 0ull) {        // wave-uniform
             asm volatile("" ::: "memory");      // keeps the division inside the branch (it was if-converted into a select)
-            r = z / zz;
+            const float r = z / zz;
+            x = x * r + cam.sx;
+            y = y * r + cam.sy;
+        } else {
+            x = x + cam.sx;
+            y = y + cam.sy;
         }
-        x = x * r + cam.sx;
-        y = y * r + cam.sy;
         z = z + cam.sz;
     }
 }
@@ -78,7 +96,17 @@ __device__ __forceinline__ bool project_xy(const Camera& cam, float px, float py
     // :453 (also covers :461).  `(double) pz >= 0.001` in fp32: 0.001f is the smallest float that is >= the double 0.001
     if (!(pz >= 0.001f)) return false;
     const float lvx = 0.0f - px, lvy = 0.0f - py, lvz = 0.0f - pz;
+#if defined(KBE_DIV_FAST) && !KBE_DIV_FAST
     const float dist = (cam.focal_f - pz) / lvz;               // :457-459
+#else
+    // :457-459.  pz >= 0.001 here; F - pz is 0 or at least half an ulp of the smaller of the two (>= 2^-34): with pz and
+    // F below 2^100 -- one test for the wave -- div_unscaled IS the division
+    float dist;
+    const float num = cam.focal_f - pz;
+    const bool f_small = fabsf(cam.focal_f) < 1.0e30f;             // uniform; loop-invariant where a wave places several units
+    if (f_small && __ballot(!(pz < 1.0e30f)) == 0ull) dist = div_unscaled(num, lvz);
+    else dist = num / lvz;
+#endif
     const float ix = __builtin_fmaf(dist, lvx, px);            // :465 as NVRTC (--fmad=true) emits it
     const float iy = __builtin_fmaf(dist, lvy, py);
     if (cam.fp32_centre) {                                     // wave-uniform; the normal case

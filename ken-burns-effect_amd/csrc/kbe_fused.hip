@@ -366,7 +366,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     TileLds& L = F.T;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tile = xcd_tile_rot(blockIdx.x, gridDim.x, job);
     const int tiles_x = ap->tiles_x, tiles_y = ap->tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
@@ -454,6 +454,9 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     KBE_PROBE(1);
     __syncthreads();
     KBE_PROBE(2);
+#if defined(KBE_SETPRIO) && KBE_SETPRIO
+    __builtin_amdgcn_s_setprio(KBE_SETPRIO);           // (dev) the tile's own phases ahead of other workgroups' prologues and placements
+#endif
     if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
@@ -546,11 +549,17 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     KBE_STOP_AFTER(3);                                          // (dev) + the splat
 
     // ---- the second phase reads its arguments now
+    // (the degrid and the gather need the frame's size and the two optional z planes; the planes the epilogue stores to are read
+    // in front of it: loaded here, these sixteen scalars were parked in the lanes of a vector register across the degrid and the
+    // gather -- a v_writelane each and a v_readlane to fetch it back, on a kernel bound by vector issue)
     asm volatile("" : "+s"(ap) :: "memory");
     TileOut a;
     a.cam.W = W; a.cam.H = H;
+    a.zee = ap->zee; a.zee_pre = ap->zee_pre;
+#if defined(KBE_LATE_ARGS) && !KBE_LATE_ARGS
     a.frame = ap->frame; a.depth = ap->depth; a.mask = ap->mask; a.holes = ap->holes; a.hole_count = ap->hole_count; a.bbox = ap->bbox; a.coarse = ap->coarse;
-    a.render = ap->render; a.existing = ap->existing; a.zee = ap->zee; a.zee_pre = ap->zee_pre;
+    a.render = ap->render; a.existing = ap->existing;
+#endif
 
     constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
     constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
@@ -749,8 +758,16 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 #else
     (void) total;
 #endif
+#if !defined(KBE_LATE_ARGS) || KBE_LATE_ARGS
+    asm volatile("" : "+s"(ap) :: "memory");
+    a.frame = ap->frame; a.depth = ap->depth; a.mask = ap->mask; a.holes = ap->holes; a.hole_count = ap->hole_count; a.bbox = ap->bbox; a.coarse = ap->coarse;
+    a.render = ap->render; a.existing = ap->existing;
+#endif
     tile_epilogue(a, L, acc, tile, x0, y0);
     KBE_PROBE(8);
+#if defined(KBE_SETPRIO) && KBE_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (AHEAD && KBE_AHEAD_AT != 1) {
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");

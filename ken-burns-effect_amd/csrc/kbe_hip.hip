@@ -45,6 +45,16 @@ __global__ void k_selftest_err(const float* __restrict__ z, size_t n, Camera cam
     }
 }
 
+// self-test: the frame loop's eight-instruction division (div_unscaled, kbe_device.h) against `/`
+__global__ void k_selftest_division(const float* __restrict__ num, const float* __restrict__ den, size_t n, float* __restrict__ fast, float* __restrict__ ieee)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fast[i] = div_unscaled(num[i], den[i]);
+        ieee[i] = num[i] / den[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel_pointrender_updateZee (common.py:435-507)
 // ---------------------------------------------------------------------------------------
@@ -629,6 +639,13 @@ int kbe_selftest_err(const float* z, size_t n, double focal, double baseline, fl
     const Camera cam = make_camera(1, 1, focal, baseline, nullptr);
     hipLaunchKernelGGL(k_selftest_err, dim3(2048), dim3(kBlock), 0, (hipStream_t) stream, z, n, cam, fast, exact);
     return launched("kbe_selftest_err");
+}
+
+int kbe_selftest_division(const float* num, const float* den, size_t n, float* fast, float* ieee, kbe_stream_t stream)
+{
+    KBE_REQUIRE(num && den && fast && ieee && n > 0, "kbe_selftest_division: bad arguments");
+    hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(kBlock), 0, (hipStream_t) stream, num, den, n, fast, ieee);
+    return launched("kbe_selftest_division");
 }
 
 int kbe_zkeys_clear(uint32_t* zkeys, size_t n, kbe_stream_t stream)

@@ -175,6 +175,21 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
     const int xcd = b & 7, j = b >> 3, q = n >> 3, r = n & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
+// The same for frame `job` of a launch that renders several (blockIdx.y = the frame; workgroups are dealt to the XCDs by their
+// linear id, so with gridDim.x a multiple of 8 block b of EVERY frame runs on XCD b % 8): the bands rotate with the frame, so
+// that an XCD whose band of one frame holds more work (the part of the image where surfaces overlap) gets a lighter band of
+// the next -- the launch ends with its slowest XCD (a 4-frame launch spanned 66.0 - 76.2 M cycles by XCD with every frame's
+// band fixed: profiles/r04_scatter_wave_timeline.txt).  Only when the bands are equal (n % 8 == 0): else they are not interchangeable.
+__device__ __forceinline__ int xcd_tile_rot(int b, int n, int job)
+{
+#if defined(KBE_XCD_ROT) && !KBE_XCD_ROT
+    (void) job;
+    return xcd_tile(b, n);
+#else
+    if (n & 7) return xcd_tile(b, n);
+    return (((b + job) & 7) * (n >> 3)) + (b >> 3);
+#endif
+}
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -329,7 +344,11 @@ __device__ __forceinline__ void tile_epilogue(const Args& a, TileLds& L, PixAcc 
         // q = a * y, q' = fma(fma(-den, q, a), y, q) per channel -- the correctly rounded a / den (Markstein;
         // tests/markstein_div_check.c) unless an intermediate underflows, i.e. for |a| below ~2^-100, where the
         // last bit may differ (no colour or depth of a real cloud gets there)
+#if defined(KBE_DIV_FAST) && !KBE_DIV_FAST
         const float y = 1.0f / den;
+#else
+        const float y = div_unscaled(1.0f, den);          // den = w + 1e-7 with 0 <= w <= 4 N: in [2^-24, 2^27], nowhere near a rescaling
+#endif
         auto quot = [&](float a_) { const float q = a_ * y; return __builtin_fmaf(__builtin_fmaf(-den, q, a_), y, q); };
         res[m][0] = quot(acc[m].rg.x); res[m][1] = quot(acc[m].rg.y); res[m][2] = quot(acc[m].bd.x); res[m][3] = quot(acc[m].bd.y);
         dms[m] = res[m][3] * (w > 0.0f ? 1.0f : 0.0f);

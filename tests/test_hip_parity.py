@@ -119,6 +119,40 @@ def test_fast_dbl_error_is_exact(K, focal, baseline):
     assert_bits_equal(c(fast), want, 'fast path')
 
 
+def test_unscaled_division_is_the_ieee_division(K):
+    """div_unscaled (kbe_device.h: the reciprocal estimate, its refinement, the quotient and two residual corrections -- what the
+    compiler's fp32 division is without v_div_scale / v_div_fixup) against `/` on the GPU and against numpy, on the operands the
+    frame loop gives it -- (F - z) / -z of common.py:457-459 for depths from the near plane up, 1 / (w + 1e-7) of :686 -- and on
+    random operands over the whole range its callers guarantee (exponents within +-100 of 1, a zero numerator)."""
+    rng = np.random.default_rng(5)
+    n = 6_000_000
+    nums, dens = [], []
+    for F in (512.0, 409.6, 153.60000000000002, 1536.0):
+        z = np.concatenate([10.0 ** rng.uniform(-3, 6, n // 8), rng.uniform(0.001, 4.0 * F, n // 8),
+                            np.nextafter(np.float32(F), np.float32(0), dtype=np.float32) * np.ones(4), np.float32(F) * np.ones(4)]).astype(np.float32)
+        z = z[z >= np.float32(0.001)]
+        nums.append(np.float32(F) - z)
+        dens.append(-z)
+    w = np.concatenate([rng.uniform(0, 8, n // 4), 10.0 ** rng.uniform(-12, 7, n // 4), np.zeros(8)]).astype(np.float32)
+    nums.append(np.ones_like(w))
+    dens.append(w + np.float32(0.0000001))
+    e = rng.integers(27, 227, n, dtype=np.uint32)        # biased exponents 27..226: |x| in [2^-100, 2^100)
+    m = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+    sg = rng.integers(0, 2, n, dtype=np.uint32) << np.uint32(31)
+    a = (sg | (e << np.uint32(23)) | m).view(np.float32)
+    e2 = np.clip(e.astype(np.int64) + rng.integers(-90, 91, n), 27, 226).astype(np.uint32)
+    b = ((rng.integers(0, 2, n, dtype=np.uint32) << np.uint32(31)) | (e2 << np.uint32(23)) | rng.integers(0, 1 << 23, n, dtype=np.uint32)).view(np.float32)
+    a[:1000] = 0.0
+    nums.append(a)
+    dens.append(b)
+    num, den = np.concatenate(nums), np.concatenate(dens)
+    fast, ieee = K.selftest_division(torch.from_numpy(num).cuda(), torch.from_numpy(den).cuda())
+    with np.errstate(all='ignore'):
+        want = (num.astype(np.float64) / den.astype(np.float64)).astype(np.float32)      # the double quotient rounds to the fp32 one (no double rounding: 53 >= 2 * 24 + 2)
+    assert_bits_equal(c(ieee), want, 'the compiler\'s division vs numpy')
+    assert_bits_equal(c(fast), want, 'div_unscaled')
+
+
 def test_shift_fused_equals_shift_then_render(K):
     z = load_golden('render_f512')
     W, H, F, Bl = int(z['W']), int(z['H']), float(z['focal']), _baseline(z)

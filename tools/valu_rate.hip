@@ -78,8 +78,28 @@
     X(60, "v_fma_f32 %0, %0, %1, %0\n\tv_lshl_add_u32 %0, %0, 1, %1", F, 2) \
     X(61, "v_readfirstlane_b32 s20, %0", F, 1) \
     X(62, "v_lshlrev_b64 %0, 1, %0", D, 1) \
-    X(63, "v_cvt_u32_f32 %0, %0", F, 1)
-constexpr int N_OPS = 64;
+    X(63, "v_cvt_u32_f32 %0, %0", F, 1) \
+    X(64, "v_cndmask_b32 %0, %0, %1, s[22:23]", F, 1) \
+    X(65, "v_lshrrev_b32 %0, 1, %0", F, 1) \
+    X(66, "v_subrev_u32 %0, %0, %1", F, 1) \
+    X(67, "v_not_b32 %0, %0", F, 1) \
+    X(68, "v_bcnt_u32_b32 %0, %0, %1", F, 1) \
+    X(69, "v_lshlrev_b32 %0, 2, %0", F, 1) \
+    X(70, "v_max_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1", F, 2) \
+    X(71, "v_cvt_i32_f32 %0, %0\n\tv_add_u32 %0, %0, %1", F, 2) \
+    X(72, "v_min_i32 %0, %0, %1\n\tv_and_b32 %0, %0, %1", F, 2) \
+    X(73, "v_mad_u32_u24 %0, %0, %1, %0\n\tv_mul_f32 %0, %0, %1", F, 2) \
+    X(74, "v_cmp_lt_f32 vcc, %0, %1\n\tv_add_f32 %0, %0, %1", F, 2) \
+    X(75, "v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1", F, 2) \
+    X(76, "v_max_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1", F, 3) \
+    X(77, "v_max_f32 %0, %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1", F, 3) \
+    X(78, "v_cmp_lt_f32 s[22:23], %0, %1\n\tv_cndmask_b32 %0, %0, %1, s[22:23]", F, 2) \
+    X(79, "v_sub_f32 %0, %1, %0", F, 1) \
+    X(80, "v_mul_f32 %0, %0, %1 \n\tv_xor_b32 %0, %0, %1", F, 2) \
+    X(81, "v_add_f32 %0, s24, %0", F, 1) \
+    X(82, "v_add_u32 %0, 0x12345, %0", F, 1) \
+    X(83, "v_fma_f32 %0, %0, %1, %1", F, 1)
+constexpr int N_OPS = 84;
 
 constexpr int ITER = 1024;
 
@@ -91,7 +111,7 @@ template <int OP> __device__ __forceinline__ void step(float (&f)[8], double (&d
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-#define X(id, str, cls, n) if constexpr (OP == id) asm volatile(str : "+v"(REG_##cls) : "v"(k) : "vcc", "s20");
+#define X(id, str, cls, n) if constexpr (OP == id) asm volatile(str : "+v"(REG_##cls) : "v"(k) : "vcc", "s20", "s22", "s23", "s24");
             OPS(X)
 #undef X
         }
@@ -132,8 +152,15 @@ int main(int argc, char** argv)
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("# %s: %d CUs, clockRate %.0f MHz (hipDeviceProp); %d x 32 instructions per wave per launch\n", prop.gcnArchName, cus, prop.clockRate / 1e3, ITER);
-    int ws[16] = { 1, 2, 5, 8 }, n_ws = 4;
-    if (argc > 1) { n_ws = 0; for (int i = 1; i < argc && n_ws < 16; i++) ws[n_ws++] = atoi(argv[i]); }
+    int ws[16] = { 1, 2, 5, 8 }, n_ws = 4, op_from = 0;
+    if (argc > 1) {
+        n_ws = 0;
+        for (int i = 1; i < argc && n_ws < 16; i++) {
+            if (!strncmp(argv[i], "from=", 5)) op_from = atoi(argv[i] + 5);         // only the kinds from this id on
+            else ws[n_ws++] = atoi(argv[i]);
+        }
+        if (n_ws == 0) { ws[0] = 1; ws[1] = 2; ws[2] = 5; ws[3] = 8; n_ws = 4; }
+    }
     float* sink; unsigned long long* cyc;
     CHECK(hipMalloc(&sink, 64));
     CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * cus * 32 * 2));
@@ -141,7 +168,7 @@ int main(int argc, char** argv)
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     unsigned long long* h = (unsigned long long*) malloc(sizeof(unsigned long long) * cus * 32 * 2);
     printf("%-52s %6s %13s %11s %10s %16s\n", "instruction", "w/SIMD", "wave-inst/ns", "us/launch", "clock GHz", "cycles/inst/SIMD");
-    for (int op = 0; op < N_OPS; op++)
+    for (int op = op_from; op < N_OPS; op++)
         for (int wi = 0; wi < n_ws; wi++) {
             const int w = ws[wi];
             const int blocks = cus * w;             // a workgroup of 256 threads = one wave per SIMD of a CU; w workgroups per CU
