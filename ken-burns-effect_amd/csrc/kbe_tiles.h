@@ -187,7 +187,9 @@ __device__ __forceinline__ int xcd_tile_rot(int b, int n, int job)
     return xcd_tile(b, n);
 #else
     if (n & 7) return xcd_tile(b, n);
-    return (((b + job) & 7) * (n >> 3)) + (b >> 3);
+    // (a launch of fewer than eight frames spreads its frames' bands over the eight: 4 frames -> every second band)
+    const int stride = gridDim.y >= 8 ? 1 : 8 / (int) gridDim.y;
+    return (((b + job * stride) & 7) * (n >> 3)) + (b >> 3);
 #endif
 }
 
