@@ -436,7 +436,20 @@ class HipKernels:
         launch.keep = keep
         return launch
 
-    def video_launch_shape(self, state, cameras, batch, to_host=False):
+    def scratch_set_budget(self, state):
+        """How many scratch sets (kbe_video_scratch_stride bytes each) a video loop may hold: KBE_SCRATCH_BUDGET_MB, or half of the
+        device memory that is free now plus what the cloud's sets already hold; at least one per lane."""
+        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
+        env = os.environ.get('KBE_SCRATCH_BUDGET_MB')
+        if env:
+            budget = float(env) * 1e6
+        else:
+            free, _ = torch.cuda.mem_get_info(state['points'].device)
+            held = state['scratch_groups'].numel() if 'scratch_groups' in state else 0
+            budget = 0.5 * (free + held)
+        return max(state['lanes'], int(budget // stride))
+
+    def video_launch_shape(self, state, cameras, batch, to_host=False, max_group=None):
         """(flags of kbe_render_video, frames per launch, fused route?) for a video of `cameras`.
         KBE_VIDEO_FILL_DIST, the table-driven hole fill: for videos whose frames have hundreds of thousands of holes -- a
         cloud without appended points (no inpainting) seen by a camera that zooms out (a dolly zoom lowers the focal length:
@@ -476,19 +489,31 @@ class HipKernels:
             group = 1
         if not fused:
             group = min(group, 4)
+        if max_group is not None:
+            group = max(1, min(group, int(max_group)))
         return flags | (((group - 1) << 1) if group <= 4 else ((group - 1) << 5)), group, fused
+
+    @staticmethod
+    def zooms_out(state, cameras):
+        return bool(cameras) and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
 
     def delivery_lanes(self, state, cameras, baseline, crop=None):
         """Lanes of the frame loop when the frames go to pinned host memory: two where the link binds, all where the rendering
         does (`host_lanes` has the measurements).  Which it is depends on the cloud, the camera path and the route, so it is
-        MEASURED once per cloud -- twelve of the video's frames rendered into HBM on all lanes, timed with two events (a
-        few hundred microseconds) -- and kept in the cloud's state; videos shorter than that, and the first lookup without a
-        camera path, take the a-priori estimate.  Env KBE_HOST_LANES overrides."""
+        MEASURED once per cloud, camera-path kind and crop -- twelve of the video's frames rendered into HBM on all lanes, timed
+        with two events (a few hundred microseconds, and ONE host synchronisation: the first render_video of a cloud is not
+        enqueue-only) -- and kept in the cloud's state; videos shorter than that, and the first lookup without a camera path, take
+        the a-priori estimate.  A rank that received the cloud by broadcast takes what rank 0 measured (`delivery_lanes_hint`:
+        sharding.measure_delivery_lanes) and never probes.  Env KBE_HOST_LANES overrides."""
         lanes, W, H = state['lanes'], state['W'], state['H']
         env = os.environ.get('KBE_HOST_LANES')
         if env:
             return min(lanes, max(1, int(env)))
-        key = bool(cameras) and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']      # a zoom-out renders differently: its own entry
+        zoom = self.zooms_out(state, cameras)                  # a zoom-out renders differently: its own entry
+        hint = state.get('delivery_lanes_hint', {})
+        if zoom in hint:                                       # measured on rank 0, broadcast with the cloud (sharding.py)
+            return min(lanes, max(1, int(hint[zoom])))
+        key = (zoom, None if crop is None else (int(crop[0]), int(crop[1])))
         cache = state.setdefault('delivery_lanes', {})
         if key in cache:
             return cache[key]
@@ -551,6 +576,7 @@ class HipKernels:
         cw, ch = (0, 0) if crop is None else (int(crop[0]), int(crop[1]))
         copy_stream = ctypes.c_void_p(state['copy_stream'].cuda_stream) if overlap else _stream()
         flags, group, fused = self.video_launch_shape(state, cameras, batch, to_host=not host_out.is_cuda)
+        base_flags = flags
         if fused:
             self._pack(state)
         # KBE_VIDEO_FREE_TRANSFERS: videos that fill with the tables are bound by their rendering (the link is half idle), and
@@ -563,9 +589,21 @@ class HipKernels:
             flags |= 16
         if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
             flags |= 512
+        keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again
         scratch = state['scratch']
         if group > 1:
-            scratch, _ = self.group_scratch(state, group * lanes)      # n sets per lane in use, allocated on first use (224 MB each at 1024^2)
+            # n scratch sets per lane in use, allocated on first use -- 224 MB each at 1024^2, 0.9 GB at 2048^2 (most of it the
+            # bucket / spill area): a launch shape that would take more than the budget (KBE_SCRATCH_BUDGET_MB, default half of
+            # what is free, never less than one set per lane) falls back to fewer frames per launch
+            max_sets, fits = self.scratch_set_budget(state), group
+            while fits > 1 and fits * lanes > max_sets:
+                fits = max(1, fits // 2)
+            if fits != group:
+                flags, group, fused = self.video_launch_shape(state, cameras, batch, to_host=not host_out.is_cuda, max_group=fits)
+                flags |= keep_flags
+        state['video_sets'] = group * lanes
+        if group > 1:
+            scratch, _ = self.group_scratch(state, group * lanes)
         self._check(self.lib.kbe_render_video(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']), _i(state['N']),
                                               _i(W), _i(H), _d(float(baseline)), _i(n), focals, shifts, _i(cw), _i(ch),
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),

@@ -307,6 +307,8 @@ def _prepared_cloud(K, objectCommon):
                                 objectCommon['dblFocal'], raster=objectCommon.get('_kbeCloudRaster'))
         cached = (key, state, tensors)        # keeps the tensors alive so that data_ptr stays a valid identity
         objectCommon['_kbePreparedCloud'] = cached
+    if '_kbeDeliveryLanes' in objectCommon:   # measured by rank 0 and broadcast with the cloud (sharding.py): no probe on this rank
+        cached[1]['delivery_lanes_hint'] = dict(objectCommon['_kbeDeliveryLanes'])
     return cached[1]
 
 

@@ -71,8 +71,13 @@ def broadcast_cloud(objectCommon, device, src=0):
     header = torch.zeros(16, dtype=torch.float64, device=device)
     if rank == src:
         dr = objectCommon['objectDepthrange']
+        # [12], [13]: the lanes rank `src` MEASURED for delivering this cloud's frames to host memory (ordinary camera path /
+        # zoom-out; 0 = not measured): the other ranks take them instead of probing -- eight ranks timing twelve frames each
+        # while their neighbours load the host memory system would each measure the others (measure_delivery_lanes below)
+        hint = objectCommon.get('_kbeDeliveryLanes', {})
         vals = [objectCommon['tensorInpaPoints'].shape[-1]] + [objectCommon[k] for k in _SCALAR_KEYS] + \
-               [dr[0], dr[1], dr[2][0], dr[2][1], dr[3][0], dr[3][1], 1.0 if isinstance(objectCommon['dblBaseline'], int) else 0.0]
+               [dr[0], dr[1], dr[2][0], dr[2][1], dr[3][0], dr[3][1], 1.0 if isinstance(objectCommon['dblBaseline'], int) else 0.0,
+                float(hint.get(False, 0)), float(hint.get(True, 0))]
         header[:len(vals)] = torch.tensor(vals, dtype=torch.float64)
     dist.broadcast(header, src)
     h = header.cpu().tolist()
@@ -95,7 +100,26 @@ def broadcast_cloud(objectCommon, device, src=0):
         objectCommon['tensorInpaPoints'] = packed[0:3].unsqueeze(0)
         objectCommon['tensorInpaImage'] = packed[3:6].unsqueeze(0)
         objectCommon['tensorInpaDepth'] = packed[6:7].unsqueeze(0)
+        hint = {key: int(v) for key, v in ((False, h[12]), (True, h[13])) if int(v) > 0}
+        if hint:
+            objectCommon['_kbeDeliveryLanes'] = hint
     return objectCommon
+
+
+def measure_delivery_lanes(objectSettings, objectCommon):
+    """Rank 0, before broadcast_cloud: how many lanes deliver this video's frames to host memory fastest (the renderer's own
+    probe, HipKernels.delivery_lanes: twelve frames timed with two events), noted in ``objectCommon`` so that the broadcast's
+    header carries it to every rank.  Without a GPU renderer (the CPU tests' kernel sets) nothing is measured."""
+    from . import common
+    K = common._K()
+    if not hasattr(K, 'delivery_lanes') or 'tensorInpaPoints' not in objectCommon or not objectCommon['tensorInpaPoints'].is_cuda:
+        return None
+    cameras = common.frame_cameras(objectSettings, objectCommon)
+    crop = common.crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
+    state = common._prepared_cloud(K, objectCommon)
+    lanes = K.delivery_lanes(state, cameras, objectCommon['dblBaseline'], crop)
+    objectCommon['_kbeDeliveryLanes'] = {K.zooms_out(state, cameras): int(lanes)}
+    return lanes
 
 
 def gather_frames(local_frames, indices, total, device, dst=0):
@@ -142,6 +166,8 @@ def _process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, devic
     elif rank == 0:
         if 'tensorInpaPoints' not in objectCommon:
             common._reset_inpa(objectCommon)
+    if rank == 0 and world_size > 1 and not gather:
+        measure_delivery_lanes(objectSettings, objectCommon)
     broadcast_cloud(objectCommon, device)
     idx, steps = shard_steps(objectSettings['dblSteps'], rank, world_size)
     local_settings = dict(objectSettings, dblSteps=steps)

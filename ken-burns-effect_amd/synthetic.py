@@ -23,10 +23,39 @@ FOCAL = 1024.0 / 2   # utils/pipeline.py:26
 BASELINE = 120       # utils/pipeline.py:27 (an *int* there; see include/kbe.h)
 
 
-def make_rgbd(height, width, seed=0, kind='smooth', baseline=BASELINE):
-    """Returns (image[1,3,H,W], disparity[1,1,H,W]) as float32 CPU tensors."""
+def photo_like(image, cell=24):
+    """A photograph's statistics from white noise: the seeded colours low-passed -- a coarse grid of them (one per `cell` pixels)
+    interpolated bilinearly -- plus a tenth of the noise as texture.  Pure numpy on the host, float64 inside: the same bits
+    in the build container and on the GPU box."""
+    _, C, H, W = image.shape
+    gh, gw = H // cell + 2, W // cell + 2
+    coarse = image[0, :, :gh * 1, :gw * 1].astype(np.float64) if (gh <= H and gw <= W) else None
+    if coarse is None:
+        return image
+    ys = (np.arange(H, dtype=np.float64) + 0.5) / cell
+    xs = (np.arange(W, dtype=np.float64) + 0.5) / cell
+    y0 = np.minimum(np.floor(ys).astype(np.int64), gh - 2)
+    x0 = np.minimum(np.floor(xs).astype(np.int64), gw - 2)
+    fy = (ys - y0)[None, :, None]
+    fx = (xs - x0)[None, None, :]
+    a = coarse[:, y0][:, :, x0]
+    b = coarse[:, y0][:, :, x0 + 1]
+    c = coarse[:, y0 + 1][:, :, x0]
+    d = coarse[:, y0 + 1][:, :, x0 + 1]
+    low = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+    out = 0.9 * low + 0.1 * image[0].astype(np.float64)
+    return np.ascontiguousarray(out.astype(np.float32))[None]
+
+
+def make_rgbd(height, width, seed=0, kind='smooth', baseline=BASELINE, colours='noise'):
+    """Returns (image[1,3,H,W], disparity[1,1,H,W]) as float32 CPU tensors.  colours: 'noise' (uniform [0, 1): SURVEY.md 8d)
+    or 'photo' (the same noise low-passed: photo_like)."""
     rng = np.random.default_rng(seed)
     image = rng.random((1, 3, height, width), dtype=np.float32)
+    if colours == 'photo':
+        image = photo_like(image)
+    elif colours != 'noise':
+        raise ValueError('unknown colours: ' + str(colours))
     ys = np.arange(height, dtype=np.float64)[:, None]
     xs = np.arange(width, dtype=np.float64)[None, :]
     if kind == 'smooth':

@@ -44,7 +44,7 @@ def at_size_scene(z, device, depth_to_points):
     """(settings, objectCommon) of a tests/golden/kenburns_at_size_*.npz fixture: the inputs are regenerated from its seed."""
     from ken_burns_effect_amd import synthetic
     H, W, dolly = int(z['H']), int(z['W']), bool(z['dolly'])
-    image, disp = synthetic.make_rgbd(H, W, int(z['seed']), 'smooth')
+    image, disp = synthetic.make_rgbd(H, W, int(z['seed']), 'smooth', colours=str(z['colours']) if 'colours' in z else 'noise')
     depth = (512.0 * 120) / (disp + 1e-7)
     oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H, 'dblDispmin': disp.min().item(), 'dblDispmax': disp.max().item(),
           'objectDepthrange': synthetic.depthrange_of(depth), 'tensorRawImage': image.to(device), 'tensorRawDisparity': disp.to(device),

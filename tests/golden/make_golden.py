@@ -531,8 +531,11 @@ def gen_kenburns_at_size():
     net = h.PI.Inpaint().eval()
     synthetic.seeded_fill_(net, 3)
     H, W = 256, 320
-    for tag, (seed, dolly, steps) in {'kbe': (61, False, [0.0, 0.35, 0.7, 1.0]), 'dolly': (62, True, [0.0, 0.4, 0.8])}.items():
-        image, disp = synthetic.make_rgbd(H, W, seed, 'smooth')
+    # (kbe_photo: the same scene kind with photograph-like colours -- synthetic.photo_like -- where a pixel that takes another source
+    # point moves by a few counts instead of up to 255: the PSNR between two legal degrid schedules means something there)
+    for tag, (seed, dolly, steps, colours) in {'kbe': (61, False, [0.0, 0.35, 0.7, 1.0], 'noise'), 'dolly': (62, True, [0.0, 0.4, 0.8], 'noise'),
+                                               'kbe_photo': (63, False, [0.0, 0.35, 0.7, 1.0], 'photo'), 'dolly_photo': (64, True, [0.0, 0.4, 0.8], 'photo')}.items():
+        image, disp = synthetic.make_rgbd(H, W, seed, 'smooth', colours=colours)
         depth = (512.0 * 120) / (disp + 1e-7)
         pts = h.C.depth_to_points(depth, 512.0)
         common = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H,
@@ -544,8 +547,9 @@ def gen_kenburns_at_size():
         settings = {'dblSteps': steps, 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
         with torch.no_grad():
             frames, _ = h.traced(h.C.process_kenburns, settings, common, net)
+        extra = {} if colours == 'noise' else {'colours': np.array(colours)}         # (the two noise fixtures keep their bytes)
         save('kenburns_at_size_' + tag, frames=np.stack(frames), steps=np.array(steps, np.float64), dolly=np.bool_(dolly), seed=np.int64(seed),
-             H=np.int64(H), W=np.int64(W), n_points=np.int64(common['tensorInpaPoints'].shape[-1]))
+             H=np.int64(H), W=np.int64(W), n_points=np.int64(common['tensorInpaPoints'].shape[-1]), **extra)
 
 
 def gen_generate_mask():

@@ -152,3 +152,35 @@ def test_one_launch_scatter_at_1024_equals_the_two_launches(K, dense_cloud):
     # 16.8 M points on a 2048^2 raster: eight units of 64 points per wave of the tile launch -- too many to ride along
     assert K.lib.kbe_render_frame_group_ahead_ok(dense_cloud[1].shape[2], 2048, 2048, 4, 4) == 0
     assert K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 1, 12) == 0 and K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 8, 0) == 0
+
+
+def test_config4_2048_multi_pass_inpaint_then_frames_against_the_oracle(K, oracle):
+    """BASELINE.json configs[4]'s "multi-pass inpaint" at 2048 x 2048: process_kenburns with boolInpaint=True (common.py:181-219 on a
+    2048^2 image: two end poses, each through the 68-channel warp of kbe_render_pointcloud_tiled and the Inpaint network --
+    seeded weights -- with the pixels that pose cannot see appended), then frames of the loop (:222-255) compared value for value
+    with the oracle rendering the SAME grown cloud with the same cameras (Jacobi schedule, the product's)."""
+    from ken_burns_effect_amd import common, synthetic
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    size = 2048
+    image, disp = synthetic.make_rgbd(size, size, seed=5, colours='photo')
+    depth = (synthetic.FOCAL * 2 * synthetic.BASELINE) / (disp + 1e-7)            # focal 2 F: the 1024^2 camera at twice the resolution
+    focal = synthetic.FOCAL * 2
+    oc = {'dblFocal': focal, 'dblBaseline': synthetic.BASELINE, 'intWidth': size, 'intHeight': size, 'dblDispmin': float(disp.min()), 'dblDispmax': float(disp.max()),
+          'objectDepthrange': synthetic.depthrange_of(depth), 'tensorRawImage': image.cuda(), 'tensorRawDisparity': disp.cuda(), 'tensorRawDepth': depth.cuda()}
+    oc['tensorRawPoints'] = K.depth_to_points(oc['tensorRawDepth'], focal).view(1, 3, -1)
+    ofrom, oto = synthetic.default_windows(size, size, False)
+    steps = [0.0, 0.45, 1.0]
+    settings = {'dblSteps': steps, 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False, 'boolCrop': False}
+    net = synthetic.seeded_fill_(Inpaint(), 3).cuda().eval()
+    with torch.no_grad():
+        frames = common.process_kenburns(settings, oc, net)
+    n = oc['tensorInpaPoints'].shape[-1]
+    assert len(frames) == len(steps) and frames[0].shape == (size, size, 3)
+    assert size * size * 1.005 < n < size * size * 1.25, 'both passes appended points: %d' % n
+    ok = oracle.OracleKernels(schedule='jacobi')
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), size, size)
+    for k in (0, 2):
+        focal_k, shift3 = common.frame_cameras(settings, oc)[k]
+        ref = ok.render_frame(state, shift3, focal_k, oc['dblBaseline']).numpy()
+        d = np.abs(frames[k].astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, 'frame %d of the 2048^2 video: %d values differ from the oracle, max %d' % (k, int((d > 0).sum()), int(d.max()))

@@ -1212,18 +1212,17 @@ def test_sharded_video_on_the_hip_path_two_ranks():
 
 def test_hand_off_turns_with_four_processes_on_one_gpu():
     """Four ranks share this GPU (gloo), each delivering videos to its own pinned host memory on two lanes that take turns on
-    the link: every pass delivers the same frames, and no pass takes longer than twice its rank's median -- the turns' bounded
+    the link: every pass delivers the same frames, a rank's second-slowest pass stays within twice its median and its slowest within four
+    times -- the turns' bounded
     device-side wait is never what a pass waits for (tools/turn_check.py)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for attempt in range(2):        # four processes time-slice one GPU: a pass can lose a slice to a neighbour (seen: 1.2-1.7 x); one more try
-        out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
-                              '--master-port', str(29537 + attempt), os.path.join(root, 'tools', 'turn_check.py')],
-                             capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
-        if out.returncode == 0 and 'OK' in out.stdout:
-            break
+    # (no second try: the bound tools/turn_check.py applies allows a rank ONE pass that lost a time slice to a neighbour)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+                          '--master-port', '29537', os.path.join(root, 'tools', 'turn_check.py')],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

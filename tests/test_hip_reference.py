@@ -128,7 +128,13 @@ def test_reference_run_frames_on_the_hip_kernels_serial_schedule(K, monkeypatch,
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, 'frame %d: %d values differ, max %d' % (i, int((d > 0).sum()), int(d.max()))
 
 
-@pytest.mark.parametrize('tag', ['kbe', 'dolly'])
+# floors for the shipped route against the reference-run frames (tests/test_host_logic.py measures the same on the CPU oracle:
+# photograph-like colours 44-52 dB on the KBE path -- what is left are pixels one degrid schedule hands to the seeded-random
+# Inpaint network's colours and the other to the surface -- and 50-59 dB on the dolly zoom)
+PRODUCT_FLOOR_DB = {'kbe': 30.0, 'dolly': 30.0, 'kbe_photo': 43.0, 'dolly_photo': 49.0}
+
+
+@pytest.mark.parametrize('tag', ['kbe', 'dolly', 'kbe_photo', 'dolly_photo'])
 def test_product_route_against_reference_run_frames_at_size(K, tag):
     """The SHIPPED route -- the tile kernels with their out-of-place (Jacobi) degrid, their own accumulation order, the Inpaint
     network on MIOpen -- against the frames the reference's process_kenburns produced at 256 x 320 (kernel text run serially;
@@ -150,7 +156,7 @@ def test_product_route_against_reference_run_frames_at_size(K, tag):
     for i, (f, ref) in enumerate(zip(frames, z['frames'])):
         moved = (np.abs(f.astype(np.int32) - ref.astype(np.int32)).max(axis=2) > 1).mean()
         db = psnr_u8(f, ref)
-        assert db > 30.0 and moved < 0.01, 'frame %d: %.2f dB against the reference-run frame, %.3f %% of the pixels moved by more than one count' % (i, db, 100 * moved)
+        assert db > PRODUCT_FLOOR_DB[tag] and moved < 0.01, 'frame %d: %.2f dB against the reference-run frame, %.3f %% of the pixels moved by more than one count' % (i, db, 100 * moved)
 
 
 @pytest.mark.parametrize('case', ['render_f512', 'render_f409', 'render_f153', 'render_noise', 'render_b2c7'])
@@ -303,6 +309,42 @@ def test_partial_inpaint_forward_on_the_gpu_matches_reference(K):
     assert list(out['tensorMaskOut'].shape) == [int(v) for v in z['fw_existing_shape']] and out['tensorExisting'].shape[1] == 1
     _close(out['tensorImage'], z['fw_image'], 2 * TOL_IMAGE, 'partial Inpaint image')
     _close(out['tensorDisparity'], z['fw_disparity'], 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(z['fw_disparity']).max())), 'partial Inpaint disparity')
+
+
+def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_formulation(K):
+    """BASELINE configs[3] "4b" at its size: the partial-convolution Inpaint.forward on a 1024 x 1024 input (68 channels, a mask
+    with a fifth of the pixels missing, in blobs and single pixels), every PartialConv2d through the fused epilogue
+    (kbe_pconv_epilogue) against the same network with every layer in the reference's formulation (the mask's own convolution
+    and five element-wise passes, /root/reference/utils/partial_conv.py:58-77; bench.partial_conv_reference_forward): the
+    propagated masks equal, image and disparity within twice the tolerance of the 32 x 40 fixture test above."""
+    import bench
+    from ken_burns_effect_amd import partial_conv, synthetic
+    from ken_burns_effect_amd.partial_inpainting import Inpaint
+    big = 1024
+    net = synthetic.seeded_fill_(Inpaint().eval(), 5).cuda()
+    gen = torch.Generator(device='cpu').manual_seed(21)
+    data = torch.randn(1, 68, big, big, generator=gen).cuda()
+    coarse = (torch.rand(1, 1, big // 16, big // 16, generator=gen) > 0.15).float()
+    mask = (torch.nn.functional.interpolate(coarse, size=(big, big), mode='nearest') * (torch.rand(1, 1, big, big, generator=gen) > 0.05).float()).cuda()
+    image, disp = synthetic.make_rgbd(big, big, 44, 'smooth')
+    with torch.no_grad():
+        net.normalize_images_disp(image.cuda(), disp.cuda(), not_normed=True)
+        fused = net(tensorData=data, tensorMasks=mask)
+        fused = {k: v.clone() for k, v in fused.items() if torch.is_tensor(v)}
+        fused_forward = partial_conv.PartialConv2d.forward
+        partial_conv.PartialConv2d.forward = bench.partial_conv_reference_forward
+        for m in net.modules():
+            if isinstance(m, partial_conv.PartialConv2d):
+                m.last_size = (None, None, None, None)
+        try:
+            ref = net(tensorData=data, tensorMasks=mask)
+        finally:
+            partial_conv.PartialConv2d.forward = fused_forward
+    assert torch.equal(fused['tensorMaskOut'], ref['tensorMaskOut']) and torch.equal(fused['tensorExisting'], ref['tensorExisting'])
+    assert 0.05 < float(1 - mask.mean()) < 0.4
+    _close(fused['tensorImage'], c(ref['tensorImage']), 2 * TOL_IMAGE, 'partial Inpaint image at 1024^2')
+    dref = c(ref['tensorDisparity'])
+    _close(fused['tensorDisparity'], dref, 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(dref).max())), 'partial Inpaint disparity at 1024^2')
 
 
 # ---------------------------------------------------------------------------------------

@@ -106,7 +106,14 @@ def test_jacobi_schedule_stays_close_to_serial(oracle, monkeypatch):
     assert 0.0 < diff < 0.25
 
 
-@pytest.mark.parametrize('tag', ['kbe', 'dolly'])
+# PSNR floors of the product's (Jacobi) schedule against the reference-run frames; measured on the CPU oracle: noise colours KBE
+# 32.2-36.1 dB, dolly 33.9-43.5; photograph-like colours (synthetic.photo_like) KBE 44.2-51.6 dB (0.10-0.34 % of the pixels moved
+# by more than a count, by up to 153: pixels that one schedule leaves to the SEEDED-RANDOM Inpaint network's colours and the
+# other to the surface -- a trained network's colours would blend in), dolly 50.2-59.0 dB (no network there, moves of <= 70)
+JACOBI_FLOOR_DB = {'kbe': 30.0, 'dolly': 30.0, 'kbe_photo': 43.0, 'dolly_photo': 49.0}
+
+
+@pytest.mark.parametrize('tag', ['kbe', 'dolly', 'kbe_photo', 'dolly_photo'])
 def test_reference_frames_at_size_byte_for_byte_and_where_the_jacobi_schedule_moves_them(oracle, monkeypatch, tag):
     """process_kenburns of the REFERENCE at 256 x 320 (kernel text executed serially; tests/golden/make_golden.py
     gen_kenburns_at_size) against this package's host logic + its own Inpaint module + the oracle:
@@ -140,7 +147,7 @@ def test_reference_frames_at_size_byte_for_byte_and_where_the_jacobi_schedule_mo
         assert np.array_equal(fs.numpy(), ref)
         assert not (moved & ~dz & ~holes).any(), 'frame %d: a pixel moved that is neither a hole nor a pixel whose z the schedules degrid differently' % i
         # measured: KBE 32.3-36.7 dB with 394-509 of 81 920 pixels moved; dolly 33.9-43.5 dB, 84-175 pixels
-        assert psnr_u8(fj.numpy(), ref) > 30.0 and moved.mean() < 0.01, 'frame %d: %.2f dB, %d pixels' % (i, psnr_u8(fj.numpy(), ref), int(moved.sum()))
+        assert psnr_u8(fj.numpy(), ref) > JACOBI_FLOOR_DB[tag] and moved.mean() < 0.01, 'frame %d: %.2f dB, %d pixels' % (i, psnr_u8(fj.numpy(), ref), int(moved.sum()))
 
 
 def test_crop_is_applied_by_default(common):

@@ -83,6 +83,63 @@ def test_two_ranks_render_the_same_video_as_one(tmp_path):
     assert np.array_equal(sharded, single)
 
 
+def _worker_many(rank, world_size, port, out_dir, n_frames):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from ken_burns_effect_amd import common, sharding
+        from oracle import kbe_oracle
+        common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+        settings, oc = _scene()
+        settings['dblSteps'] = [i / (n_frames - 1.0) for i in range(n_frames)]
+        if rank != 0:
+            oc = {}
+        else:
+            common._reset_inpa(oc)
+            oc['_kbeDeliveryLanes'] = {False: 3}        # what rank 0 measured travels with the cloud's header
+        idx, mine = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'))       # every rank keeps its frames
+        assert oc['_kbeDeliveryLanes'] == {False: 3}
+        assert idx == list(range(rank, n_frames, world_size)) and len(mine) == len(idx)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), idx=np.array(idx), frames=np.stack(mine))
+        full = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'), gather=True)
+        if rank == 0:
+            np.save(os.path.join(out_dir, 'gathered.npy'), np.stack(full))
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_render_a_75_frame_video_as_one_process_does(tmp_path):
+    """The product's video length on a node's worth of ranks (gloo, CPU, the oracle as the kernel set): 75 frames over 8 ranks --
+    an uneven 10 / 9 split -- every rank keeping its own frames (the default) and gathered on rank 0: both byte-identical to one
+    process rendering the same steps."""
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import common
+    from oracle import kbe_oracle
+    n_frames, world_size = 75, 8
+    mp.spawn(_worker_many, args=(world_size, _free_port(), str(tmp_path), n_frames), nprocs=world_size, join=True)
+    common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+    try:
+        settings, oc = _scene()
+        settings['dblSteps'] = [i / (n_frames - 1.0) for i in range(n_frames)]
+        common._reset_inpa(oc)
+        single = np.stack(common.process_kenburns(settings, oc, None))
+    finally:
+        common._kernel_set = None
+    kept = np.zeros_like(single)
+    counts = []
+    for r in range(world_size):
+        z = np.load(str(tmp_path / ('rank%d.npz' % r)))
+        kept[z['idx']] = z['frames']
+        counts.append(len(z['idx']))
+    assert counts == [10, 10, 10, 9, 9, 9, 9, 9]
+    assert np.array_equal(kept, single), 'frames the ranks kept'
+    assert np.array_equal(np.load(str(tmp_path / 'gathered.npy')), single), 'frames gathered on rank 0'
+
+
 def test_shard_steps_partition():
     from ken_burns_effect_amd import sharding
     steps = list(range(10))
