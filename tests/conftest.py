@@ -4,6 +4,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault('KBE_MIOPEN_FIND', '0')      # no MIOpen find step (20-50 s per process) inside the test suite
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -97,3 +97,42 @@ def test_missing_checkpoints_fail_unless_random_weights_are_allowed(tmp_path, mo
     monkeypatch.setenv('KBE_ALLOW_RANDOM_WEIGHTS', '1')
     with pytest.warns(UserWarning, match='seeded random weights'):
         Pipeline(model_paths=None, device='cpu', steps=2)
+
+
+def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch, capsys):
+    """Pipeline(miopen_find='auto'), the default: the first call for an image size this machine has not tuned runs under MIOpen's
+    find step (torch.backends.cudnn.benchmark) and leaves a marker; later calls -- and other sizes' markers -- do not switch it on
+    again.  (Stubbed: no network runs here; the modes' timings are in profiles/r04_networks.txt.)"""
+    from ken_burns_effect_amd import pipeline as P
+    monkeypatch.setenv('KBE_CACHE_DIR', str(tmp_path))
+    monkeypatch.delenv('KBE_MIOPEN_FIND', raising=False)
+    seen = []
+
+    class Stub(P.Pipeline):
+        def __init__(self):
+            self.output_frames, self.dolly, self.steps, self.objectCommon, self.moduleInpaint = False, False, 2, {}, None
+            self.partial_inpainting, self.moduleRefine, self.miopen_find = False, None, 'auto'
+            self.device = type('D', (), {'type': 'cuda'})()
+
+        def tuning_marker(self, width, height):
+            return str(tmp_path / 'miopen-tuned' / ('%dx%d' % (width, height)))
+
+        def estimate(self, tensorImage):
+            seen.append(torch.backends.cudnn.benchmark)
+            return self.objectCommon
+
+    monkeypatch.setattr(P.common, 'process_kenburns', lambda *a, **k: [])
+    monkeypatch.setattr(P.common, 'on_device_of', lambda *_: __import__('contextlib').nullcontext())
+    before = torch.backends.cudnn.benchmark
+    pipe = Stub()
+    zoom = {'objectFrom': {}, 'objectTo': {}}
+    pipe(torch.zeros(1, 3, 64, 96), zoom)
+    pipe(torch.zeros(1, 3, 64, 96), zoom)
+    pipe(torch.zeros(1, 3, 32, 48), zoom)
+    assert seen == [True, False, True] and torch.backends.cudnn.benchmark == before
+    assert (tmp_path / 'miopen-tuned' / '96x64').exists() and 'measures its convolution solvers once' in capsys.readouterr().err
+    # explicit settings: never / always
+    assert P.Pipeline.__init__.__defaults__ is not None
+    monkeypatch.setenv('KBE_MIOPEN_FIND', '0')
+    real = P.Pipeline(model_paths=None, allow_random_weights=True, device='cpu', steps=2)
+    assert real.miopen_find is False and 'plain' in real.tuning_marker(96, 64) and '96x64' in real.tuning_marker(96, 64)

@@ -3,13 +3,15 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
 from ken_burns_effect_amd import synthetic
 from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+if os.environ.get('NET') == 'partial':
+    from ken_burns_effect_amd.partial_inpainting import Inpaint
 dev = torch.device('cuda:0')
 size = int(os.environ.get('SIZE', '1024'))
 if os.environ.get('BENCHMARK') == '1':
     torch.backends.cudnn.benchmark = True
 net = synthetic.seeded_fill_(Inpaint(), 3).to(dev).eval()
 net.compute_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(os.environ.get('DTYPE', ''))
-data = torch.randn(1, 68, size, size, device=dev); mask = torch.ones(1, 1, size, size, device=dev)
+data = torch.randn(1, 68, size, size, device=dev); mask = (torch.rand(1, 1, size, size, device=dev) > 0.2).float()
 if os.environ.get('CL') == '1':
     net = net.to(memory_format=torch.channels_last); data = data.contiguous(memory_format=torch.channels_last)
 def T(fn, n=5):
