@@ -379,7 +379,8 @@ def pipeline_bench(args, device):
         'ms_per_step': call_s * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: %dx%d image -> Semantics + Disparity + Refine -> point cloud -> 2 inpaint passes -> %d frames in host memory; '
                                'a step = one whole video; seeded random weights' % (size, size, frames_per_video),
-                   'miopen_find': True if args.miopen_find else pipe.miopen_find,      # 'auto': the find step ran in the first warm-up call if this machine had not tuned this size 'call_ms': {'median': round(call_s * 1e3, 2), 'min': round(min(call_ts) * 1e3, 2), 'max': round(max(call_ts) * 1e3, 2)}},
+                   # ('auto': the find step ran in the first warm-up call if this machine had not tuned this size)
+                   'miopen_find': True if args.miopen_find else pipe.miopen_find, 'call_ms': {'median': round(call_s * 1e3, 2), 'min': round(min(call_ts) * 1e3, 2), 'max': round(max(call_ts) * 1e3, 2)}},
         'stages_ms': {'estimate (resize + 3 networks + unprojection)': round(est_s * 1e3, 2), 'point cloud growth (2 x context net, 68-channel warp, Inpaint forward)': round(grow_s * 1e3, 2),
                       'frame loop (%d frames delivered)' % frames_per_video: round(loop_s * 1e3, 2)},
         'partial_inpaint_1024': {'what': 'SURVEY 8d "4b": partial-convolution Inpaint.forward at 1024x1024, fp32 on MIOpen',

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 7
+#define KBE_ABI_VERSION 8
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -272,8 +272,10 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
  * NEXT group -- k_place's work spread over the tile launch's waves, whose waits for memory it fills -- so that the scatter
  * of a group is ONE launch.  A scratch set holds two banks of placements, lists and counters; the k-th use of a set in the
  * sequence (turns [n]: k >= 0, counted per set; a set on turn 0 has its counters zeroed in front of the launch that first
- * names it) renders from bank k & 1 and uses hole counter k & 1; a sequence must END with a call that places nothing ahead
- * (the banks are then empty again).  placed != 0: the group's placements exist (the previous call named these frames, sets and turns as its
+ * names it -- the hole counters, the list totals and BOTH banks of list counters, so a sequence that was abandoned after a call
+ * that placed ahead, or that ended in an error, costs the next one nothing but that reset) renders from bank k & 1 and uses
+ * hole counter k & 1; a sequence should END with a call that places nothing ahead (the banks are then empty again; a set used
+ * with parity -1 / by kbe_render_frame_fused afterwards relies on that).  Every argument is validated before anything is enqueued.  placed != 0: the group's placements exist (the previous call named these frames, sets and turns as its
  * `next`), else a placement launch is made in front of the tile launch.  n_next > 0: the tile launch makes the placements
  * of the frames next_* (the cameras, sets and turns the next call will render with; a set that both groups use has
  * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
@@ -308,7 +310,7 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  * frame has landed and every lane is idle.
  * Hand-off to pinned (device-visible) host memory happens in the lanes' own streams (no copy stream, no event), the
  * lanes taking turns on the PCIe link (a bounded, advisory device-side wait), by `batch`:
- *   batch < 0: groups of up to G = -batch consecutive frames (the first ones smaller: 1, 2, 4, ...; KBE_VIDEO_EVEN_GROUPS) are
+ *   batch < 0: groups of up to G = -batch consecutive frames (the first ones smaller: 1, 2, 4, ... or, with KBE_VIDEO_FAST_RAMP, 1, 3, 7, ...; KBE_VIDEO_EVEN_GROUPS: all of size G) are
  *       rendered by one lane into its own G buffers and leave with ONE hipMemcpyAsync per group (the runtime's transfer engine).  The default of the Python host side:
  *       G = 16 on 2 lanes keeps the link busy back to back (58 us per 1024^2 frame, 54 GB/s of PCIe Gen5 x16; G = 8: 59 us).
  *   batch == 0: per frame, by a small copy kernel (k_deliver: 16 workgroups, 16-byte stores, throttled).
@@ -320,7 +322,9 @@ KBE_API int kbe_render_pointcloud_tiled(const float* points, const float* data, 
  *   scratch: lanes * kbe_video_scratch_stride(W, H, N) bytes (n times that with KBE_VIDEO_FILL_GROUP(n)), each lane's part
  *            initialised with kbe_frame_scratch_init;
  *   stage:   DEVICE buffer, 256-byte aligned, of kbe_video_stage_bytes(W, H, lanes, batch) bytes.
- * The call creates and destroys its HIP events. */
+ * The call creates and destroys its HIP events (the one exception to "nothing is allocated": conventions at the top), and on the
+ * fused route starts by zeroing every scratch set's counters -- hole counters, list totals, both banks of list counters -- so a
+ * previous call that ended in an error leaves nothing behind. */
 #define KBE_MAX_LANES 8
 KBE_API size_t kbe_video_scratch_stride(int W, int H, int N);
 KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
@@ -346,6 +350,11 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * of a lane's group also makes the placements of the lane's NEXT group (kbe_render_frame_group_ahead) unless that group is
  * larger (the ramp at the start of a delivered video), so that the scatter of a group is one launch. */
 #define KBE_VIDEO_NO_AHEAD 512
+/* the transfer groups of the hand-off by groups grow 1, 3, 7, 15, 31, ... (each twice the last plus one) instead of 1, 2, 4, 8, ...:
+ * the link needs 25 us + 57 us per 1024^2 frame for a group while the next group renders at 20-30 us per frame, so a group may
+ * be a little more than twice the one in flight -- and every transfer saved is ~25 us of link time (a 20-frame video: 4 transfers
+ * instead of 6, a 75-frame video 6 instead of 8).  The last group takes what is left. */
+#define KBE_VIDEO_FAST_RAMP 1024
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

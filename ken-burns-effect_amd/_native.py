@@ -24,7 +24,7 @@ SYMBOLS = (
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
 )
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
@@ -560,7 +560,10 @@ class HipKernels:
                     raise KbeError('KBE_DELIVERY_BATCH=%r is not an integer (frames per transfer: < 0 groups per lane, > 0 staged ring)' % env)
                 # groups of up to 32 frames per transfer (the first ones ramp 1, 2, 4, 8, 16: include/kbe.h; 16 -> 32: 17.3 -> 17.5 k frames/s); a short video's groups stay
                 # small enough for each lane to have two of full size
-                batch = batch or -max(1, min(32, n // (2 * lanes)))
+                # (KBE_RAMP=fast, the default: groups of 1, 3, 7, 15, 31, ... frames -- two transfers fewer than 1, 2, 4, 8, ... for a 20- or a
+                # 75-frame video, ~25 us of link time each; their cap is then half the video, so that a short video ends 1, 3, 7, 9)
+                fast_ramp = os.environ.get('KBE_RAMP', 'fast') == 'fast'
+                batch = batch or -max(1, min(32, max(n // (2 * lanes), (n + 1) // 2 if fast_ramp else 0)))
         # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
         batch = int(batch)
         batch = -min(-batch, max(n, 1), 64) if batch < 0 else min(batch, max(n, 1), 64)
@@ -587,6 +590,8 @@ class HipKernels:
             flags |= 8
         if os.environ.get('KBE_EVEN_GROUPS') == '1':        # (dev) transfer groups of one size instead of the ramp 1, 2, 4, ...
             flags |= 16
+        if os.environ.get('KBE_RAMP', 'fast') == 'fast':    # KBE_VIDEO_FAST_RAMP: transfer groups of 1, 3, 7, 15, ... frames
+            flags |= 1024
         if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
             flags |= 512
         keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again

@@ -51,10 +51,15 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
 }
 
 // the hole counters / list totals (HOLE_COUNT_INTS ints) of `n` scratch sets `stride` bytes apart
-__global__ void k_zero_counters(int* first, size_t stride, int n)
+// ... and both banks of their per-tile list counters (`tile_ints` ints at `tile_first` of the first set; blockIdx.y = the set): a
+// video that ended in an error after a launch that had placed ahead leaves the counters of one bank standing
+__global__ void k_zero_counters(int* first, size_t stride, int n, int* tile_first, size_t tile_ints)
 {
     static_assert(HOLE_COUNT_INTS == 8, "k >> 3, k & 7");
-    for (int k = threadIdx.x; k < HOLE_COUNT_INTS * n; k += blockDim.x) ((int*) ((char*) first + (size_t) (k >> 3) * stride))[k & 7] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int k = threadIdx.x; k < HOLE_COUNT_INTS * n; k += blockDim.x) ((int*) ((char*) first + (size_t) (k >> 3) * stride))[k & 7] = 0;
+    int* const t = (int*) ((char*) tile_first + (size_t) blockIdx.y * stride);
+    for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < tile_ints; k += (size_t) gridDim.x * blockDim.x) t[k] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1012,11 +1017,6 @@ int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, 
         const Scratch sc = carve(scratch[k], W, H);
         n_tiles = sc.tiles_x * sc.tiles_y;
         const int par = turns[k] & 1;
-        if (turns[k] == 0 && !placed) {
-            // a set's first turn: its hole counters and list totals start from zero (as a frame on its own zeroes them)
-            const hipError_t e = hipMemsetAsync(sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
-            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
-        }
         ft[k] = FusedTarget{ make_camera(W, H, focals[k], baseline, shifts + 3 * (size_t) k), sc, scratch_place(scratch[k], W, H), par, frames_u8[k], nullptr, nullptr, nullptr, nullptr, turns[k] };
         targets[k] = FillTarget{ sc, sc.hole_count + par, frames_u8[k], nullptr, 0, sc.hole_count + (par ^ 1) };
     }
@@ -1027,11 +1027,27 @@ int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, 
             KBE_REQUIRE(next_scratch[k] != scratch[j] || next_turns[k] == turns[j] + 1, "kbe_render_frame_group_ahead: a set used by both groups takes consecutive turns");
         nt[k] = FusedTarget{ make_camera(W, H, next_focals[k], baseline, next_shifts + 3 * (size_t) k), carve(next_scratch[k], W, H), scratch_place(next_scratch[k], W, H),
                              next_turns[k] & 1, nullptr, nullptr, nullptr, nullptr, nullptr, next_turns[k] };
-        if (next_turns[k] == 0) {       // a set that joins the sequence with the next group: zeroed before its placements count in it
-            const hipError_t e = hipMemsetAsync(nt[k].sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
+    }
+    // (every argument has been checked: only now is anything enqueued)
+    // A set's first turn -- in this group, without placements made ahead, or joining the sequence with the next group: its hole
+    // counters and list totals start from zero (as a frame on its own zeroes them), and so do BOTH banks of its per-tile list
+    // counters: a sequence that was abandoned (an error return, a caller that stopped after a launch that placed ahead) leaves
+    // the counters of the bank it placed into standing, and placements appended behind stale counts list sub-blocks twice.
+    auto start_set = [&](const Scratch& sc) -> hipError_t {
+        hipError_t e = hipMemsetAsync(sc.hole_count, 0, HOLE_COUNT_INTS * sizeof(int), s);
+        if (e == hipSuccess) e = hipMemsetAsync(sc.tile_count, 0, 2 * align16(4 * (size_t) sc.tiles_x * sc.tiles_y * CNT_STRIDE), s);
+        return e;
+    };
+    for (int k = 0; k < n_frames; k++)
+        if (turns[k] == 0 && !placed) {
+            const hipError_t e = start_set(ft[k].sc);
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
         }
-    }
+    for (int k = 0; k < n_next; k++)
+        if (next_turns[k] == 0) {
+            const hipError_t e = start_set(nt[k].sc);
+            if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
+        }
     if (stages & KBE_STAGE_TILES) {
         launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt);
         if ((rc = launched("kbe_render_frame_group_ahead/scatter"))) return rc;
@@ -1163,7 +1179,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     if (packed) {
         // every scratch set starts the call on hole counter 0: its counters (and list totals) are zeroed here, on `stream`, before
         // the lanes start -- by ONE small launch for all sets (a memset per set was eight launches in front of a video's first frame)
-        hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, cs, carve(scratch, W, H).hole_count, sb, group * lanes);
+        const Scratch sc0 = carve(scratch, W, H);
+        hipLaunchKernelGGL(k_zero_counters, dim3(16, group * lanes), dim3(256), 0, cs, sc0.hole_count, sb, group * lanes, sc0.tile_count,
+                           2 * align16(4 * (size_t) sc0.tiles_x * sc0.tiles_y * CNT_STRIDE) / sizeof(int));
         if (int rc0 = launched("kbe_render_video/counters")) return rc0;
     }
     hipEvent_t start = lanes > 1 || (ringed && ds[0] != cs) ? make() : nullptr;
@@ -1176,7 +1194,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     // which lane renders frame i with one frame per launch (render() below): whole groups of G = -batch consecutive frames when
     // they are handed to pinned host memory per group, round-robin otherwise; a lane's frame count tells its LAST frame
     const bool by_groups = batch < 0 && host_dev != nullptr;
-    // The transfer groups of the hand-off by groups: sizes 1, 2, 4, ... up to G = -batch, then G.  The link is idle until the
+    // The transfer groups of the hand-off by groups: sizes 1, 2, 4, ... (KBE_VIDEO_FAST_RAMP: 1, 3, 7, ...) up to G = -batch, then G.  The link is idle until the
     // first group has been rendered, and a transfer costs ~25 us whatever its size: a video of 20 frames in groups of 2 ran at
     // 41 GB/s, in groups of 16 it would wait for 16 frames before the first byte moves.  Small groups first start the link
     // after one frame; the groups double while it is busy.  Group g goes to lane g % lanes.
@@ -1186,7 +1204,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         for (int i0 = 0, size = (flags & KBE_VIDEO_EVEN_GROUPS) ? G : 1; i0 < n_frames; ) {
             group_start.push_back(i0);
             i0 += size < n_frames - i0 ? size : n_frames - i0;
-            size = size * 2 < G ? size * 2 : G;
+            const int grown = (flags & KBE_VIDEO_FAST_RAMP) ? size * 2 + 1 : size * 2;
+            size = grown < G ? grown : G;
         }
         group_start.push_back(n_frames);
     }

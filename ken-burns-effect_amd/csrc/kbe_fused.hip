@@ -182,7 +182,10 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 // A DPP read needs two wait states behind the VALU write of its source; inline asm gets no hazard handling, hence the s_nop.
 __device__ __forceinline__ int row_min(int v)
 {
-    asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    // (s_nop 4 in front: should the compiler ever schedule a VALU write of EXEC just ahead, a DPP read needs five wait states behind
+    // it.  EVERY lane of the row must be active: bound_ctrl is off, a disabled lane would keep its own value out of the others'
+    // minimum -- the callers hold whole waves, Np is a multiple of 64 and every branch around a call is wave-uniform.  gfx9 wave64.)
+    asm("s_nop 4\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
