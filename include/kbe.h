@@ -353,7 +353,8 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 /* the transfer groups of the hand-off by groups grow 1, 3, 7, 15, 31, ... (each twice the last plus one) instead of 1, 2, 4, 8, ...:
  * the link needs 25 us + 57 us per 1024^2 frame for a group while the next group renders at 20-30 us per frame, so a group may
  * be a little more than twice the one in flight -- and every transfer saved is ~25 us of link time (a 20-frame video: 4 transfers
- * instead of 6, a 75-frame video 6 instead of 8).  The last group takes what is left. */
+ * instead of 6, a 75-frame video 6 instead of 8).  The last group takes what is left.  (Measured: no gain on MI355X -- the larger
+ * groups render next to the other lane's transfer and are slowed by it; the Python host side leaves it off.) */
 #define KBE_VIDEO_FAST_RAMP 1024
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,

@@ -560,9 +560,11 @@ class HipKernels:
                     raise KbeError('KBE_DELIVERY_BATCH=%r is not an integer (frames per transfer: < 0 groups per lane, > 0 staged ring)' % env)
                 # groups of up to 32 frames per transfer (the first ones ramp 1, 2, 4, 8, 16: include/kbe.h; 16 -> 32: 17.3 -> 17.5 k frames/s); a short video's groups stay
                 # small enough for each lane to have two of full size
-                # (KBE_RAMP=fast, the default: groups of 1, 3, 7, 15, 31, ... frames -- two transfers fewer than 1, 2, 4, 8, ... for a 20- or a
-                # 75-frame video, ~25 us of link time each; their cap is then half the video, so that a short video ends 1, 3, 7, 9)
-                fast_ramp = os.environ.get('KBE_RAMP', 'fast') == 'fast'
+                # (KBE_RAMP=fast: groups of 1, 3, 7, 15, 31, ... frames, capped at half the video -- two transfers fewer than 1, 2, 4, 8, ...
+                # for a 20- or a 75-frame video.  Measured, round 4 (profiles/r04_short_videos.txt): no gain -- 20 frames 14.05 against
+                # 13.93 k frames/s, 75 frames 16.05 against 16.21 k: the larger groups render next to the other lane's transfer, whose
+                # blit kernel's PCIe-bound stores slow them.  Not the default.)
+                fast_ramp = os.environ.get('KBE_RAMP', 'classic') == 'fast'
                 batch = batch or -max(1, min(32, max(n // (2 * lanes), (n + 1) // 2 if fast_ramp else 0)))
         # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
         batch = int(batch)
@@ -590,7 +592,7 @@ class HipKernels:
             flags |= 8
         if os.environ.get('KBE_EVEN_GROUPS') == '1':        # (dev) transfer groups of one size instead of the ramp 1, 2, 4, ...
             flags |= 16
-        if os.environ.get('KBE_RAMP', 'fast') == 'fast':    # KBE_VIDEO_FAST_RAMP: transfer groups of 1, 3, 7, 15, ... frames
+        if os.environ.get('KBE_RAMP', 'classic') == 'fast':    # KBE_VIDEO_FAST_RAMP: transfer groups of 1, 3, 7, 15, ... frames
             flags |= 1024
         if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
             flags |= 512

@@ -20,5 +20,8 @@ ofrom, oto = synthetic.default_windows(size, size, dolly)
 settings = {'dblSteps': [i / (n - 1) for i in range(n)], 'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': dolly}
 oc = bench.build_scene(size, torch.device('cuda:0'), os.environ.get('CLOUD', 'inpaint') == 'inpaint' and not dolly and int(os.environ.get('UPSAMPLE', '1')) == 1, settings,
                        int(os.environ.get('UPSAMPLE', '1')))
-frames = common.render_frames(common.frame_cameras(settings, oc), oc, common.crop_size(settings), overlap=False)
+import time  # noqa: E402
+for _ in range(int(os.environ.get('REPS', '1'))):       # REPS > 1: bursts 20 ms apart (tools/handoff_timeline.py shows the last one)
+    frames = common.render_frames(common.frame_cameras(settings, oc), oc, common.crop_size(settings), overlap=False)
+    time.sleep(0.02)
 print(frames.shape, oc['tensorInpaPoints'].shape[-1])
