@@ -107,10 +107,17 @@ def measured_instructions():
 
 GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group / _fused) when the timed region uses one
 BUCKET_GROUP_MAX = 4    # kbe_render_frame_group takes up to four frames, kbe_render_frame_group_fused up to eight
-VALU_ISSUE_PER_US = 1024 * 2400.0 / 4.0     # wave-level VALU instructions the chip issues per us: 1024 SIMDs, one per 4 cycles each, 2.4 GHz
+# Wave-level VALU instructions the chip issues per us through ONE issue port per SIMD -- measured (tools/valu_rate.hip,
+# profiles/r04_valu_rate.txt, r04_valu_pairs.txt): 557-571 per ns chip-wide for every instruction kind outside the co-issue class
+# (fused multiply-adds with a separate addend register, min / max, compares, conversions, shifts left, 24-bit multiplies, DPP, every
+# three-operand integer form ...), from two waves per SIMD up -- 1024 SIMDs x ~2.38 GHz / 4.26 cycles.  Plain fp32 add / sub / mul,
+# integer add / sub, and / or / xor, mov, shifts right WITH VECTOR-REGISTER OPERANDS ONLY go through a second port alongside
+# (up to 1 070 per ns when nothing else issues; a 50 : 50 mix with one-port instructions: 890-1 000); in the scatter a fifth of
+# the instructions do (SQ_ACTIVE_INST_VALU2 / SQ_INSTS_VALU, profiles/r04_scatter_busy.json).
+VALU_ISSUE_PER_US = 570.0e3
 
 
-def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES):
+def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES, fill_flags=0):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
     launches between two events; the tile kernel is timed alone (back to back on a prepared scratch) --
@@ -212,6 +219,21 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
     for k in ('scatter', 'scatter+fill'):
         out[k] = out[route + ':' + k]
     out['fill'] = out['scatter+fill'] - out['scatter']
+    # the hole fill along the camera path (its cost follows the number of holes: a dolly zoom's late frames have 700 k of them):
+    # eight cameras spread over the video, each the frame's launches with and without the fill, with the schedule the video loop
+    # uses (`fill_flags`: KBE_STAGE_FILL_BY_COUNT, and KBE_STAGE_FILL_DIST where the loop fills with the tables)
+    fills = []
+    fkw = dict(fused=(route == 'fused'))
+    for cam_f, cam_s in [cams[(2 * i + 1) * len(cams) // 16] for i in range(8)]:
+        if route == 'fused':
+            t_all = timed(lambda: K.render_frame(state, cam_s, cam_f, Bl, stages=6 | fill_flags, fill_rect=fill_rect, **fkw))
+            t_scatter = timed(lambda: K.render_frame(state, cam_s, cam_f, Bl, stages=2, parity=-1, **fkw))
+        else:
+            t_all = timed(lambda: K.render_frame(state, cam_s, cam_f, Bl, stages=7 | fill_flags, fill_rect=fill_rect, **fkw))
+            t_scatter = timed(lambda: K.render_frame(state, cam_s, cam_f, Bl, stages=7, fill_rect=empty, **fkw))    # the fill launch with nothing to fill: its reset
+        fills.append(max(t_all - t_scatter, 0.0))
+    out['fill_along_path'] = sum(fills) / len(fills)
+    out['fill_along_path_max'] = max(fills)
     frame = K.render_frame(state, shift3, focal, Bl)
     cw, ch = int(0.9 * W), int(0.9 * H)
     out['crop_resize'] = timed(lambda: K.crop_resize_u8(frame, cw, ch))
@@ -604,10 +626,12 @@ def main():
         # the route and the frames per launch of the timed region (_native.video_launch_shape: the fused route with four frames
         # per launch where the frames are delivered to host memory; a zoom-out or a cloud denser than the raster: the bucket route)
         state = common._prepared_cloud(_native.kernels(), oc)
-        _, group_used, fused_used = _native.kernels().video_launch_shape(state, cams, args.batch, to_host=not args.device_only)
+        video_flags, group_used, fused_used = _native.kernels().video_launch_shape(state, cams, args.batch, to_host=not args.device_only)
         route = 'fused' if fused_used else 'bucket'
         group_frames = group_used if group_used > 1 else GROUP_FRAMES
-        kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames)
+        fill_flags = 32 | (512 if video_flags & 1 else 0)           # KBE_STAGE_FILL_BY_COUNT, + KBE_STAGE_FILL_DIST where the loop fills with the tables
+        kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames,
+                          fill_flags=fill_flags)
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch) per frame
@@ -677,6 +701,22 @@ def main():
                                  '(in the timed region the kernels of several lanes overlap and per-kernel durations stretch)',
                          'kernel_us': {k: round(v * 1e6, 2) for k, v in kt.items()}},
         }
+        # the hole fill (fill_disocclusion, common.py:833-937) under the same roofline: SURVEY.md 8d's 36 HW bytes per frame (the render
+        # and the depth plane in, the render out) over the HIP-event time of its launches (k_hole_dist + k_fill_tables + k_fill_holes
+        # where the loop fills with the tables, else k_fill_holes), mean over eight cameras along the path.  Where it takes longer per
+        # frame than the scatter -- a dolly zoom without inpainting -- it is the line's `roofline`, the scatter's figures beside it.
+        fill_t = kt['fill_along_path']
+        fill_obj = {'bound': 'hbm', 'kernel': ('k_hole_dist + k_fill_tables + k_fill_holes' if video_flags & 1 else 'k_fill_holes') + ' (fill_disocclusion)',
+                    'achieved': 36 * HW / max(fill_t, 1e-9) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 36 * HW / max(fill_t, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                    'traffic': None, 'algorithmic_bytes': 36 * HW, 'formula': '36 HW per frame (SURVEY.md 8d)', 'us_per_frame': round(fill_t * 1e6, 2),
+                    'us_worst_of_eight_cameras': round(kt['fill_along_path_max'] * 1e6, 2),
+                    'note': 'a frame on its own on one stream (HIP events, 40 repetitions), with and without its fill, eight cameras along the path; '
+                            'the walk is bound by instruction issue and the number of holes, not by these bytes'}
+        if fill_t * 1e6 > main['us_per_frame']:
+            fill_obj['scatter'] = line['roofline']
+            line['roofline'] = fill_obj
+        else:
+            line['roofline']['fill'] = fill_obj
         if frames_check is not None:
             line['frames_check'] = frames_check
             if not frames_check['ok']:          # a rate measured on wrong frames is not a measurement: no headline number, exit status 3

@@ -25,6 +25,11 @@ cp /tmp/ks2/b_kernel_stats.csv $OUT/bench_bucket_lanes1_kernel_stats.csv
 KBE_FUSED=0 timeout 900 python $R/bench.py --no-cpu-baseline 2>> $OUT/bench.err | tail -1 > $OUT/bench_bucket.json
 # 2c'. short videos (the driver's --steps 20 / 75)
 for k in 20 75; do timeout 600 python $R/bench.py --no-cpu-baseline --steps $k --warmup 5 2>> $OUT/bench.err | tail -1 > $OUT/bench_steps$k.json; done
+# 2c''. the other BASELINE configurations, each a bench line with the `roofline` of its dominant kernel: the dolly
+# zoom (configs[3] 4a: its fill), 2048^2 from 16.8 M points (configs[4]), 512^2 (configs[1]'s frame loop)
+timeout 900 python $R/bench.py --no-cpu-baseline --dolly --steps 256 --warmup 32 2>> $OUT/bench.err | tail -1 > $OUT/bench_dolly.json
+timeout 900 python $R/bench.py --no-cpu-baseline --size 2048 --upsample 2 --steps 64 --warmup 8 2>> $OUT/bench.err | tail -1 > $OUT/bench_config4.json
+timeout 900 python $R/bench.py --no-cpu-baseline --size 512 --steps 1024 --warmup 64 2>> $OUT/bench.err | tail -1 > $OUT/bench_512.json
 # 2d. multi-rank code path on this one GPU (gloo; ranks share the device: a functional check, not a measurement)
 KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 32 --warmup 4 2>> $OUT/bench.err | tail -1 > $OUT/bench_2ranks_gloo_one_gpu.json
 # 3. HBM traffic: one PMC pass per counter (no trace domains alongside)
