@@ -712,7 +712,7 @@ def main():
                     'us_worst_of_eight_cameras': round(kt['fill_along_path_max'] * 1e6, 2),
                     'note': 'a frame on its own on one stream (HIP events, 40 repetitions), with and without its fill, eight cameras along the path; '
                             'the walk is bound by instruction issue and the number of holes, not by these bytes'}
-        if fill_t * 1e6 > main['us_per_frame']:
+        if fill_t * 1e6 > single['us_per_frame']:          # (like with like: both a frame on its own)
             fill_obj['scatter'] = line['roofline']
             line['roofline'] = fill_obj
         else:
