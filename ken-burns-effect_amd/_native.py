@@ -27,7 +27,10 @@ SYMBOLS = (
 ABI_VERSION = 8
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
-FUSED_MAX_DENSITY = 1.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto)
+FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
+                                 # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
+                                 # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
+FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
 FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP): transfer groups
                        # of 16 frames are then two EQUAL launches, and equal groups place ahead (the scatter alone: 19.4 us per frame with 8 or 12)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
@@ -481,6 +484,11 @@ class HipKernels:
             # 1024^2 25.5 / 24.9 / 25.0, 1280^2 41.4 / 40.5 / 41.2, 1536^2 59.3 / 58.4 / 58.5; with a placement launch per group, round
             # 3's first half: 1024^2 25.3 / 26.7; the bucket route: 13.7, 18.8, 25.5, 29.4, 51.7, 72.8)
             group = FUSED_HOST_GROUP if to_host else 4
+            if to_host and state['N'] > FUSED_DENSE * W * H:
+                # a cloud much denser than the raster is bound by its rendering, not by the link: long launches next to another lane's
+                # transfer (a blit kernel) only slow each other -- measured, 16.8 M points at 2048^2, us per delivered frame with 8 / 4 / 2
+                # frames per launch on four lanes: 446 / 422 / 395 (the bucket route: 433); 4.2 M at 1024^2: 118 / 108 / 104 (114-154)
+                group = 2
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
             # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)

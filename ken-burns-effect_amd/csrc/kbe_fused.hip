@@ -339,7 +339,7 @@ __device__ __forceinline__ Camera load_camera(const __attribute__((address_space
 // blockIdx.y takes frames blockIdx.y, blockIdx.y + gridDim.y, ... of `nx`, its waves the frames' units of 64 points in turn.
 // k_place alone is a streaming launch that waits for memory 70 % of its life (the point, then its list slots); k_frame is bound
 // by instruction issue: one launch lets the one's waits hide under the other's arithmetic whatever else the chip is doing.
-__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane)
+__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane, int units_up_front)
 {
     const CloudPoint* const pd = pcp->pd;
     const int n_units = pcp->Np / kCloudBlock;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
         int* const tile_count = a->tile_count;
         int* const cand = a->cand;
         unsigned* const bin_flag = a->bin_flag;
-        const int u0 = first + (j == (int) blockIdx.y ? AHEAD_UNITS * step : 0);      // (the row's first frame: its first units were placed up front)
+        const int u0 = first + (j == (int) blockIdx.y ? units_up_front * step : 0);      // (the row's first frame: its first units were placed up front)
         if (u0 >= n_units) continue;
         CloudPoint p = pd[u0 * kCloudBlock + lane];
         for (int u = u0; u < n_units; u += step) {                      // wave-uniform; the next unit's point requested before this one is worked on
@@ -365,7 +365,10 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
 
 // AHEAD: a launch that also makes placements (k_frame_ahead, k_frame_group_ahead: kernels of their own, so that a launch
 // that places nothing carries none of it and profiles tell the two apart)
-template <int J, bool AHEAD>
+// UNITS: how many of a wave's units of the next frames' placement are requested with the tile's list and placed up front (the
+// rest behind the epilogue): three for a cloud of about a point per pixel (a wave's share of an equal group is 2.2 units), eight
+// for one much denser than the raster (configs[4]: 8 units per wave)
+template <int J, bool AHEAD, int UNITS = AHEAD_UNITS>
 __device__ __forceinline__ void frame_body(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
 {
     FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
@@ -422,7 +425,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     fetch_entries(wave);
     // the points of this wave's first units of the NEXT frame's placement, requested with the list (unconditionally, the
     // addresses clamped: a row with no frame to place reads the cloud's first block)
-    constexpr int NU = AHEAD ? AHEAD_UNITS : 0;
+    constexpr int NU = AHEAD ? UNITS : 0;
     const int n_next = AHEAD ? jp->n_next : 0;
     const bool ahead = NU > 0 && (int) blockIdx.y < n_next;             // uniform: this row has a frame to place
     const int a_units = ahead ? pcp->Np / kCloudBlock : 1;
@@ -567,7 +570,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             if (more) fetch_points();
         }
     }
-    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane);
+    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane, NU);
     KBE_PROBE(3);
     if (KBE_AHEAD_AT == 3) ahead_finish();
     __syncthreads();
@@ -798,7 +801,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");
         const int n_left = jp->n_next;
-        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane);
+        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU);
     }
     KBE_PROBE(9);
 #if defined(KBE_FRAME_PROBE)
@@ -844,20 +847,33 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) 
     frame_body<KBE_FRAME_JOBS, true>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
 }
 
+// ... for a cloud much denser than the raster: eight units of a wave's placements up front (configs[4], 16.8 M points on a 2048^2
+// raster: 8 units per wave; the placement launch of its own that such a cloud used to keep waits for memory 70 % of its life --
+// 183 us per frame next to a tile launch of 208 -- and as part of the tile launch it hides: 401 -> 349 us per frame left in HBM)
+constexpr int AHEAD_UNITS_DENSE = 8;
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_ahead_dense(FrameJobs)
+{
+    frame_body<KBE_FRAME_JOBS, true, AHEAD_UNITS_DENSE>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
+}
+
 }  // namespace
 
 namespace kbe {
 // Can the tile launch of n frames make the placements of n_next frames without outliving its own work?  Its waves share them:
-// up to a few units of 64 points per wave.  (A cloud much denser than the raster keeps the placement launch of its own.)
+// up to a few units of 64 points per wave (beyond AHEAD_UNITS per wave the launch is k_frame_group_ahead_dense).
 #ifndef KBE_AHEAD_MAX_UNITS
-#define KBE_AHEAD_MAX_UNITS 6
+#define KBE_AHEAD_MAX_UNITS 9
 #endif
+static size_t ahead_units_per_wave(int N, int W, int H, int n, int n_next)        // rounded up
+{
+    const size_t units = (size_t) cloud_layout_base(N).Np / kCloudBlock * (size_t) n_next;
+    const size_t waves = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * (TILE_THREADS / 64) * (size_t) n;
+    return (units + waves - 1) / waves;
+}
 bool fused_can_place_ahead(int N, int W, int H, int n, int n_next)
 {
     if (n < 1 || n_next < 1) return false;
-    const size_t units = (size_t) cloud_layout_base(N).Np / kCloudBlock * (size_t) n_next;
-    const size_t waves = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * (TILE_THREADS / 64) * (size_t) n;
-    return units <= (size_t) KBE_AHEAD_MAX_UNITS * waves;
+    return ahead_units_per_wave(N, W, H, n, n_next) <= (size_t) KBE_AHEAD_MAX_UNITS;
 }
 
 // the scatter of n <= KBE_FRAME_JOBS frames of the same packed cloud and frame size: one placement launch (unless the frames are
@@ -903,7 +919,12 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         f1.pc = pc; f1.n_next = n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
         if (n_next) hipLaunchKernelGGL(k_frame_ahead, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
         else hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
-    } else if (n_next) hipLaunchKernelGGL(k_frame_group_ahead, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);        // (also: one frame that places several)
+    } else if (n_next) {                                                        // (also: one frame that places several)
+        const Scratch& sc0 = t[0].sc;
+        const bool dense = ahead_units_per_wave(N, sc0.tiles_x * TW, sc0.tiles_y * TH, n, n_next) > (size_t) AHEAD_UNITS + 1;
+        if (dense) hipLaunchKernelGGL(k_frame_group_ahead_dense, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+        else hipLaunchKernelGGL(k_frame_group_ahead, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+    }
     else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }

@@ -149,9 +149,35 @@ def test_one_launch_scatter_at_1024_equals_the_two_launches(K, dense_cloud):
         d = (buf.int() - want[i].int()).abs()
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-4, 'group %d: max %d, %.2e differ' % (i, int(d.max()), float((d > 0).float().mean()))
         assert float((buf == 0).all(dim=3).float().mean()) < 0.2, 'frames are rendered'
-    # 16.8 M points on a 2048^2 raster: eight units of 64 points per wave of the tile launch -- too many to ride along
-    assert K.lib.kbe_render_frame_group_ahead_ok(dense_cloud[1].shape[2], 2048, 2048, 4, 4) == 0
+    # 16.8 M points on a 2048^2 raster: eight units of 64 points per wave of the tile launch -- they ride along in the launch's
+    # dense form (k_frame_group_ahead_dense: test below); on a 1024^2 raster the same cloud would be 32 units per wave: too many
+    assert K.lib.kbe_render_frame_group_ahead_ok(dense_cloud[1].shape[2], 2048, 2048, 4, 4) == 1
+    assert K.lib.kbe_render_frame_group_ahead_ok(dense_cloud[1].shape[2], 1024, 1024, 4, 4) == 0
     assert K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 1, 12) == 0 and K.lib.kbe_render_frame_group_ahead_ok(state['N'], size, size, 8, 0) == 0
+
+
+def test_one_launch_scatter_of_the_dense_cloud_equals_the_two_launches(K, dense_cloud, monkeypatch):
+    """configs[4] pipelined: groups of frames of the 16.8 M-point cloud at 2048^2 whose tile launch also makes the next group's
+    placements -- eight units of 64 points per wave, the dense form of the launch -- against the same groups with their placement
+    launches in front."""
+    monkeypatch.setenv('KBE_LANES', '1')
+    from ken_burns_effect_amd import synthetic
+    size, pts, img, dep = dense_cloud
+    state = K.prepare_cloud(pts, img, dep, size, size, synthetic.FOCAL, raster=(size * 2, pts.shape[2]))
+    K._pack(state)
+    Bl = synthetic.BASELINE
+    cams = [(synthetic.FOCAL * (1.0 + 0.004 * i), (2.0 * i - 5.0, 3.0 - 0.7 * i, -2.5 * i)) for i in range(6)]
+    groups = [cams[0:2], cams[2:4], cams[4:6]]
+    buf = torch.zeros(2, size, size, 3, dtype=torch.uint8, device='cuda')
+    want = []
+    for g in groups:
+        K.render_frame_group_fused(state, g, Bl, buf)
+        want.append(buf.clone())
+    for i, g in enumerate(groups):
+        K.render_frame_group_ahead(state, g, Bl, buf, turn=i, placed=i > 0, next_cameras=groups[i + 1] if i + 1 < len(groups) else None)
+        d = (buf.int() - want[i].int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-4, 'group %d: max %d, %.2e differ' % (i, int(d.max()), float((d > 0).float().mean()))
+        assert float((buf == 0).all(dim=3).float().mean()) < 0.2, 'frames are rendered'
 
 
 def test_config4_2048_multi_pass_inpaint_then_frames_against_the_oracle(K, oracle):
