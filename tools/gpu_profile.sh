@@ -32,6 +32,8 @@ timeout 900 python $R/bench.py --no-cpu-baseline --size 2048 --upsample 2 --step
 timeout 900 python $R/bench.py --no-cpu-baseline --size 512 --steps 1024 --warmup 64 2>> $OUT/bench.err | tail -1 > $OUT/bench_512.json
 # 2d. multi-rank code path on this one GPU (gloo; ranks share the device: a functional check, not a measurement)
 KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 32 --warmup 4 2>> $OUT/bench.err | tail -1 > $OUT/bench_2ranks_gloo_one_gpu.json
+# 2d'. the same code path with configs[4]'s cloud: a 470 MB broadcast (gloo here: a functional check of the size, not an xGMI figure)
+KBE_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 2 --size 2048 --upsample 2 --steps 8 --warmup 2 2>> $OUT/bench.err | tail -1 > $OUT/bench_config4_2ranks_gloo_one_gpu.json
 # 3. HBM traffic: one PMC pass per counter (no trace domains alongside)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c
@@ -44,6 +46,12 @@ for fused in 1 0; do
   KBE_FUSED=$fused KBE_LANES=1 KBE_FILL_GROUP=1 FRAMES=17 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/pi_$fused -o c --output-format csv -- python $R/tools/frame_once.py > $OUT/pmc_insts_$fused.log 2>&1
 done
 python $R/tools/pmc_insts.py /tmp/pi_1/c_counter_collection.csv /tmp/pi_0/c_counter_collection.csv > $OUT/scatter_insts.json
+# 3c. configs[4] on one lane: HBM bytes per launch of its scatter (FETCH_SIZE in 2 KB units, WRITE_SIZE in 1 KB units: tools/pmc_report.py's calibration)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pd_$c
+  SIZE=2048 UPSAMPLE=2 CLOUD=raw KBE_LANES=1 FRAMES=16 REPS=1 timeout 400 rocprofv3 --pmc $c -d /tmp/pd_$c -o c --output-format csv -- python $R/tools/throughput.py > /tmp/pd.log 2>&1 || tail -3 /tmp/pd.log
+  python $R/tools/pmc_by_grid.py /tmp/pd_$c/c_counter_collection.csv k_frame_group_ahead k_frame_group k_place k_project k_tiles 2>&1 | cut -c1-300
+done > $OUT/config4_traffic.txt
 # 4. other workloads (device-only and delivered), both routes where it matters
 (
 for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPSAMPLE=2 CLOUD=raw"; do
