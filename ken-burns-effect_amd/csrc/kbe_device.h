@@ -18,15 +18,26 @@ constexpr int kWave = 64;   // CDNA wavefront
 // order-preserving fp32 <-> uint32 key (replaces the CAS-loop float atomicMin of
 // /root/reference/utils/common.py:275-283 by one native global/LDS atomic umin)
 // ---------------------------------------------------------------------------------------
+// (written as shift / or / xor rather than compare-and-select: the same three instructions per key, but of the kinds a SIMD
+// issues through its second port -- v_ashrrev_i32, v_or_b32, v_xor_b32 -- where v_cmp and v_cndmask take the first, which is
+// the one the frame kernels are bound by: DESIGN.md section 4, profiles/r04_valu_rate.txt)
 __device__ __forceinline__ uint32_t zkey_encode(float f)
 {
     const uint32_t b = __float_as_uint(f);
+#if defined(KBE_KEY_SELECT) && KBE_KEY_SELECT
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+#else
+    return b ^ ((uint32_t) ((int32_t) b >> 31) | 0x80000000u);          // sign set: ^ 0xFFFFFFFF, clear: ^ 0x80000000
+#endif
 }
 
 __device__ __forceinline__ float zkey_decode(uint32_t k)
 {
+#if defined(KBE_KEY_SELECT) && KBE_KEY_SELECT
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+#else
+    return __uint_as_float(k ^ ~((uint32_t) ((int32_t) k >> 31) & 0x7FFFFFFFu));        // top bit set: ^ 0x80000000, clear: ^ 0xFFFFFFFF
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -388,6 +388,9 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     unsigned long long probe_t[PROBE_STAMPS] = {};
 #endif
     KBE_PROBE(0);
+#if defined(KBE_FRAME_PROBE)
+    probe_t[13] = __builtin_amdgcn_s_memrealtime();     // 100 MHz: with stamp 9 - stamp 0 the shader clock this wave ran at
+#endif
 
     // The candidate list first (everything else waits for it).  A wave takes four sub-blocks per step -- sixteen lanes each, a
     // lane one point -- and the steps go round the waves; the operands of FOUR steps are requested before the first is
@@ -805,6 +808,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     }
     KBE_PROBE(9);
 #if defined(KBE_FRAME_PROBE)
+    probe_t[13] = __builtin_amdgcn_s_memrealtime() - probe_t[13];
     {
         const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave;
         if (lane < PROBE_STAMPS && w < (unsigned) PROBE_WAVES) {

@@ -9,7 +9,7 @@ Differences, on purpose: the unused Mask-RCNN of the reference (:36, deleted at 
 weights of ``Semantics`` come from a file (``semantics_path``) instead of a torchvision download;
 ``cv2.minMaxLoc`` is replaced by :func:`synthetic.depthrange_of`; frames are written with PIL and the
 video through an ``ffmpeg`` binary if one is on PATH (OpenCV / moviepy are not dependencies) --
-otherwise only the PNG frames / an ``.npy`` stack are written.  Returns the frame list.
+otherwise a Motion-JPEG ``.avi`` (written here, no external encoder) stands in for the ``.mp4``.  Returns the frame list.
 """
 import os
 import shutil
@@ -177,14 +177,51 @@ def write_frames(frames_dir, frames_rgb):
         Image.fromarray(np.ascontiguousarray(frame)).save(os.path.join(frames_dir, '%d.png' % idx))
 
 
+def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
+    """A playable video without any external encoder: Motion-JPEG in an AVI container (RIFF 'AVI ' with one 'vids' / 'MJPG' stream,
+    an 'idx1' index; every frame a baseline JPEG from PIL).  What write_video falls back to where there is no ffmpeg binary."""
+    import io
+    import struct
+    from PIL import Image
+    h, w = frames_rgb[0].shape[:2]
+    jpegs = []
+    for frame in frames_rgb:
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
+        jpegs.append(buf.getvalue())
+    n = len(jpegs)
+    biggest = max(len(j) for j in jpegs)
+
+    def chunk(tag, data):
+        return tag + struct.pack('<I', len(data)) + data + (b'\0' if len(data) & 1 else b'')
+
+    def lst(tag, data):
+        return b'LIST' + struct.pack('<I', len(data) + 4) + tag + data
+
+    avih = struct.pack('<14I', int(1e6 / fps), biggest * fps, 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)       # AVIF_HASINDEX
+    strh = b'vids' + b'MJPG' + struct.pack('<IHHIIIIIIII', 0, 0, 0, 0, 1, fps, 0, n, biggest, 0xFFFFFFFF, 0) + struct.pack('<4h', 0, 0, w, h)
+    strf = struct.pack('<IiiHH4sIiiII', 40, w, h, 1, 24, b'MJPG', w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b'hdrl', chunk(b'avih', avih) + lst(b'strl', chunk(b'strh', strh) + chunk(b'strf', strf)))
+    movi_body, index, offset = b'', b'', 4
+    for j in jpegs:
+        c = chunk(b'00dc', j)
+        index += b'00dc' + struct.pack('<III', 0x10, offset, len(j))                    # AVIIF_KEYFRAME
+        movi_body += c
+        offset += len(c)
+    body = hdrl + lst(b'movi', movi_body) + chunk(b'idx1', index)
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', len(body) + 4) + b'AVI ' + body)
+    return path
+
+
 def write_video(path, frames_rgb, fps=25):
     """mpeg4 through an ffmpeg pipe when the binary exists (what moviepy does, pipeline.py:132-134);
-    otherwise the frame stack is saved next to it as .npy and the function says so."""
+    otherwise a Motion-JPEG .avi of the same frames is written next to it (no external encoder needed) and the function says so."""
     ffmpeg = shutil.which('ffmpeg')
     h, w = frames_rgb[0].shape[:2]
     if ffmpeg is None:
-        np.save(os.path.splitext(path)[0] + '.npy', np.stack(frames_rgb))
-        print('ffmpeg not found: wrote %s.npy (%d frames) instead of %s' % (os.path.splitext(path)[0], len(frames_rgb), path))
+        avi = write_mjpeg_avi(os.path.splitext(path)[0] + '.avi', frames_rgb, fps)
+        print('ffmpeg not found: wrote %s (Motion-JPEG, %d frames at %d fps) instead of %s' % (avi, len(frames_rgb), fps, path))
         return False
     proc = subprocess.Popen([ffmpeg, '-y', '-loglevel', 'error', '-f', 'rawvideo', '-pix_fmt', 'rgb24', '-s', '%dx%d' % (w, h),
                              '-r', str(fps), '-i', '-', '-c:v', 'mpeg4', path], stdin=subprocess.PIPE)

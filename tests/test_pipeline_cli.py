@@ -31,7 +31,7 @@ def test_pipeline_end_to_end_on_cpu(oracle, monkeypatch, tmp_path, recwarn):
     assert abs(oc['dblDispmax'] - 120) < 1e-3 and oc['dblDispmin'] >= 0                      # pipeline.py:79-81
     assert oc['tensorInpaPoints'].shape[2] >= 64 * 96                                         # inpainting appended points
     assert (tmp_path / 'frames' / '2.png').exists()
-    assert (tmp_path / '3d_kbe.mp4').exists() or (tmp_path / '3d_kbe.npy').exists()
+    assert (tmp_path / '3d_kbe.mp4').exists() or (tmp_path / '3d_kbe.avi').exists()
     assert any('seeded random weights' in str(w.message) for w in recwarn.list)
     assert any('semantics (VGG19-bn)' in str(w.message) for w in recwarn.list)
 
@@ -136,3 +136,30 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
     monkeypatch.setenv('KBE_MIOPEN_FIND', '0')
     real = P.Pipeline(model_paths=None, allow_random_weights=True, device='cpu', steps=2)
     assert real.miopen_find is False and 'plain' in real.tuning_marker(96, 64) and '96x64' in real.tuning_marker(96, 64)
+
+
+def test_video_without_ffmpeg_is_a_motion_jpeg_avi_that_decodes_back(tmp_path, monkeypatch):
+    """No ffmpeg binary (either image): write_video leaves a Motion-JPEG AVI -- a RIFF file whose frames decode back (PIL) to the
+    frames written, in order, within JPEG's loss; its header carries the size, the rate and the frame count."""
+    import io
+    import struct
+    from PIL import Image
+    from ken_burns_effect_amd import pipeline as P
+    monkeypatch.setattr(P.shutil, 'which', lambda name: None)
+    yy, xx = np.mgrid[0:48, 0:64]
+    frames = [np.stack([(xx * 3 + 10 * i) % 256, (yy * 4) % 256, np.full_like(xx, 40 * i)], axis=2).astype(np.uint8) for i in range(5)]
+    assert P.write_video(str(tmp_path / '3d_kbe.mp4'), frames, fps=25) is False
+    blob = (tmp_path / '3d_kbe.avi').read_bytes()
+    assert blob[:4] == b'RIFF' and blob[8:12] == b'AVI ' and struct.unpack('<I', blob[4:8])[0] == len(blob) - 8
+    avih = blob.index(b'avih') + 8
+    us_per_frame, _, _, flags, total = struct.unpack('<5I', blob[avih:avih + 20])
+    width, height = struct.unpack('<2I', blob[avih + 32:avih + 40])
+    assert (us_per_frame, total, width, height) == (40000, 5, 64, 48) and flags & 0x10
+    pos, decoded = blob.index(b'movi') + 4, []
+    while blob[pos:pos + 4] == b'00dc':
+        size = struct.unpack('<I', blob[pos + 4:pos + 8])[0]
+        decoded.append(np.asarray(Image.open(io.BytesIO(blob[pos + 8:pos + 8 + size])).convert('RGB')))
+        pos += 8 + size + (size & 1)
+    assert len(decoded) == 5 and blob[pos:pos + 4] == b'idx1'
+    for want, got in zip(frames, decoded):
+        assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).mean() < 6.0

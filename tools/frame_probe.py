@@ -52,6 +52,11 @@ names = ['entry -> list count known, points requested, placements ahead begun', 
          'decode z, barrier, degrid', 'wait at barrier 4', 'gather', 'epilogue (incl. its barrier, stores, hole list)', 'placements left over']
 tot = (t[:, 9] - t[:, 0]).astype(np.float64)
 print('a wave lives %.0f cycles on average (median %.0f, p90 %.0f); the launch spans %.0f cycles' % (tot.mean(), np.median(tot), np.percentile(tot, 90), float(t[:, 9].max() - t0)))
+real = t[:, 13].astype(np.float64)          # ticks of the 100 MHz s_memrealtime over the wave's life
+good = real > 0
+print('shader clock while the waves ran (s_memtime ticks per 10 ns of s_memrealtime): mean %.3f GHz, median %.3f, p10 %.3f, p90 %.3f; a wave lives %.2f us' % (
+    (tot[good] / (real[good] * 10.0)).mean(), np.median(tot[good] / (real[good] * 10.0)), np.percentile(tot[good] / (real[good] * 10.0), 10),
+    np.percentile(tot[good] / (real[good] * 10.0), 90), (real[good] * 0.01).mean()))
 for k, name in enumerate(names):
     d = (t[:, k + 1] - t[:, k]).astype(np.float64)
     print('  %5.1f %%  mean %6.0f  median %6.0f  p90 %6.0f   %s' % (100.0 * d.sum() / tot.sum(), d.mean(), np.median(d), np.percentile(d, 90), name))
