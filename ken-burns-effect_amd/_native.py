@@ -21,7 +21,7 @@ SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_selftest_division', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
-    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue',
+    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask',
 )
 
 ABI_VERSION = 8
@@ -703,8 +703,18 @@ class HipKernels:
                                                  _stream()), 'kbe_laplacian_valid')
         return out
 
-    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None):
-        """raw [B,Cout,Ho,Wo] = conv(x * mask); mask [B,Cin|1,H,W] or None (then in_channels/in_size say what x was)."""
+    def prelu_mask(self, x, slope, mask=None, out=None):
+        """prelu(x, slope) * mask in one pass (kbe_prelu_mask); mask [B,1,H,W] or None."""
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x) if out is None else out
+        self._check(self.lib.kbe_prelu_mask(_ptr(x), _ptr(_f32c(slope)), _ptr(None if mask is None else _f32c(mask)), _i(B), _i(C), _i(H), _i(W), _ptr(out),
+                                            _stream()), 'kbe_prelu_mask')
+        return out
+
+    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None, act_slope=None, residual=None):
+        """raw [B,Cout,Ho,Wo] = conv(x * mask); mask [B,Cin|1,H,W] or None (then in_channels/in_size say what x was).
+        act_slope [Cout] / residual [B,Cout,Ho,Wo] (optional): out = prelu(out + residual) in the same pass (include/kbe.h)."""
         raw = _f32c(raw)
         B, Cout, Ho, Wo = raw.shape
         if mask is not None:
@@ -715,9 +725,13 @@ class HipKernels:
             Cm, Cin, (H, W) = 1, int(in_channels), in_size
         out = torch.empty_like(raw)
         um = torch.empty(B, 1, Ho, Wo, dtype=torch.float32, device=raw.device)
+        if residual is not None:
+            residual = _f32c(residual)
+            assert residual.shape == raw.shape
         self._check(self.lib.kbe_pconv_epilogue(_ptr(raw), _ptr(None if bias is None else _f32c(bias)), _ptr(mask), _i(Cm), _i(B),
                                                 _i(Cin), _i(H), _i(W), _i(Cout), _i(Ho), _i(Wo), _i(int(kernel_size)),
-                                                _i(int(stride)), _i(int(padding)), _ptr(out), _ptr(um), _stream()),
+                                                _i(int(stride)), _i(int(padding)), _ptr(out), _ptr(um),
+                                                _ptr(None if act_slope is None else _f32c(act_slope)), _ptr(residual), _stream()),
                     'kbe_pconv_epilogue')
         return out, um
 

@@ -575,7 +575,8 @@ __global__ void __launch_bounds__(kBlock) k_median(const float* __restrict__ in,
 __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restrict__ raw, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, int Cm, int Cin, int H, int W, int Cout,
                                                            int Ho, int Wo, int k, int stride, int pad,
-                                                           float* __restrict__ out, float* __restrict__ um_out)
+                                                           float* __restrict__ out, float* __restrict__ um_out,
+                                                           const float* __restrict__ slope, const float* __restrict__ residual)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -603,12 +604,34 @@ __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restri
     for (int co = 0; co < Cout; co++) {
         const size_t o = ((size_t) b * Cout + co) * Ho * Wo + i;
         const float r = raw[o];
+        float v;
         if (bias) {
             const float bv = bias[co];
-            out[o] = ((r - bv) * ratio + bv) * um;
+            v = ((r - bv) * ratio + bv) * um;
         } else {
-            out[o] = r * ratio;
+            v = r * ratio;
         }
+        // what follows the layer in the GridNet's blocks, in the same pass: `+ skip` (partial_inpainting.py: Basic), or the next
+        // layer's PReLU (its mask multiplication needs nothing: v is 0 wherever um -- the next layer's mask -- is)
+        if (residual) v = v + residual[o];
+        if (slope) v = v > 0.0f ? v : slope[co] * v;          // (torch.nn.functional.prelu, to the sign of a zero)
+        out[o] = v;
+    }
+}
+
+// prelu(x) * mask in one pass (partial_inpainting.py: `p_relu_1`, then `input * mask_in` of PartialConv2d.forward, :61): x, out
+// [B,C,HW] (may alias), slope [C], mask [B,1,HW] or NULL
+__global__ void __launch_bounds__(kBlock) k_prelu_mask(const float* __restrict__ x, const float* __restrict__ slope, const float* __restrict__ mask,
+                                                       int C, size_t HW, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float m = mask ? mask[(size_t) b * HW + i] : 1.0f;
+    for (int c = 0; c < C; c++) {
+        const size_t o = ((size_t) b * C + c) * HW + i;
+        const float v = x[o];
+        out[o] = (v > 0.0f ? v : slope[c] * v) * m;
     }
 }
 
@@ -850,14 +873,22 @@ int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int
 }
 
 int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int mask_channels, int B, int Cin, int H, int W,
-                       int Cout, int Ho, int Wo, int k, int stride, int pad, float* out, float* um, kbe_stream_t stream)
+                       int Cout, int Ho, int Wo, int k, int stride, int pad, float* out, float* um, const float* prelu_slope,
+                       const float* residual, kbe_stream_t stream)
 {
     KBE_REQUIRE(raw && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k > 0 && stride > 0 && pad >= 0,
                 "kbe_pconv_epilogue: bad arguments");
     KBE_REQUIRE(!mask || mask_channels == 1 || mask_channels == Cin, "kbe_pconv_epilogue: mask must have 1 or Cin channels");
     hipLaunchKernelGGL(k_pconv_epilogue, dim3(blocks_for((size_t) Ho * Wo), B), dim3(kBlock), 0, (hipStream_t) stream, raw,
-                       bias, mask, mask_channels, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um);
+                       bias, mask, mask_channels, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um, prelu_slope, residual);
     return launched("kbe_pconv_epilogue");
+}
+
+int kbe_prelu_mask(const float* x, const float* slope, const float* mask, int B, int C, int H, int W, float* out, kbe_stream_t stream)
+{
+    KBE_REQUIRE(x && slope && out && B > 0 && C > 0 && H > 0 && W > 0, "kbe_prelu_mask: bad arguments");
+    hipLaunchKernelGGL(k_prelu_mask, dim3(blocks_for((size_t) H * W), B), dim3(kBlock), 0, (hipStream_t) stream, x, slope, mask, C, (size_t) H * W, out);
+    return launched("kbe_prelu_mask");
 }
 
 }  // extern "C"

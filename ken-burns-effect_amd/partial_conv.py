@@ -36,12 +36,16 @@ class PartialConv2d(nn.Conv2d):
                 or self.groups != 1:
             raise NotImplementedError('fused partial convolution supports square kernels, dilation 1, groups 1')
 
-    def forward(self, input, mask_in=None):
+    def forward(self, input, mask_in=None, premasked=False, act_slope=None, residual=None):
+        """As the reference's forward (utils/partial_conv.py:39-83).  The three keyword arguments are this package's own, for callers
+        that fuse what surrounds the layer (partial_inpainting._Pair; only on a kernel set that has them, `fuses_neighbours`):
+        ``premasked``: ``input`` is already 0 wherever ``mask_in`` is -- skip ``input * mask_in`` (:61); ``residual``: added to the
+        output, and ``act_slope`` [Cout]: the output then goes through PReLU -- both in the epilogue's pass (include/kbe.h)."""
         assert len(input.shape) == 4
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
             raise NotImplementedError('the fused partial convolution is inference-only: call it under torch.no_grad()')
         fresh = mask_in is not None or self.last_size != tuple(input.shape)
-        raw = F.conv2d(input * mask_in if mask_in is not None else input, self.weight, self.bias, self.stride, self.padding)
+        raw = F.conv2d(input * mask_in if mask_in is not None and not premasked else input, self.weight, self.bias, self.stride, self.padding)
         if fresh:
             self.last_size = tuple(input.shape)
             self._mask = mask_in
@@ -49,9 +53,12 @@ class PartialConv2d(nn.Conv2d):
         if not self.multi_channel and mask is not None and mask.shape[1] != 1:
             raise ValueError('single-channel PartialConv2d wants a [*,1,H,W] mask')
         cin = self.in_channels if self.multi_channel else 1
+        extra = {} if act_slope is None and residual is None else dict(act_slope=act_slope, residual=residual)
         output, um = common._K().pconv_epilogue(raw, self.bias, mask, self.kernel_size[0], self.stride[0], self.padding[0],
-                                                in_channels=cin, in_size=tuple(input.shape[2:]))
+                                                in_channels=cin, in_size=tuple(input.shape[2:]), **extra)
         self.update_mask = um
         if self.return_mask:
             return output, um.expand(-1, self.out_channels, -1, -1) if self.multi_channel else um
         return output
+
+    forward.fuses_neighbours = True         # (a forward patched in from elsewhere -- bench.py's reference formulation -- does not carry this)

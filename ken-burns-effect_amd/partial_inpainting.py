@@ -47,12 +47,29 @@ class _Pair(nn.Module):
         self.conv2 = _pconv(cmid, cout)
         self._first_act = first_act
 
-    def _pair(self, x, mask):
+    def _fused(self):
+        """The element-wise passes around the two layers ride in the layers' own passes (include/kbe.h: kbe_prelu_mask,
+        kbe_pconv_epilogue's prelu_slope / residual) when the kernel set has them and PartialConv2d.forward is this package's:
+        per pair three passes over the feature maps instead of seven -- [prelu * mask] conv [renormalise + prelu] conv
+        [renormalise + skip] against prelu, * mask, conv, renormalise, prelu, * mask, conv, renormalise, + skip.  Same values
+        (a PReLU of the 0 the renormalisation leaves outside the mask is 0: the second multiplication has nothing to do)."""
+        return hasattr(common._K(), 'prelu_mask') and getattr(type(self.conv1).forward, 'fuses_neighbours', False) and not torch.is_grad_enabled()
+
+    def _pair(self, x, mask, skip=None):
+        """-> (conv2(act(conv1([act] x))) [+ skip], mask)"""
+        if self._fused():
+            pre = False
+            if self._first_act:
+                x = common._K().prelu_mask(x, self.p_relu_1.weight, mask)
+                pre = mask is not None
+            x, mask = self.conv1(x, mask_in=mask, premasked=pre, act_slope=self.p_relu_2.weight)
+            x, mask = self.conv2(x, mask_in=_one(mask), premasked=True, residual=skip)
+            return x, _one(mask)
         if self._first_act:
             x = self.p_relu_1(x)
         x, mask = self.conv1(x, mask_in=mask)
         x, mask = self.conv2(self.p_relu_2(x), mask_in=_one(mask))
-        return x, _one(mask)
+        return (x if skip is None else x + skip), _one(mask)
 
 
 class Basic(_Pair):
@@ -66,8 +83,7 @@ class Basic(_Pair):
 
     def forward(self, tensorInput, mask_in=None):
         skip = tensorInput if self.moduleShortcut is None else self.moduleShortcut(tensorInput)   # no mask: :44, :53
-        out, mask = self._pair(tensorInput, mask_in)
-        return out + skip, mask
+        return self._pair(tensorInput, mask_in, skip)
 
 
 class Downsample(_Pair):

@@ -214,6 +214,34 @@ def test_pconv_epilogue(K, oracle):
         assert_bits_equal(c(um.expand(-1, cout, -1, -1)), z['mask_' + tag], 'update_mask vs reference')
 
 
+def test_pconv_epilogue_with_its_neighbours_fused_and_prelu_mask(K):
+    """What follows a partial-convolution layer inside the GridNet's blocks, fused into the epilogue's pass (kbe_pconv_epilogue's
+    prelu_slope / residual) and the block's first activation with the layer's `input * mask_in` (kbe_prelu_mask), against the
+    same steps as separate torch operations: bit for bit (each step is one fp32 operation per element either way)."""
+    z = load_golden('partial_conv')
+    gen = torch.Generator().manual_seed(3)
+    for tag in 'abc':
+        cin, cout, k, s, p = [int(v) for v in z['cfg_' + tag]]
+        x, m = torch.from_numpy(z['x_' + tag]), torch.from_numpy(z['m_' + tag])
+        bias = g(z['b_' + tag])
+        raw = torch.nn.functional.conv2d(x * m, torch.from_numpy(z['w_' + tag]), torch.from_numpy(z['b_' + tag]), stride=s, padding=p).cuda()
+        plain, um = K.pconv_epilogue(raw, bias, m.cuda(), k, s, p)
+        slope = (torch.rand(cout, generator=gen) * 0.5 - 0.1).cuda()
+        res = torch.randn(raw.shape, generator=gen).cuda()
+        act, um2 = K.pconv_epilogue(raw, bias, m.cuda(), k, s, p, act_slope=slope)
+        assert torch.equal(um, um2)
+        assert_bits_equal(c(act), c(torch.nn.functional.prelu(plain, slope)), 'epilogue + PReLU')
+        added, _ = K.pconv_epilogue(raw, bias, m.cuda(), k, s, p, residual=res)
+        assert_bits_equal(c(added), c(plain + res), 'epilogue + residual')
+        both, _ = K.pconv_epilogue(raw, bias, m.cuda(), k, s, p, act_slope=slope, residual=res)
+        assert_bits_equal(c(both), c(torch.nn.functional.prelu(plain + res, slope)), 'epilogue + residual + PReLU')
+        # the block's first activation and the mask multiplication: masks of one channel (how the GridNet carries them)
+        sl_in = (torch.rand(cin, generator=gen) * 0.5 - 0.1).cuda()
+        m1 = m[:, :1].contiguous().cuda()
+        assert_bits_equal(c(K.prelu_mask(x.cuda(), sl_in, m1)), c(torch.nn.functional.prelu(x.cuda(), sl_in) * m1), 'prelu * mask')
+        assert_bits_equal(c(K.prelu_mask(x.cuda(), sl_in, None)), c(torch.nn.functional.prelu(x.cuda(), sl_in)), 'prelu alone')
+
+
 def test_crop_resize_matches_written_algorithm(K, oracle):
     rng = np.random.default_rng(5)
     # even / odd crops (sub-pixel 0.5 and 0), the full frame (replicated border taps), widths that are not a
