@@ -661,6 +661,48 @@ def test_video_whose_tile_launches_place_ahead_equals_the_video_with_placement_l
     same(K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy(), alone[0], 'a frame on its own after the videos')
 
 
+def test_scratch_budget_falls_back_to_fewer_frames_per_launch_and_hint_replaces_the_probe(K, monkeypatch):
+    """ADVICE r3 / VERDICT r3 item 6.  (1) The video loop's scratch sets (frames per launch x lanes of them) are capped by a memory
+    budget: with KBE_SCRATCH_BUDGET_MB too small for the default shape the loop takes fewer frames per launch -- same frames.
+    (2) The lanes of a delivered video measured on rank 0 and handed over with the cloud (`_kbeDeliveryLanes`, sharding.py) are
+    taken as they are: no timing probe runs on the rank that received them."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '1')
+    size = (224, 288)
+    settings, oc = _scene(size, 19, 'smooth', True)
+    settings = dict(settings, dblSteps=[i / 39.0 for i in range(40)])
+    cams = common.frame_cameras(settings, oc)
+    state = common._prepared_cloud(K, oc)
+    want = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+    full_sets = state['video_sets']
+    assert full_sets == 16                                  # four frames per launch on four lanes
+    stride = int(K.lib.kbe_video_scratch_stride(size[1], size[0], state['N']))
+    monkeypatch.setenv('KBE_SCRATCH_BUDGET_MB', str(9 * stride / 1e6))            # room for nine sets: two frames per launch
+    got = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+    assert state['video_sets'] == 8
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    monkeypatch.setenv('KBE_SCRATCH_BUDGET_MB', '1')        # less than one set: one frame per launch, one set per lane
+    got = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+    assert state['video_sets'] == 4
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    monkeypatch.delenv('KBE_SCRATCH_BUDGET_MB')
+    # (2)
+    state.pop('delivery_lanes', None)
+    state.pop('delivery_probe_us', None)
+    oc['_kbeDeliveryLanes'] = {K.zooms_out(state, cams): 3}
+    state = common._prepared_cloud(K, oc)
+    assert K.delivery_lanes(state, cams, oc['dblBaseline'], None) == 3 and 'delivery_probe_us' not in state
+    delivered = common.render_frames(cams, oc, None)
+    d = np.abs(delivered.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3 and 'delivery_probe_us' not in state
+    del oc['_kbeDeliveryLanes']
+    state.pop('delivery_lanes_hint')
+    K.delivery_lanes(state, cams, oc['dblBaseline'], None)
+    assert 'delivery_probe_us' in state                     # a cloud of one's own: measured
+
+
 @pytest.mark.parametrize('size', [(50, 37), (33, 64)])
 def test_frame_hand_off_with_unaligned_frame_sizes(K, size):
     """W*H*3 not a multiple of 16: the frames of a video start at unaligned host addresses (k_deliver's byte path)."""
