@@ -387,6 +387,10 @@ def pipeline_bench(args, device):
     mask = (torch.rand(1, 1, big, big, device=device) > 0.2).float()
     with torch.no_grad():
         net.normalize_images_disp(torch.rand(1, 3, big, big, device=device), torch.rand(1, 1, big, big, device=device), not_normed=True)
+        # (tuned once per machine like the pipeline's own networks: the first run here pays MIOpen's find step for these shapes)
+        from ken_burns_effect_amd.utils import miopen_tuned_once
+        with miopen_tuned_once('bench-partial-inpaint-%d' % big, device, enabled=pipe.miopen_find == 'auto'):
+            net.forward(tensorData=data, tensorMasks=mask)
         fused_s, _ = timed(lambda: net.forward(tensorData=data, tensorMasks=mask), 5, 2)
         with FlopCounterMode(display=False) as fc:
             net.forward(tensorData=data, tensorMasks=mask)

@@ -39,7 +39,7 @@ class Pipeline():
         # (channels_last is NOT the answer on this stack: 36.3 instead of 21.4 ms immediate, 17.0 instead of 15.0 with the find.)
         # So ``miopen_find`` = 'auto' (the default; env KBE_MIOPEN_FIND=auto): the first call for an image size this machine
         # has not tuned runs under the find step -- it says so on stderr -- and leaves a marker next to the find-db
-        # (~/.cache/kbe, see tuning_marker); every later call and process runs in immediate mode on the tuned db.  True / '1':
+        # (~/.cache/kbe: utils.miopen_tuned_once); every later call and process runs in immediate mode on the tuned db.  True / '1':
         # always find (a long-lived server that sees many sizes); False / '0': never (tests, one-off runs that cannot wait).
         if miopen_find is None:
             miopen_find = {'1': True, '0': False}.get(os.environ.get('KBE_MIOPEN_FIND', 'auto'), 'auto')
@@ -122,43 +122,21 @@ class Pipeline():
         with common.on_device_of(getattr(self, 'device', torch.device('cpu'))):      # the C ABI launches on the current device's stream
             return self._run(tensorImage, zoom_settings, output_path, inpaint_depth, pretrained_estim)
 
-    def tuning_marker(self, width, height):
-        """The file whose presence says: MIOpen's find step has run for this pipeline's networks at this image size on this machine
-        (its results are in MIOpen's user find-db: MIOPEN_USER_DB_PATH, default ~/.config/miopen).  One per image size, network
-        variant, device and PyTorch / HIP version, under KBE_CACHE_DIR (default ~/.cache/kbe)."""
-        root = os.environ.get('KBE_CACHE_DIR') or os.path.join(os.path.expanduser('~'), '.cache', 'kbe')
-        dev = torch.cuda.get_device_name(self.device).replace(' ', '_') if self.device.type == 'cuda' and torch.cuda.is_available() else 'cpu'
-        tag = '%dx%d-%s%s%s-%s-torch%s-hip%s' % (width, height, 'partial' if self.partial_inpainting else 'plain', '-dolly' if self.dolly else '',
-                                                 '-pretrain' if isinstance(self.moduleRefine, RefinePretrained) else '', dev, torch.__version__, getattr(torch.version, 'hip', None))
-        return os.path.join(root, 'miopen-tuned', tag.replace('/', '_'))
+    def tuning_tag(self, width, height):
+        """What MIOpen is tuned for, once per machine (utils.miopen_tuned_once): this pipeline's networks at this image size."""
+        return '%dx%d-%s%s%s' % (width, height, 'partial' if self.partial_inpainting else 'plain', '-dolly' if self.dolly else '',
+                                 '-pretrain' if isinstance(self.moduleRefine, RefinePretrained) else '')
 
     def _run(self, tensorImage, zoom_settings, output_path, inpaint_depth, pretrained_estim):
-        marker, was = None, torch.backends.cudnn.benchmark
-        if getattr(self, 'miopen_find', False) == 'auto' and self.device.type == 'cuda':
-            marker = self.tuning_marker(tensorImage.size(3), tensorImage.size(2))
-            if os.path.exists(marker):
-                marker = None
-            else:
-                import sys
-                sys.stderr.write('ken_burns_effect_amd: first %d x %d video on this machine: MIOpen measures its convolution solvers once (tens of '
-                                 'seconds; the results stay in its find-db, marker %s; KBE_MIOPEN_FIND=0 skips this)\n' % (tensorImage.size(3), tensorImage.size(2), marker))
-                torch.backends.cudnn.benchmark = True
-        try:
+        from .utils import miopen_tuned_once
+        auto = getattr(self, 'miopen_find', False) == 'auto'
+        with miopen_tuned_once(self.tuning_tag(tensorImage.size(3), tensorImage.size(2)) if auto else '', getattr(self, 'device', 'cpu'), enabled=auto):
             self.estimate(tensorImage)
             if inpaint_depth:
                 raise NotImplementedError('two-network depth inpainting is broken in the reference (common.py:50-69)')
             frames = common.process_kenburns({'dblSteps': np.linspace(0.0, 1.0, self.steps).tolist(),
                                               'objectFrom': zoom_settings['objectFrom'], 'objectTo': zoom_settings['objectTo'],
                                               'boolInpaint': True, 'dolly': self.dolly}, self.objectCommon, self.moduleInpaint)
-        finally:
-            if marker is not None:
-                torch.backends.cudnn.benchmark = was
-        if marker is not None:
-            try:
-                os.makedirs(os.path.dirname(marker), exist_ok=True)
-                open(marker, 'w').write('tuned\n')
-            except OSError:
-                pass            # a read-only home: the find step runs again next time
         if output_path is not None:
             os.makedirs(output_path, exist_ok=True)
             # channel order on disk as the reference produces it: frames are in the INPUT's channel order

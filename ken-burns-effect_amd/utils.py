@@ -100,3 +100,44 @@ def get_masks(tensorImage, tensorDisparity, tensorDepth, zoom_settings, camera, 
     data = [tensorImage, tensorDisparity] + ([tensorContext] if tensorContext is not None else [])
     tensorRender, tensorMasks = common.render_pointcloud(flat + tensorShift, torch.cat(data, 1).view(B, -1, H * W), W, H, focal, baseline)
     return tensorRender, (tensorMasks > 0.0).float(), flat, tensorShift, objects
+
+
+class miopen_tuned_once:
+    """``with miopen_tuned_once(tag, device):`` -- the block's convolutions run under MIOpen's find step
+    (torch.backends.cudnn.benchmark) the first time this machine sees ``tag`` and in PyTorch's immediate mode from then on (the find
+    step leaves its measurements in MIOpen's user find-db, which the immediate mode of every later process consults; a marker file
+    under KBE_CACHE_DIR, default ~/.cache/kbe/miopen-tuned/, records that it ran).  The find step costs tens of seconds, once per
+    machine and tag -- it says so on stderr.  ``enabled=False`` (or a CPU device): nothing happens."""
+
+    def __init__(self, tag, device, enabled=True):
+        import os
+        self.marker = None
+        if enabled and torch.device(device).type == 'cuda' and torch.cuda.is_available():
+            root = os.environ.get('KBE_CACHE_DIR') or os.path.join(os.path.expanduser('~'), '.cache', 'kbe')
+            dev = torch.cuda.get_device_name(device).replace(' ', '_')
+            name = '%s-%s-torch%s-hip%s' % (tag, dev, torch.__version__, getattr(torch.version, 'hip', None))
+            self.marker = os.path.join(root, 'miopen-tuned', name.replace('/', '_'))
+            if os.path.exists(self.marker):
+                self.marker = None
+        self.tag = tag
+
+    def __enter__(self):
+        self.was = torch.backends.cudnn.benchmark
+        if self.marker is not None:
+            import sys
+            sys.stderr.write('ken_burns_effect_amd: first "%s" on this machine: MIOpen measures its convolution solvers once (tens of seconds; the '
+                             'results stay in its find-db, marker %s; KBE_MIOPEN_FIND=0 skips this)\n' % (self.tag, self.marker))
+            torch.backends.cudnn.benchmark = True
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        import os
+        if self.marker is not None:
+            torch.backends.cudnn.benchmark = self.was
+            if exc_type is None:
+                try:
+                    os.makedirs(os.path.dirname(self.marker), exist_ok=True)
+                    open(self.marker, 'w').write('tuned\n')
+                except OSError:
+                    pass        # a read-only home: the find step runs again next time
+        return False

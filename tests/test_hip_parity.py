@@ -1347,25 +1347,30 @@ def test_partial_conv_inpainting_pipeline_on_gpu(K):
 
 
 def test_bench_times_its_kernels_on_a_cloud_that_keeps_its_placement_launch(K):
-    """bench.time_kernels on a cloud four times denser than the raster: the one-launch scatter is not available there
-    (kbe_render_frame_group_ahead_ok = 0), and the timing must fall back to the two launches instead of raising (round 3: the
-    configs[4] bench line was lost to exactly that)."""
+    """bench.time_kernels on a cloud twelve times denser than the raster: the one-launch scatter is not available there
+    (kbe_render_frame_group_ahead_ok = 0: 24 units of placements per wave), and the timing must fall back to the two launches
+    instead of raising (round 3: the configs[4] bench line was lost to exactly that); four times denser (configs[4]) the launch's
+    dense form takes the placements along since round 4."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     g0 = torch.Generator().manual_seed(4)
     W, H = 96, 64
-    N = 4 * W * H
+    N = 12 * W * H
     u = torch.rand(N, generator=g0) * W - W / 2 + 0.5
     v = torch.rand(N, generator=g0) * H - H / 2 + 0.5
     z = torch.rand(N, generator=g0) * 400 + 600
     pts = torch.stack([u * z / 512.0, v * z / 512.0, z]).unsqueeze(0).cuda()
     oc = {'intWidth': W, 'intHeight': H, 'dblFocal': 512.0, 'dblBaseline': 120.0, 'tensorInpaPoints': pts,
           'tensorInpaImage': torch.rand(1, 3, N, generator=g0).cuda(), 'tensorInpaDepth': z.view(1, 1, N).cuda()}
-    assert K.lib.kbe_render_frame_group_ahead_ok(N, W, H, 4, 4) == 0
+    assert K.lib.kbe_render_frame_group_ahead_ok(N, W, H, 4, 4) == 0 and K.lib.kbe_render_frame_group_ahead_ok(4 * W * H, W, H, 4, 4) == 1
     kt = bench.time_kernels(oc, [(512.0, (0.5, -0.25, -3.0))] * 3, 'fused', reps=2, group_frames=4)
-    assert 'fused:scatter_group' in kt and 'fused:scatter_group_ahead' not in kt and all(v > 0 for v in kt.values())
+    assert 'fused:scatter_group' in kt and 'fused:scatter_group_ahead' not in kt and all(v > 0 for v in kt.values() if not isinstance(v, list))
+    dense = dict(oc, tensorInpaPoints=pts[:, :, :4 * W * H].contiguous(), tensorInpaImage=oc['tensorInpaImage'][:, :, :4 * W * H].contiguous(),
+                 tensorInpaDepth=oc['tensorInpaDepth'][:, :, :4 * W * H].contiguous())
+    kt = bench.time_kernels(dense, [(512.0, (0.5, -0.25, -3.0))] * 3, 'fused', reps=2, group_frames=4)
+    assert 'fused:scatter_group_ahead' in kt and len(kt['fused:scatter_group_ahead:rounds']) == 5
     sparse = dict(oc, tensorInpaPoints=pts[:, :, :W * H].contiguous(), tensorInpaImage=oc['tensorInpaImage'][:, :, :W * H].contiguous(),
                   tensorInpaDepth=oc['tensorInpaDepth'][:, :, :W * H].contiguous())
     kt = bench.time_kernels(sparse, [(512.0, (0.5, -0.25, -3.0))] * 3, 'fused', reps=2, group_frames=4)

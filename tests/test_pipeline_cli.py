@@ -112,15 +112,17 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
         def __init__(self):
             self.output_frames, self.dolly, self.steps, self.objectCommon, self.moduleInpaint = False, False, 2, {}, None
             self.partial_inpainting, self.moduleRefine, self.miopen_find = False, None, 'auto'
-            self.device = type('D', (), {'type': 'cuda'})()
+            self.device = torch.device('cuda:0')
 
-        def tuning_marker(self, width, height):
-            return str(tmp_path / 'miopen-tuned' / ('%dx%d' % (width, height)))
+        def tuning_tag(self, width, height):
+            return '%dx%d' % (width, height)
 
         def estimate(self, tensorImage):
             seen.append(torch.backends.cudnn.benchmark)
             return self.objectCommon
 
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'get_device_name', lambda *a: 'AMD Instinct MI355X')
     monkeypatch.setattr(P.common, 'process_kenburns', lambda *a, **k: [])
     monkeypatch.setattr(P.common, 'on_device_of', lambda *_: __import__('contextlib').nullcontext())
     before = torch.backends.cudnn.benchmark
@@ -130,12 +132,14 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
     pipe(torch.zeros(1, 3, 64, 96), zoom)
     pipe(torch.zeros(1, 3, 32, 48), zoom)
     assert seen == [True, False, True] and torch.backends.cudnn.benchmark == before
-    assert (tmp_path / 'miopen-tuned' / '96x64').exists() and 'measures its convolution solvers once' in capsys.readouterr().err
+    import glob
+    assert len(glob.glob(str(tmp_path / 'miopen-tuned' / '96x64-AMD_Instinct_MI355X-*'))) == 1 and len(glob.glob(str(tmp_path / 'miopen-tuned' / '*'))) == 2
+    assert 'measures its convolution solvers once' in capsys.readouterr().err
     # explicit settings: never / always
     assert P.Pipeline.__init__.__defaults__ is not None
     monkeypatch.setenv('KBE_MIOPEN_FIND', '0')
     real = P.Pipeline(model_paths=None, allow_random_weights=True, device='cpu', steps=2)
-    assert real.miopen_find is False and 'plain' in real.tuning_marker(96, 64) and '96x64' in real.tuning_marker(96, 64)
+    assert real.miopen_find is False and real.tuning_tag(96, 64) == '96x64-plain'
 
 
 def test_video_without_ffmpeg_is_a_motion_jpeg_avi_that_decodes_back(tmp_path, monkeypatch):
