@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 os.environ.setdefault('KBE_MIOPEN_FIND', '0')      # no MIOpen find step (20-50 s per process) inside the test suite
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')   # ... and no solver search behind PyTorch's immediate mode either (the GPU suite: 45 s instead of 220)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
