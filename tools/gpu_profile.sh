@@ -32,7 +32,7 @@ timeout 900 python $R/bench.py --no-cpu-baseline --size 2048 --upsample 2 --step
 timeout 900 python $R/bench.py --no-cpu-baseline --size 512 --steps 1024 --warmup 64 2>> $OUT/bench.err | tail -1 > $OUT/bench_512.json
 # 2c'''. BASELINE configs[1] as a whole and the 1024^2 partial-convolution forward (bench.py --pipeline), twice: the first process on a fresh
 # box runs MIOpen's find step once (Pipeline(miopen_find='auto')), the second runs in immediate mode on the tuned find-db
-for k in first second; do MIOPEN_FIND_MODE= timeout 900 python $R/bench.py --pipeline --steps 10 --warmup 2 2>> $OUT/bench.err | tail -1 > $OUT/pipeline_${k}_process.json; done
+for k in first second; do timeout 900 python $R/bench.py --pipeline --steps 10 --warmup 2 2>> $OUT/bench.err | tail -1 > $OUT/pipeline_${k}_process.json; done
 # 2d. multi-rank code path on this one GPU (gloo; ranks share the device: a functional check, not a measurement)
 KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 32 --warmup 4 2>> $OUT/bench.err | tail -1 > $OUT/bench_2ranks_gloo_one_gpu.json
 # 2d'. the same code path with configs[4]'s cloud: a 470 MB broadcast (gloo here: a functional check of the size, not an xGMI figure)
