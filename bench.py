@@ -549,6 +549,10 @@ def main():
     # rank 0 owns the scene; other ranks receive the cloud through the broadcast below
     oc = build_scene(size, device, args.cloud == 'inpaint' and not args.dolly and args.upsample == 1, settings, args.upsample) if rank == 0 else {}
     if world_size > 1:
+        if rank == 0 and not args.device_only:
+            # the lanes a delivered video uses are measured ONCE, here, and travel with the cloud's header: the other ranks do not
+            # run the timing probe against each other's host traffic (sharding.measure_delivery_lanes)
+            sharding.measure_delivery_lanes(dict(settings, dblSteps=sharding.shard_steps(settings['dblSteps'], 0, world_size)[1], boolCrop=not args.no_crop), oc)
         sharding.broadcast_cloud(oc, device)          # untimed warm-up of the communicator + fills `oc` everywhere
     n_points = oc['tensorInpaPoints'].shape[-1]
     _, my_steps = sharding.shard_steps(settings['dblSteps'], rank, world_size)
