@@ -34,6 +34,7 @@ FUSED_DENSE = 1.5                # "denser than the raster" from here on: delive
 FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP): transfer groups
                        # of 16 frames are then two EQUAL launches, and equal groups place ahead (the scatter alone: 19.4 us per frame with 8 or 12)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
+PROBE_MIN_FRAMES = 128 # delivered videos from this length on have their lanes measured (HipKernels.delivery_lanes); shorter ones take the a-priori estimate
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
 
 
@@ -510,8 +511,8 @@ class HipKernels:
         does (`host_lanes` has the measurements).  Which it is depends on the cloud, the camera path and the route, so it is
         MEASURED once per cloud, camera-path kind and crop -- twelve of the video's frames rendered into HBM on all lanes, timed
         with two events (a few hundred microseconds, and ONE host synchronisation: the first render_video of a cloud is not
-        enqueue-only) -- and kept in the cloud's state; videos shorter than that, and the first lookup without a camera path, take
-        the a-priori estimate.  A rank that received the cloud by broadcast takes what rank 0 measured (`delivery_lanes_hint`:
+        enqueue-only) -- and kept in the cloud's state; videos shorter than PROBE_MIN_FRAMES (the product's 75 frames: the probe would
+        be a third of their work), and the first lookup without a camera path, take the a-priori estimate.  A rank that received the cloud by broadcast takes what rank 0 measured (`delivery_lanes_hint`:
         sharding.measure_delivery_lanes) and never probes.  Env KBE_HOST_LANES overrides."""
         lanes, W, H = state['lanes'], state['W'], state['H']
         env = os.environ.get('KBE_HOST_LANES')
@@ -525,7 +526,9 @@ class HipKernels:
         cache = state.setdefault('delivery_lanes', {})
         if key in cache:
             return cache[key]
-        if len(cameras) < 24 or lanes == 1:
+        # (a video shorter than PROBE_MIN_FRAMES takes the a-priori estimate: the probe renders 24 frames and synchronises the host --
+        # 0.5 ms of the 1.4 ms a 64-frame 512^2 video takes, paid by every Pipeline call, each with a cloud of its own: ADVICE r3)
+        if len(cameras) < PROBE_MIN_FRAMES or lanes == 1:
             return host_lanes(lanes, state['N'], W, H, 3 * W * H)
         probe = cameras[::max(1, len(cameras) // 12)][:12]
         out = torch.empty(len(probe), H, W, 3, dtype=torch.uint8, device=state['points'].device)

@@ -666,8 +666,9 @@ def test_scratch_budget_falls_back_to_fewer_frames_per_launch_and_hint_replaces_
     budget: with KBE_SCRATCH_BUDGET_MB too small for the default shape the loop takes fewer frames per launch -- same frames.
     (2) The lanes of a delivered video measured on rank 0 and handed over with the cloud (`_kbeDeliveryLanes`, sharding.py) are
     taken as they are: no timing probe runs on the rank that received them."""
-    from ken_burns_effect_amd import common
+    from ken_burns_effect_amd import _native, common
     monkeypatch.setenv('KBE_FUSED', '1')
+    monkeypatch.setattr(_native, 'PROBE_MIN_FRAMES', 24)         # (the probe runs for videos from 128 frames on; this one has 40)
     size = (224, 288)
     settings, oc = _scene(size, 19, 'smooth', True)
     settings = dict(settings, dblSteps=[i / 39.0 for i in range(40)])

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
 
-size = 1024
+size = int(os.environ.get('SIZE', '1024'))
 dev = torch.device('cuda:0')
 ofrom, oto = synthetic.default_windows(size, size, False)
 base = {'objectFrom': ofrom, 'objectTo': oto, 'boolInpaint': True, 'dolly': False}
