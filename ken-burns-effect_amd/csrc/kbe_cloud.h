@@ -25,7 +25,10 @@
 namespace kbe {
 
 constexpr int kCloudBlock = 64;         // points per block (one per lane)
-constexpr int kCloudSub = 16;           // points per SUB-BLOCK (a quarter of a block): the unit of a tile's candidate list (kbe_fused.hip)
+#ifndef KBE_CLOUD_SUB
+#define KBE_CLOUD_SUB 16
+#endif
+constexpr int kCloudSub = KBE_CLOUD_SUB; // points per SUB-BLOCK (a quarter of a block; 8 = an eighth, dev): the unit of a tile's candidate list (kbe_fused.hip)
 constexpr int kCloudFan = 32;           // children per node
 constexpr int kCloudTopMax = 64;        // nodes of the top level at most (one wave tests them in one go)
 constexpr int kCloudMaxLevels = 6;      // 64 * 32^5 blocks: far beyond the 2^30-point limit of the frame loop

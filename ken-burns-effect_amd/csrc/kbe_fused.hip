@@ -46,7 +46,7 @@ constexpr int BIN_WIDE_FAN = 64;
 constexpr int BIN_WIDE_BUDGET = 32;
 __device__ __forceinline__ unsigned bin_budget(int tiles_x, int tiles_y) { return (unsigned) BIN_WIDE_BUDGET * (unsigned) (tiles_x * tiles_y) + 4096u; }
 static_assert(MAXC == TILE_THREADS, "one candidate per thread in the prefix scan of the slow path");
-static_assert(LIST_CAP % TILE_THREADS == 0 && kCloudBlock % kCloudSub == 0 && kCloudSub == 16, "list geometry: a sub-block is one DPP row");
+static_assert(LIST_CAP % TILE_THREADS == 0 && kCloudBlock % kCloudSub == 0 && (kCloudSub == 16 || kCloudSub == 8), "list geometry: a sub-block is one DPP row, or half of one");
 
 struct Placement { float ox, oy, err; };     // 12 bytes per point and frame; ox = PLACE_NONE: the point touches no pixel
 static_assert(sizeof(Placement) == 12, "placement record");
@@ -185,6 +185,11 @@ __device__ __forceinline__ int row_min(int v)
     // (s_nop 4 in front: should the compiler ever schedule a VALU write of EXEC just ahead, a DPP read needs five wait states behind
     // it.  EVERY lane of the row must be active: bound_ctrl is off, a disabled lane would keep its own value out of the others'
     // minimum -- the callers hold whole waves, Np is a multiple of 64 and every branch around a call is wave-uniform.  gfx9 wave64.)
+    if (kCloudSub == 8)         // (dev: sub-blocks of 8 points -- the minimum over each half of the row)
+        asm("s_nop 4\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    else
     asm("s_nop 4\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
@@ -225,7 +230,7 @@ __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i
         const int pos = atomicAdd(&tile_count[(uint32_t) t * CNT_STRIDE], 1);
         if (pos < LIST_CAP) cand_lists[(size_t) t * LIST_CAP + pos] = sub;     // beyond: the tile sees count > LIST_CAP and scans
     };
-    if (some && w <= 4 && h <= 4) {
+    if (some && w <= 4 && h <= kCloudSub / 4) {
         // the usual box of one to four tiles (at most 4 x 4): lane j of the row takes tile (j & 3, j >> 2) of it -- one
         // atomic per lane, no loop, no division
 #if defined(KBE_FRAME_STATS)
@@ -415,7 +420,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     Placement pl[DEPTH]; CloudColour cc[DEPTH]; int ix[DEPTH], ent[DEPTH];
     auto fetch_entries = [&](int st0) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[min((st0 + d * WAVES) * SUBS_PER_STEP + (lane >> 4), LIST_CAP - 1)];
+        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[min((st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub, LIST_CAP - 1)];
     };
     auto fetch_points = [&]() {
 #pragma unroll
@@ -567,7 +572,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 #pragma unroll
             for (int d = 0; d < DEPTH; d++)
                 if (st0 + d * WAVES < n_steps) {
-                    const bool valid = (st0 + d * WAVES) * SUBS_PER_STEP + (lane >> 4) < n_cand;
+                    const bool valid = (st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub < n_cand;
                     placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
                 }
             if (more) fetch_points();

@@ -12,6 +12,7 @@
 #include "kbe_device.h"
 #include "kbe_fill.h"
 #include "kbe_host.h"
+#include "kbe_cloud.h"
 
 #pragma clang fp contract(off)
 
@@ -48,7 +49,7 @@ constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's 
 constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between two buckets: NOT a power-of-two multiple, or the
                                                     // live head of every bucket lands on the same few HBM channels
 #ifndef KBE_CAND_CAP
-#define KBE_CAND_CAP 512
+#define KBE_CAND_CAP (512 * 16 / KBE_CLOUD_SUB)
 #endif
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2
