@@ -338,13 +338,21 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
                 m.last_size = (None, None, None, None)
         try:
             ref = net(tensorData=data, tensorMasks=mask)
+            ref = {k: v.clone() for k, v in ref.items() if torch.is_tensor(v)}
+            again = net(tensorData=data, tensorMasks=mask)          # the same formulation once more: what MIOpen's own run-to-run noise is
         finally:
             partial_conv.PartialConv2d.forward = fused_forward
     assert torch.equal(fused['tensorMaskOut'], ref['tensorMaskOut']) and torch.equal(fused['tensorExisting'], ref['tensorExisting'])
     assert 0.05 < float(1 - mask.mean()) < 0.4
-    _close(fused['tensorImage'], c(ref['tensorImage']), 2 * TOL_IMAGE, 'partial Inpaint image at 1024^2')
+    # MIOpen's fp32 solvers at this size are not bit-reproducible from run to run (split-K accumulation by atomics): two runs of the
+    # SAME formulation differ by up to ~5e-5 in the image after thirty layers (measured: 3e-5 - 5e-5), which is where the two
+    # formulations sit as well -- so the bar is twice the fixture test's tolerance plus twice that noise, measured here
+    noise_i = float((again['tensorImage'] - ref['tensorImage']).abs().max())
+    noise_d = float((again['tensorDisparity'] - ref['tensorDisparity']).abs().max())
+    print('run-to-run noise of the reference formulation: image %.3g, disparity %.3g' % (noise_i, noise_d))
+    _close(fused['tensorImage'], c(ref['tensorImage']), 2 * TOL_IMAGE + 2 * noise_i, 'partial Inpaint image at 1024^2')
     dref = c(ref['tensorDisparity'])
-    _close(fused['tensorDisparity'], dref, 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(dref).max())), 'partial Inpaint disparity at 1024^2')
+    _close(fused['tensorDisparity'], dref, 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(dref).max())) + 2 * noise_d, 'partial Inpaint disparity at 1024^2')
 
 
 # ---------------------------------------------------------------------------------------
