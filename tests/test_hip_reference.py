@@ -156,6 +156,7 @@ def test_product_route_against_reference_run_frames_at_size(K, tag):
     for i, (f, ref) in enumerate(zip(frames, z['frames'])):
         moved = (np.abs(f.astype(np.int32) - ref.astype(np.int32)).max(axis=2) > 1).mean()
         db = psnr_u8(f, ref)
+        print('%s frame %d: %.2f dB against the reference-run frame, %.3f %% of the pixels moved by more than one count' % (tag, i, db, 100 * moved))
         assert db > PRODUCT_FLOOR_DB[tag] and moved < 0.01, 'frame %d: %.2f dB against the reference-run frame, %.3f %% of the pixels moved by more than one count' % (i, db, 100 * moved)
 
 
