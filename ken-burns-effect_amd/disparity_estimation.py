@@ -41,6 +41,10 @@ class Semantics(nn.Module):
                 cin = v
                 idx += 3
         self.moduleVgg = nn.Sequential(*blocks)
+        # the ImageNet statistics of :109-113 as (non-persistent: not in the state dict) buffers: built from Python lists in every
+        # forward they were two synchronous host-to-device copies per image
+        self.register_buffer('_mean', torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer('_std', torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
 
     def load_torchvision_state_dict(self, state):
         """`state`: torchvision vgg19_bn().state_dict() (keys 'features.N.weight' ...)."""
@@ -53,9 +57,8 @@ class Semantics(nn.Module):
 
     def forward(self, tensorInput):
         # BGR -> RGB and ImageNet statistics (:109-113), without modifying the caller's tensor
-        mean = tensorInput.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
-        std = tensorInput.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-        return self.moduleVgg((tensorInput[:, [2, 1, 0], :, :] - mean) / std)
+        mean, std = self._mean.to(tensorInput.dtype), self._std.to(tensorInput.dtype)
+        return self.moduleVgg((tensorInput.flip(1) - mean) / std)       # [:, [2, 1, 0]]: a flip of the three channels, without an index tensor from the host
 
 
 class Disparity(nn.Module):
