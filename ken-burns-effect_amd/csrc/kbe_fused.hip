@@ -325,6 +325,9 @@ typedef const __attribute__((address_space(4))) PackedCloud* PackedCloudPtr;
 #define KBE_AHEAD_UNITS 3       // (a wave's share of an equal group is 2.17 units: with three up front nothing is left for the end; 17.9 -> 17.6 us per frame)
 #endif
 constexpr int AHEAD_UNITS = KBE_AHEAD_AT >= 2 ? KBE_AHEAD_UNITS : 0;
+#ifndef KBE_LAZY_COLOURS
+#define KBE_LAZY_COLOURS 2      // colours fetched for the records only, behind the splat (see frame_body): 0 never, 1 always,
+#endif                          // 2 in the launch for dense clouds (measured: 1024^2 inpaint cloud +3 %, 2048^2 with 16.8 M points -4 %)
 
 __device__ __forceinline__ Camera load_camera(const __attribute__((address_space(4))) Camera* c)
 {
@@ -376,6 +379,7 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
 template <int J, bool AHEAD, int UNITS = AHEAD_UNITS>
 __device__ __forceinline__ void frame_body(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
 {
+    constexpr bool LAZY = KBE_LAZY_COLOURS == 1 || (KBE_LAZY_COLOURS == 2 && UNITS > AHEAD_UNITS);
     FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
     PackedCloudPtr pcp = &jp->pc;
     __shared__ FrameLds F;
@@ -427,7 +431,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         for (int d = 0; d < DEPTH; d++) {
             ix[d] = (int) (min((uint32_t) ent[d], last_sub) * kCloudSub) + (lane & (kCloudSub - 1));
             pl[d] = place[ix[d]];
-            cc[d] = colours[ix[d]];
+            if (!LAZY) cc[d] = colours[ix[d]];
         }
     };
     fetch_entries(wave);
@@ -573,7 +577,8 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             for (int d = 0; d < DEPTH; d++)
                 if (st0 + d * WAVES < n_steps) {
                     const bool valid = (st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub < n_cand;
-                    placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
+                    if (LAZY) placed_point(PASS_Z | PASS_INSERT | PASS_SPILL, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                    else placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
                 }
             if (more) fetch_points();
         }
@@ -636,10 +641,29 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     const int n_spill = F.n_ovf;
     if (listed && n_spill <= BUCKET_CAP) {
         // ---- the first REC_CAP records are in LDS with their colours
+        // ... or (LAZY: the launch for dense clouds, which is as close to the memory's limit as to the issue rate's) with their
+        // points: the colours of the RECORDS only -- the near misses of the candidate list, a third of it, never fetch
+        // theirs -- requested here and stored behind the degrid, which needs none of them
+        const int n_held = min(total, REC_CAP);
+        float4 lc[PER];
+        if (LAZY) {
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                if (i < n_held) lc[u] = fetch_rgbd(__float_as_int(L.rgbd[i].x));
+            }
+        }
         decode_z();
         __syncthreads();
         fast = tile_is_fast();
         tile_degrid(a, L, tid, x0, y0, fast);
+        if (LAZY) {
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * TILE_THREADS;
+                if (i < n_held) L.rgbd[i] = lc[u];
+            }
+        }
         KBE_PROBE(5);
         __syncthreads();                                        // the epilogue stages its bytes where the degrid still reads its neighbours' z
         KBE_PROBE(6);
