@@ -12,6 +12,8 @@ Backend "nccl" is RCCL on ROCm (xGMI is point-to-point; a 31 MB one-to-all broad
 is ~0.2 ms and happens once per video); "gloo" runs the same code on CPU tensors for
 the world_size-2 tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -60,13 +62,20 @@ def shard_steps(steps, rank=None, world_size=None):
     return idx, [steps[i] for i in idx]
 
 
+def single_rank_collectives():
+    """KBE_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank still runs the cloud broadcast (and decodes its header
+    like a receiver) and the frame gather, instead of returning early -- the way a 1-GPU box checks that RCCL comes up on the
+    device and takes these collectives' dtypes and shapes (tests/test_hip_parity.py).  Not a product setting."""
+    return os.environ.get('KBE_SINGLE_RANK_COLLECTIVES', '0') == '1'
+
+
 def broadcast_cloud(objectCommon, device, src=0):
     """Rank `src` holds the finished cloud in ``objectCommon``; afterwards every rank does,
     bit-identical (so frames are byte-identical to a single-GPU run).  Two collectives: a
     small header (N and the scalars, incl. objectDepthrange) and one packed [7,N] fp32
     payload."""
     rank, world_size = world()
-    if world_size == 1:
+    if world_size == 1 and not (dist.is_initialized() and single_rank_collectives()):
         return objectCommon
     header = torch.zeros(16, dtype=torch.float64, device=device)
     if rank == src:
@@ -92,7 +101,7 @@ def broadcast_cloud(objectCommon, device, src=0):
             packed = torch.empty(7, n, dtype=torch.float32, device=device)
             objectCommon['_kbePackedCloud'] = packed
     dist.broadcast(packed, src)
-    if rank != src:
+    if rank != src or world_size == 1:
         objectCommon['dblFocal'] = h[1]
         objectCommon['dblBaseline'] = int(h[2]) if h[11] == 1.0 else h[2]
         objectCommon['intWidth'], objectCommon['intHeight'] = int(h[3]), int(h[4])
@@ -126,7 +135,7 @@ def gather_frames(local_frames, indices, total, device, dst=0):
     """Collects per-rank uint8 frames [n_local,H,W,3] on rank `dst` in original step order.
     Returns the full [total,H,W,3] tensor on `dst`, None elsewhere."""
     rank, world_size = world()
-    if world_size == 1:
+    if world_size == 1 and not (dist.is_initialized() and single_rank_collectives()):
         return local_frames
     per = (total + world_size - 1) // world_size
     H, W = local_frames.shape[1:3]

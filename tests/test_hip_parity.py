@@ -1326,6 +1326,22 @@ def test_sharded_video_over_rccl_when_the_box_has_two_gpus():
     assert out.returncode == 0 and 'OK (nccl' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_rccl_comes_up_and_takes_the_cloud_broadcast_and_the_frame_gather_with_one_rank():
+    """What a 1-GPU box can check of the RCCL path: backend "nccl" initialises on the device, and -- with
+    KBE_SINGLE_RANK_COLLECTIVES=1, which keeps a group of one rank from returning early -- the float64 header broadcast, the
+    [7, N] fp32 payload broadcast (decoded like a receiver decodes it), the uint8 frame gather and the barrier all run on it;
+    the frames must equal the single-process render (tools/sharded_check.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                          '--master-port', '29541', os.path.join(root, 'tools', 'sharded_check.py')],
+                         capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', KBE_DIST_BACKEND='nccl', KBE_SINGLE_RANK_COLLECTIVES='1'))
+    assert out.returncode == 0 and 'OK (nccl, 1 ranks)' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_partial_conv_inpainting_pipeline_on_gpu(K):
     """BASELINE.json configs[3] in miniature: the partial-convolution Inpaint (fused HIP mask-update epilogue) driving
     the set-up of a KBE video, and a dolly video (no inpainting, common.py:217), both through Pipeline."""

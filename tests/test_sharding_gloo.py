@@ -140,6 +140,46 @@ def test_eight_ranks_render_a_75_frame_video_as_one_process_does(tmp_path):
     assert np.array_equal(np.load(str(tmp_path / 'gathered.npy')), single), 'frames gathered on rank 0'
 
 
+def _worker_one(rank, world_size, port, out_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), KBE_SINGLE_RANK_COLLECTIVES='1')
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from ken_burns_effect_amd import common, sharding
+        from oracle import kbe_oracle
+        common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+        settings, oc = _scene()
+        common._reset_inpa(oc)
+        before = {k: oc[k].clone() for k in ('tensorInpaPoints', 'tensorInpaImage', 'tensorInpaDepth')}
+        scalars = (oc['dblFocal'], oc['dblBaseline'], oc['intWidth'], oc['intHeight'], oc['objectDepthrange'])
+        frames = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'), gather=True)
+        # the receiver's decode ran on this rank: the cloud and its scalars came back as they went in
+        assert all(torch.equal(before[k], oc[k]) for k in before) and '_kbePackedCloud' not in oc
+        assert (oc['dblFocal'], oc['dblBaseline'], oc['intWidth'], oc['intHeight']) == scalars[:4] and type(oc['dblBaseline']) is type(scalars[1])
+        assert tuple(oc['objectDepthrange'][:2]) == tuple(scalars[4][:2]) and tuple(map(tuple, oc['objectDepthrange'][2:])) == tuple(map(tuple, scalars[4][2:]))
+        np.save(out_path, np.stack(frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_group_of_one_rank_can_be_made_to_run_the_collectives(tmp_path):
+    """KBE_SINGLE_RANK_COLLECTIVES=1 (the mode the GPU suite uses to put the broadcast and the gather through RCCL on a 1-GPU
+    box): header and payload broadcast, the receiver's decode, the frame gather -- same frames as without a process group."""
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import common
+    from oracle import kbe_oracle
+    out = str(tmp_path / 'frames.npy')
+    mp.spawn(_worker_one, args=(1, _free_port(), out), nprocs=1, join=True)
+    common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+    try:
+        settings, oc = _scene()
+        common._reset_inpa(oc)
+        single = np.stack(common.process_kenburns(settings, oc, None))
+    finally:
+        common._kernel_set = None
+    assert np.array_equal(np.load(out), single)
+
+
 def test_shard_steps_partition():
     from ken_burns_effect_amd import sharding
     steps = list(range(10))
