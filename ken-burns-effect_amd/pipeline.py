@@ -9,7 +9,7 @@ Differences, on purpose: the unused Mask-RCNN of the reference (:36, deleted at 
 weights of ``Semantics`` come from a file (``semantics_path``) instead of a torchvision download;
 ``cv2.minMaxLoc`` is replaced by :func:`synthetic.depthrange_of`; frames are written with PIL and the
 video through an ``ffmpeg`` binary if one is on PATH (OpenCV / moviepy are not dependencies) --
-otherwise a Motion-JPEG ``.avi`` (written here, no external encoder) stands in for the ``.mp4``.  Returns the frame list.
+otherwise the ``.mp4`` holds Motion-JPEG (ISO base media file written here, no external encoder).  Returns the frame list.
 """
 import os
 import shutil
@@ -157,16 +157,10 @@ def write_frames(frames_dir, frames_rgb):
 
 def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
     """A playable video without any external encoder: Motion-JPEG in an AVI container (RIFF 'AVI ' with one 'vids' / 'MJPG' stream,
-    an 'idx1' index; every frame a baseline JPEG from PIL).  What write_video falls back to where there is no ffmpeg binary."""
-    import io
+    an 'idx1' index; every frame a baseline JPEG from PIL).  What write_video writes for an ``.avi`` where there is no ffmpeg binary."""
     import struct
-    from PIL import Image
     h, w = frames_rgb[0].shape[:2]
-    jpegs = []
-    for frame in frames_rgb:
-        buf = io.BytesIO()
-        Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
-        jpegs.append(buf.getvalue())
+    jpegs = _jpegs(frames_rgb, quality)
     n = len(jpegs)
     biggest = max(len(j) for j in jpegs)
 
@@ -192,14 +186,77 @@ def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
     return path
 
 
+def _jpegs(frames_rgb, quality):
+    import io
+    from PIL import Image
+    out = []
+    for frame in frames_rgb:
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
+        out.append(buf.getvalue())
+    return out
+
+
+def write_mjpeg_mp4(path, frames_rgb, fps=25, quality=92):
+    """An ``.mp4`` without any external encoder: an ISO base media file (ISO/IEC 14496-12) with one video track whose samples are
+    baseline JPEGs (PIL) -- sample entry ``mp4v`` with an ``esds`` whose objectTypeIndication is 0x6C, "Visual ISO/IEC 10918-1
+    (JPEG)", the registered way of carrying Motion-JPEG in MP4 (what ffmpeg's mp4 muxer writes for ``-c:v mjpeg``; ffmpeg-based
+    players, VLC and mpv decode it).  Layout: ftyp, mdat (the samples, one chunk), moov (every sample a sync sample: no stss)."""
+    import struct
+    jpegs = _jpegs(frames_rgb, quality)
+    h, w = frames_rgb[0].shape[:2]
+    n, delta = len(jpegs), 512
+    timescale = int(fps) * delta
+    duration = n * delta
+
+    def box(tag, body):
+        return struct.pack('>I', len(body) + 8) + tag + body
+
+    def full(tag, version, flags, body):
+        return box(tag, struct.pack('>I', (version << 24) | flags) + body)
+
+    def descriptor(tag, body):
+        assert len(body) < 128
+        return bytes([tag, len(body)]) + body
+
+    matrix = struct.pack('>9I', 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+    ftyp = box(b'ftyp', b'isom' + struct.pack('>I', 0x200) + b'isomiso2mp41')
+    mdat = box(b'mdat', b''.join(jpegs))
+    first_sample = len(ftyp) + 8
+    assert first_sample + len(mdat) < (1 << 32), 'a 32-bit chunk offset: the video is too long for this writer'
+    biggest, total = max(len(j) for j in jpegs), sum(len(j) for j in jpegs)
+    decoder = descriptor(0x04, bytes([0x6C, 0x11]) + struct.pack('>I', biggest)[1:] + struct.pack('>II', biggest * 8 * int(fps), total * 8 * int(fps) // n))
+    esds = full(b'esds', 0, 0, descriptor(0x03, struct.pack('>HB', 1, 0) + decoder + descriptor(0x06, b'\x02')))
+    name = b'Motion-JPEG'
+    mp4v = box(b'mp4v', b'\0' * 6 + struct.pack('>H', 1) + b'\0' * 16 + struct.pack('>HHIIIH', w, h, 0x480000, 0x480000, 0, 1) +
+               bytes([len(name)]) + name.ljust(31, b'\0') + struct.pack('>Hh', 24, -1) + esds)
+    stbl = box(b'stbl', full(b'stsd', 0, 0, struct.pack('>I', 1) + mp4v) +
+               full(b'stts', 0, 0, struct.pack('>III', 1, n, delta)) +
+               full(b'stsc', 0, 0, struct.pack('>IIII', 1, 1, n, 1)) +
+               full(b'stsz', 0, 0, struct.pack('>II', 0, n) + b''.join(struct.pack('>I', len(j)) for j in jpegs)) +
+               full(b'stco', 0, 0, struct.pack('>II', 1, first_sample)))
+    minf = box(b'minf', full(b'vmhd', 0, 1, struct.pack('>4H', 0, 0, 0, 0)) +
+               box(b'dinf', full(b'dref', 0, 0, struct.pack('>I', 1) + full(b'url ', 0, 1, b''))) + stbl)
+    mdia = box(b'mdia', full(b'mdhd', 0, 0, struct.pack('>IIIIHH', 0, 0, timescale, duration, 0x55C4, 0)) +
+               full(b'hdlr', 0, 0, struct.pack('>I', 0) + b'vide' + b'\0' * 12 + b'VideoHandler\0') + minf)
+    tkhd = full(b'tkhd', 0, 3, struct.pack('>IIIII', 0, 0, 1, 0, duration) + b'\0' * 8 + struct.pack('>hhhH', 0, 0, 0, 0) + matrix +
+                struct.pack('>II', w << 16, h << 16))
+    mvhd = full(b'mvhd', 0, 0, struct.pack('>IIIIIH', 0, 0, timescale, duration, 0x10000, 0x100) + b'\0' * 10 + matrix + b'\0' * 24 + struct.pack('>I', 2))
+    with open(path, 'wb') as f:
+        f.write(ftyp + mdat + box(b'moov', mvhd + box(b'trak', tkhd + mdia)))
+    return path
+
+
 def write_video(path, frames_rgb, fps=25):
-    """mpeg4 through an ffmpeg pipe when the binary exists (what moviepy does, pipeline.py:132-134);
-    otherwise a Motion-JPEG .avi of the same frames is written next to it (no external encoder needed) and the function says so."""
+    """mpeg4 through an ffmpeg pipe when the binary exists (what moviepy does, pipeline.py:132-134).  Without one the video is still
+    written, under the name asked for, with the encoder this package carries: Motion-JPEG -- in an MP4 container for an ``.mp4``
+    (write_mjpeg_mp4), in an AVI for an ``.avi`` (write_mjpeg_avi) -- and the function says so and returns False."""
     ffmpeg = shutil.which('ffmpeg')
     h, w = frames_rgb[0].shape[:2]
     if ffmpeg is None:
-        avi = write_mjpeg_avi(os.path.splitext(path)[0] + '.avi', frames_rgb, fps)
-        print('ffmpeg not found: wrote %s (Motion-JPEG, %d frames at %d fps) instead of %s' % (avi, len(frames_rgb), fps, path))
+        writer = write_mjpeg_avi if path.lower().endswith('.avi') else write_mjpeg_mp4
+        writer(path, frames_rgb, fps)
+        print('ffmpeg not found: %s holds Motion-JPEG (%d frames at %d fps) instead of mpeg4' % (path, len(frames_rgb), fps))
         return False
     proc = subprocess.Popen([ffmpeg, '-y', '-loglevel', 'error', '-f', 'rawvideo', '-pix_fmt', 'rgb24', '-s', '%dx%d' % (w, h),
                              '-r', str(fps), '-i', '-', '-c:v', 'mpeg4', path], stdin=subprocess.PIPE)

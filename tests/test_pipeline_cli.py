@@ -31,7 +31,7 @@ def test_pipeline_end_to_end_on_cpu(oracle, monkeypatch, tmp_path, recwarn):
     assert abs(oc['dblDispmax'] - 120) < 1e-3 and oc['dblDispmin'] >= 0                      # pipeline.py:79-81
     assert oc['tensorInpaPoints'].shape[2] >= 64 * 96                                         # inpainting appended points
     assert (tmp_path / 'frames' / '2.png').exists()
-    assert (tmp_path / '3d_kbe.mp4').exists() or (tmp_path / '3d_kbe.avi').exists()
+    assert (tmp_path / '3d_kbe.mp4').exists()
     assert any('seeded random weights' in str(w.message) for w in recwarn.list)
     assert any('semantics (VGG19-bn)' in str(w.message) for w in recwarn.list)
 
@@ -142,9 +142,30 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
     assert real.miopen_find is False and real.tuning_tag(96, 64) == '96x64-plain'
 
 
-def test_video_without_ffmpeg_is_a_motion_jpeg_avi_that_decodes_back(tmp_path, monkeypatch):
-    """No ffmpeg binary (either image): write_video leaves a Motion-JPEG AVI -- a RIFF file whose frames decode back (PIL) to the
-    frames written, in order, within JPEG's loss; its header carries the size, the rate and the frame count."""
+def _boxes(blob, start, end):
+    """The boxes of an ISO base media file between two offsets: (type, body offset, body end)."""
+    import struct
+    out, pos = [], start
+    while pos < end:
+        size, tag = struct.unpack('>I4s', blob[pos:pos + 8])
+        assert size >= 8 and pos + size <= end, (tag, size)
+        out.append((tag, pos + 8, pos + size))
+        pos += size
+    assert pos == end
+    return out
+
+
+def _child(blob, boxes, tag):
+    hit = [b for b in boxes if b[0] == tag]
+    assert len(hit) == 1, (tag, [b[0] for b in boxes])
+    return hit[0]
+
+
+def test_video_without_ffmpeg_is_an_mp4_of_motion_jpeg_that_decodes_back(tmp_path, monkeypatch):
+    """No ffmpeg binary (either image): write_video still leaves the .mp4 it was asked for -- an ISO base media file (ftyp, mdat,
+    moov) with one video track of JPEG samples.  Walked box by box here: the sample table (stsz sizes, the one chunk's stco offset,
+    stts, stsc) must lead to every frame, which must decode (PIL) to the frame written, in order, within JPEG's loss; the track and
+    the sample entry carry the size; the esds names JPEG (objectTypeIndication 0x6C); durations are frames / fps."""
     import io
     import struct
     from PIL import Image
@@ -153,6 +174,65 @@ def test_video_without_ffmpeg_is_a_motion_jpeg_avi_that_decodes_back(tmp_path, m
     yy, xx = np.mgrid[0:48, 0:64]
     frames = [np.stack([(xx * 3 + 10 * i) % 256, (yy * 4) % 256, np.full_like(xx, 40 * i)], axis=2).astype(np.uint8) for i in range(5)]
     assert P.write_video(str(tmp_path / '3d_kbe.mp4'), frames, fps=25) is False
+    blob = (tmp_path / '3d_kbe.mp4').read_bytes()
+    top = _boxes(blob, 0, len(blob))
+    assert [b[0] for b in top] == [b'ftyp', b'mdat', b'moov'] and blob[8:12] == b'isom'
+    moov = _boxes(blob, *_child(blob, top, b'moov')[1:])
+    mvhd = _child(blob, moov, b'mvhd')
+    timescale, duration = struct.unpack('>II', blob[mvhd[1] + 12:mvhd[1] + 20])
+    assert duration / timescale == 5 / 25
+    trak = _boxes(blob, *_child(blob, moov, b'trak')[1:])
+    tkhd = _child(blob, trak, b'tkhd')
+    assert tkhd[2] - tkhd[1] == 84 and struct.unpack('>II', blob[tkhd[2] - 8:tkhd[2]]) == (64 << 16, 48 << 16)
+    mdia = _boxes(blob, *_child(blob, trak, b'mdia')[1:])
+    hdlr = _child(blob, mdia, b'hdlr')
+    assert blob[hdlr[1] + 8:hdlr[1] + 12] == b'vide'
+    mdhd = _child(blob, mdia, b'mdhd')
+    assert struct.unpack('>II', blob[mdhd[1] + 12:mdhd[1] + 20]) == (timescale, duration)
+    minf = _boxes(blob, *_child(blob, mdia, b'minf')[1:])
+    assert {b[0] for b in minf} == {b'vmhd', b'dinf', b'stbl'}
+    stbl = _boxes(blob, *_child(blob, minf, b'stbl')[1:])
+    stsd = _child(blob, stbl, b'stsd')
+    assert struct.unpack('>I', blob[stsd[1] + 4:stsd[1] + 8])[0] == 1
+    entry = _boxes(blob, stsd[1] + 8, stsd[2])
+    assert [b[0] for b in entry] == [b'mp4v']
+    e0 = entry[0][1]
+    assert struct.unpack('>HH', blob[e0 + 24:e0 + 28]) == (64, 48) and struct.unpack('>H', blob[e0 + 74:e0 + 76])[0] == 24
+    esds = _boxes(blob, e0 + 78, entry[0][2])
+    assert [b[0] for b in esds] == [b'esds']
+    d = esds[0][1] + 4
+    assert blob[d] == 0x03 and blob[d + 5] == 0x04 and blob[d + 7] == 0x6C and blob[d + 8] == 0x11         # ES, DecoderConfig: JPEG, visual stream
+    stts = _child(blob, stbl, b'stts')
+    assert struct.unpack('>III', blob[stts[1] + 4:stts[1] + 16]) == (1, 5, duration // 5)
+    stsc = _child(blob, stbl, b'stsc')
+    assert struct.unpack('>IIII', blob[stsc[1] + 4:stsc[1] + 20]) == (1, 1, 5, 1)
+    stsz = _child(blob, stbl, b'stsz')
+    uniform, count = struct.unpack('>II', blob[stsz[1] + 4:stsz[1] + 12])
+    sizes = struct.unpack('>5I', blob[stsz[1] + 12:stsz[1] + 32])
+    stco = _child(blob, stbl, b'stco')
+    n_chunks, offset = struct.unpack('>II', blob[stco[1] + 4:stco[1] + 12])
+    mdat = _child(blob, top, b'mdat')
+    assert (uniform, count, n_chunks) == (0, 5, 1) and offset == mdat[1] and offset + sum(sizes) == mdat[2]
+    assert not [b for b in stbl if b[0] == b'stss']                 # every sample a sync sample
+    for want, size in zip(frames, sizes):
+        sample = blob[offset:offset + size]
+        assert sample[:2] == b'\xff\xd8' and sample[-2:] == b'\xff\xd9'
+        got = np.asarray(Image.open(io.BytesIO(sample)).convert('RGB'))
+        assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).mean() < 6.0
+        offset += size
+
+
+def test_an_avi_without_ffmpeg_is_motion_jpeg_that_decodes_back(tmp_path, monkeypatch):
+    """No ffmpeg binary and an .avi asked for: a RIFF file whose frames decode back (PIL) to the frames written, in order, within
+    JPEG's loss; its header carries the size, the rate and the frame count."""
+    import io
+    import struct
+    from PIL import Image
+    from ken_burns_effect_amd import pipeline as P
+    monkeypatch.setattr(P.shutil, 'which', lambda name: None)
+    yy, xx = np.mgrid[0:48, 0:64]
+    frames = [np.stack([(xx * 3 + 10 * i) % 256, (yy * 4) % 256, np.full_like(xx, 40 * i)], axis=2).astype(np.uint8) for i in range(5)]
+    assert P.write_video(str(tmp_path / '3d_kbe.avi'), frames, fps=25) is False
     blob = (tmp_path / '3d_kbe.avi').read_bytes()
     assert blob[:4] == b'RIFF' and blob[8:12] == b'AVI ' and struct.unpack('<I', blob[4:8])[0] == len(blob) - 8
     avih = blob.index(b'avih') + 8

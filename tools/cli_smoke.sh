@@ -15,4 +15,5 @@ for extra in "" "--dolly" "--2d --write-frames"; do
   python -c "
 import glob, os
 f = glob.glob('/tmp/kbe_out/3d_kbe.*'); print('$extra ->', f[0], os.path.getsize(f[0]), 'bytes,', open(f[0], 'rb').read(12))"
+  file /tmp/kbe_out/3d_kbe.* 2>/dev/null
 done
