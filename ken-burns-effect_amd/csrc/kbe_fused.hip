@@ -335,11 +335,6 @@ __device__ __forceinline__ Camera load_camera(const __attribute__((address_space
     cam.focal_f = c->focal_f; cam.fb_f = c->fb_f; cam.fb = c->fb; cam.half_w = c->half_w; cam.half_h = c->half_h;
     cam.cx_f = c->cx_f; cam.cy_f = c->cy_f; cam.fp32_centre = c->fp32_centre; cam.W = c->W; cam.H = c->H;
     cam.has_shift = c->has_shift; cam.sx = c->sx; cam.sy = c->sy; cam.sz = c->sz;
-#if defined(KBE_VGPR_UNIFORMS) && KBE_VGPR_UNIFORMS
-    asm volatile("v_mov_b32 %0, %1" : "=v"(cam.sx) : "s"(cam.sx)); asm volatile("v_mov_b32 %0, %1" : "=v"(cam.sy) : "s"(cam.sy));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(cam.sz) : "s"(cam.sz)); asm volatile("v_mov_b32 %0, %1" : "=v"(cam.focal_f) : "s"(cam.focal_f));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(cam.cx_f) : "s"(cam.cx_f)); asm volatile("v_mov_b32 %0, %1" : "=v"(cam.cy_f) : "s"(cam.cy_f));
-#endif
     return cam;
 }
 
@@ -480,9 +475,6 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     KBE_PROBE(1);
     __syncthreads();
     KBE_PROBE(2);
-#if defined(KBE_SETPRIO) && KBE_SETPRIO
-    __builtin_amdgcn_s_setprio(KBE_SETPRIO);           // (dev) the tile's own phases ahead of other workgroups' prologues and placements
-#endif
     if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
@@ -496,21 +488,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     // (slow path) records each candidate block of a window contributes, then their prefix sums: in the tile's spill area, which
     // only the normal path's further rounds use -- 1 KB less LDS is what lets a fifth workgroup onto the CU
     int* const slow_cnt = (int*) spill;
-#if defined(KBE_VGPR_UNIFORMS) && KBE_VGPR_UNIFORMS
-    // (dev) wave-uniform operands of the splat's integer arithmetic held in vector registers: an instruction with a scalar-register
-    // operand does not take the second issue port (profiles/r04_valu_rate.txt: v_add_f32 with an SGPR source runs at the one-port rate)
-    int x0m2, y0m2;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(x0m2) : "s"(x0 - 2));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(y0m2) : "s"(y0 - 2));
-#endif
     auto placed_point = [&](int flags, float ox, float oy, float err, bool ok, int idx, int c, const float4& col) {
         Proj p;
         p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
-#if defined(KBE_VGPR_UNIFORMS) && KBE_VGPR_UNIFORMS
-        const int rx = p.nwx - x0m2, ry = p.nwy - y0m2;
-#else
         const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
-#endif
         // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
         const bool in_z = ok & ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
         // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
@@ -523,11 +504,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             project_weights(ox, oy, p);
             const int k = winner_corner_finite(p);                                  // common.py:486-506 (ox, oy are finite)
             const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-#if defined(KBE_VGPR_UNIFORMS) && KBE_VGPR_UNIFORMS
-            const int lx = cx - x0m2 - 1, ly = cy - y0m2 - 1;
-#else
             const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
-#endif
             // (byte offset from a 24-bit multiply-add: written on the element index the compiler folded the x 4 into a
             // quarter-rate 32-bit multiply)
             if (inside(cx, cy, W, H) & ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
@@ -826,9 +803,6 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 #endif
     tile_epilogue(a, L, acc, tile, x0, y0);
     KBE_PROBE(8);
-#if defined(KBE_SETPRIO) && KBE_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (AHEAD && KBE_AHEAD_AT != 1) {
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");
