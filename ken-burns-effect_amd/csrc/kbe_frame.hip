@@ -1378,8 +1378,18 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 }
                 counting = false;
             }
+#if defined(KBE_VIDEO_GPU_TRACE)     // dev build only (tools/handoff_gpu_trace.py): when, on the device, a group's frames are ready, its gate opens, its transfer ends
+            std::vector<hipEvent_t> ev_begin(n_groups), ev_ready(n_groups), ev_gate(n_groups), ev_copied(n_groups);
+            hipEvent_t ev_start;
+            (void) hipEventCreate(&ev_start);
+            (void) hipEventRecord(ev_start, cs);
+            for (int g = 0; g < n_groups; g++) { (void) hipEventCreate(&ev_begin[g]); (void) hipEventCreate(&ev_ready[g]); (void) hipEventCreate(&ev_gate[g]); (void) hipEventCreate(&ev_copied[g]); }
+#endif
             for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
                 const int l = g % lanes, i0 = group_start[g], nb = group_start[g + 1] - i0;
+#if defined(KBE_VIDEO_GPU_TRACE)
+                (void) hipEventRecord(ev_begin[g], ls[l]);
+#endif
 #if defined(KBE_VIDEO_TRACE)
                 const double t_g = trace_now();
 #endif
@@ -1395,12 +1405,21 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #if defined(KBE_VIDEO_TRACE)     // dev build only (tools/handoff_trace.py): where does the host spend the call?
                 const double t_r = trace_now();
 #endif
+#if defined(KBE_VIDEO_GPU_TRACE)
+                (void) hipEventRecord(ev_ready[g], ls[l]);
+#endif
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls);
+#if defined(KBE_VIDEO_GPU_TRACE)
+                (void) hipEventRecord(ev_gate[g], ls[l]);
+#endif
 #if defined(KBE_VIDEO_TRACE)
                 const double t_t = trace_now();
 #endif
                 const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
+#if defined(KBE_VIDEO_GPU_TRACE)
+                (void) hipEventRecord(ev_copied[g], ls[l]);
+#endif
 #if defined(KBE_VIDEO_TRACE)
                 const double t_c = trace_now();
 #endif
@@ -1411,6 +1430,16 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                         (t_g - t_call) * 1e6, (t_r - t_g) * 1e6, (t_t - t_r) * 1e6, (t_c - t_t) * 1e6, (trace_now() - t_c) * 1e6);
 #endif
             }
+#if defined(KBE_VIDEO_GPU_TRACE)
+            for (int l = 0; l < lanes; l++) (void) hipStreamSynchronize(ls[l]);
+            for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
+                float b = 0, r = 0, o = 0, c = 0;
+                (void) hipEventElapsedTime(&b, ev_start, ev_begin[g]); (void) hipEventElapsedTime(&r, ev_start, ev_ready[g]);
+                (void) hipEventElapsedTime(&o, ev_start, ev_gate[g]); (void) hipEventElapsedTime(&c, ev_start, ev_copied[g]);
+                fprintf(stderr, "group %3d lane %d frames %3d..%3d: render %8.1f .. %8.1f us, gate open %8.1f, transfer ends %8.1f (%.1f GB/s from the gate)\n", g, g % lanes,
+                        group_start[g], group_start[g + 1] - 1, b * 1e3, r * 1e3, o * 1e3, c * 1e3, (double) (group_start[g + 1] - group_start[g]) * fb / ((c - o) * 1e6));
+            }
+#endif
         }
     } else {
         // staged ring: a half is copied to the host with ONE runtime transfer while the other half is being rendered;
