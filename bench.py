@@ -76,13 +76,14 @@ def build_scene(size, device, inpaint, settings=None, upsample=1):
     return oc
 
 
-def measured_traffic():
-    """Per-launch HBM bytes of the frame kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+def measured_traffic(workload=''):
+    """Per-frame HBM bytes of the frame kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, calibrated and corrected by tools/pmc_report.py as MI355X_MICROARCH.md
     prescribes).  PMC counters cannot be collected from inside this process, so the figures are read from the newest
-    profiles/r*_hbm_traffic.json; ({}, None) when there is none."""
+    profiles/r*_hbm_traffic.json (the default workload) or r*_hbm_traffic_config4.json (`workload` = '_config4': 2048^2 from
+    16.8 M points, tools/pmc_config4_report.py); ({}, None) when there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic%s.json' % workload)))
     if not files:
         return {}, None
     try:
@@ -657,9 +658,10 @@ def main():
         # (the fused route's tile launch also makes the next group's placements -- k_frame_ahead / k_frame_group_ahead -- unless KBE_AHEAD=0)
         ahead = os.environ.get('KBE_AHEAD') != '0' and 'fused:scatter_group_ahead' in kt and 'fused:scatter_ahead' in kt
         route_launches = {'fused': ['k_frame_ahead'] if ahead else ['k_place', 'k_frame'], 'bucket': ['k_project', 'k_tiles'], 'fused:two_launches': ['k_place', 'k_frame']}
-        # the committed PMC passes are of the default workload only
+        # the committed PMC passes are of the default workload and of configs[4] (2048^2 from 16.8 M points) only
         default_workload = size == 1024 and args.cloud == 'inpaint' and not args.dolly and args.upsample == 1
-        per_kernel, traffic_src = measured_traffic() if default_workload else ({}, None)
+        config4_workload = size == 2048 and args.upsample == 2 and not args.dolly
+        per_kernel, traffic_src = measured_traffic() if default_workload else (measured_traffic('_config4') if config4_workload else ({}, None))
         insts, insts_src = measured_instructions() if default_workload else ({}, None)
 
         def roof(r, frames):

@@ -55,6 +55,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   SIZE=2048 UPSAMPLE=2 CLOUD=raw KBE_LANES=1 FRAMES=16 REPS=1 timeout 400 rocprofv3 --pmc $c -d /tmp/pd_$c -o c --output-format csv -- python $R/tools/throughput.py > /tmp/pd.log 2>&1 || tail -3 /tmp/pd.log
   python $R/tools/pmc_by_grid.py /tmp/pd_$c/c_counter_collection.csv k_frame_group_ahead k_frame_group k_place k_project k_tiles 2>&1 | cut -c1-300
 done > $OUT/config4_traffic.txt
+python $R/tools/pmc_config4_report.py $OUT/config4_traffic.txt $OUT/hbm_traffic.json > $OUT/hbm_traffic_config4.json
 # 4. other workloads (device-only and delivered), both routes where it matters
 (
 for env in "SIZE=512" "CLOUD=raw" "DOLLY=1" "SIZE=2048 CLOUD=raw" "SIZE=2048 UPSAMPLE=2 CLOUD=raw"; do
