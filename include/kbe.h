@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 8
+#define KBE_ABI_VERSION 9
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -429,6 +429,22 @@ KBE_API int kbe_pconv_epilogue(const float* raw, const float* bias, const float*
    (utils/partial_conv.py:61).  x, out [B,C,H,W] (may alias); slope [C]; mask [B,1,H,W] or NULL (no multiplication). */
 KBE_API int kbe_prelu_mask(const float* x, const float* slope, const float* mask, int B, int C, int H, int W, float* out,
                            kbe_stream_t stream);
+
+/* The element-wise passes PyTorch runs around a convolution of the (plain) networks, in ONE pass over the convolution's output
+   (round 4; the blocks of models/pointcloud_inpainting.py:16-80, disparity_estimation.py, disparity_refinement.py of the reference:
+   `nn.Conv2d`'s bias add -- MIOpen's Winograd kernels take none --, the `nn.PReLU` behind it, `moduleMain(x) + skip`, and the
+   GridNet's `+ the stream from the neighbouring row`, :133-172):
+       out = act(x + bias[c]) + res1 + res2        act = PReLU with slope[c] or none
+   x, out, res1, res2 [B,C,H,W] (out may alias x); bias, slope [C]; bias, slope, res1, res2 may each be NULL.  The additions are
+   made in that order, as the separate passes make them.  B C <= 65535. */
+KBE_API int kbe_bias_act(const float* x, const float* bias, const float* slope, const float* res1, const float* res2, int B, int C,
+                         int H, int W, float* out, kbe_stream_t stream);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) and the nn.PReLU behind it, the head of an `Upsample` block
+   (models/pointcloud_inpainting.py:54-80), in one pass: x [B,C,H,W] -> out [B,C,2H,2W]; slope [C] or NULL (no activation).
+   Source positions and weights as PyTorch's upsample_bilinear2d computes them (0.5 (dst + 0.5) - 0.5 clamped at 0, the
+   neighbour clamped at the edge). */
+KBE_API int kbe_upsample2x_act(const float* x, const float* slope, int B, int C, int H, int W, float* out, kbe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,10 +21,10 @@ SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_selftest_division', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
-    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask',
+    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act',
 )
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
@@ -713,6 +713,26 @@ class HipKernels:
         out = torch.empty_like(x) if out is None else out
         self._check(self.lib.kbe_prelu_mask(_ptr(x), _ptr(_f32c(slope)), _ptr(None if mask is None else _f32c(mask)), _i(B), _i(C), _i(H), _i(W), _ptr(out),
                                             _stream()), 'kbe_prelu_mask')
+        return out
+
+    def bias_act(self, x, bias=None, slope=None, res1=None, res2=None, out=None):
+        """act(x + bias[c]) + res1 + res2 in one pass (kbe_bias_act): x [B,C,H,W] contiguous fp32; every other operand optional.
+        `out` may be `x` itself (a convolution's fresh output)."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        B, C, H, W = x.shape
+        out = torch.empty_like(x) if out is None else out
+        for r in (res1, res2):
+            assert r is None or (r.shape == x.shape and r.dtype == torch.float32 and r.is_contiguous())
+        self._check(self.lib.kbe_bias_act(_ptr(x), _ptr(None if bias is None else _f32c(bias)), _ptr(None if slope is None else _f32c(slope)), _ptr(res1), _ptr(res2),
+                                          _i(B), _i(C), _i(H), _i(W), _ptr(out), _stream()), 'kbe_bias_act')
+        return out
+
+    def upsample2x_act(self, x, slope=None):
+        """prelu(bilinear x2 upsampling of x, align_corners=False) in one pass (kbe_upsample2x_act); slope [C] or None."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+        self._check(self.lib.kbe_upsample2x_act(_ptr(x), _ptr(None if slope is None else _f32c(slope)), _i(B), _i(C), _i(H), _i(W), _ptr(out), _stream()), 'kbe_upsample2x_act')
         return out
 
     def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None, act_slope=None, residual=None):

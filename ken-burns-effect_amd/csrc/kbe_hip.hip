@@ -635,6 +635,75 @@ __global__ void __launch_bounds__(kBlock) k_prelu_mask(const float* __restrict__
     }
 }
 
+// What PyTorch runs around a convolution of the networks as separate element-wise passes -- the bias add (MIOpen's Winograd kernels
+// take none), the PReLU that follows, the block's `+ skip` and the grid's `+ the stream from the neighbouring row`
+// (models/pointcloud_inpainting.py:16-52, :133-172 of the reference) -- in ONE pass over the convolution's output:
+//   out = act(x + bias[c]) + res1 + res2      act = PReLU with slope[c], or none; bias, slope, res1, res2 may each be NULL.
+// x, out, res1, res2 [B,C,HW] (out may alias x); four pixels per thread when HW is a multiple of four.  The additions are in
+// the order the separate passes make them ((x + bias) first, then the residuals left to right).
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) k_bias_act(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ slope,
+                                                     const float* __restrict__ res1, const float* __restrict__ res2, size_t HW, int C, float* __restrict__ out)
+{
+    const int bc = blockIdx.y;
+    const int c = bc % C;
+    const float b = bias ? bias[c] : 0.0f, sl = slope ? slope[c] : 0.0f;
+    const size_t base = (size_t) bc * HW;
+    auto one = [&](float v, float r1, float r2) {
+        if (bias) v = v + b;
+        if (slope) v = v > 0.0f ? v : sl * v;
+        if (res1) v = v + r1;
+        if (res2) v = v + r2;
+        return v;
+    };
+    if (VEC) {
+        const size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        if (i >= HW) return;
+        const float4 v = *(const float4*) (x + base + i);
+        const float4 r1 = res1 ? *(const float4*) (res1 + base + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 r2 = res2 ? *(const float4*) (res2 + base + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *(float4*) (out + base + i) = make_float4(one(v.x, r1.x, r2.x), one(v.y, r1.y, r2.y), one(v.z, r1.z, r2.z), one(v.w, r1.w, r2.w));
+    } else {
+        const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= HW) return;
+        out[base + i] = one(x[base + i], res1 ? res1[base + i] : 0.0f, res2 ? res2[base + i] : 0.0f);
+    }
+}
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) and the PReLU behind it (the head of an `Upsample` block,
+// models/pointcloud_inpainting.py:54-80) in one pass: x [BC,H,W] -> out [BC,2H,2W].  The source position and the weights as
+// PyTorch's upsample_bilinear2d computes them (source = 0.5 (dst + 0.5) - 0.5, clamped at 0; the neighbour clamped at the edge;
+// h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11)); two output pixels of a row per thread.
+__global__ void __launch_bounds__(kBlock) k_upsample2x_act(const float* __restrict__ x, const float* __restrict__ slope, int C, int H, int W, float* __restrict__ out)
+{
+    const int bc = blockIdx.z, y2 = blockIdx.y;
+    const int xs = blockIdx.x * blockDim.x + threadIdx.x;       // source column: output columns 2 xs, 2 xs + 1
+    if (xs >= W) return;
+    const float hr = fmaxf(0.5f * ((float) y2 + 0.5f) - 0.5f, 0.0f);
+    const int h1 = (int) hr, hp = h1 < H - 1 ? 1 : 0;
+    const float hl1 = hr - (float) h1, hl0 = 1.0f - hl1;
+    const float* r0 = x + ((size_t) bc * H + h1) * W;
+    const float* r1 = r0 + (size_t) hp * W;
+    const int xm = xs > 0 ? xs - 1 : 0, xp = xs < W - 1 ? xs + 1 : xs;
+    const float a0 = r0[xm], a1 = r0[xs], a2 = r0[xp], b0 = r1[xm], b1 = r1[xs], b2 = r1[xp];
+    const float sl = slope ? slope[bc % C] : 0.0f;
+    float o[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int w2 = 2 * xs + k;
+        const float wr = fmaxf(0.5f * ((float) w2 + 0.5f) - 0.5f, 0.0f);
+        const int w1 = (int) wr;
+        const float wl1 = wr - (float) w1, wl0 = 1.0f - wl1;
+        // w1 is xs - 1 (k = 0, xs > 0) or xs; its neighbour w1 + 1 clamped at W - 1
+        const bool left = w1 < xs;
+        const float v00 = left ? a0 : a1, v01 = left ? a1 : a2, v10 = left ? b0 : b1, v11 = left ? b1 : b2;
+        float v = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
+        if (slope) v = v > 0.0f ? v : sl * v;
+        o[k] = v;
+    }
+    *(float2*) (out + ((size_t) bc * 2 * H + y2) * 2 * W + 2 * xs) = make_float2(o[0], o[1]);
+}
+
 }  // namespace
 
 // =======================================================================================
@@ -889,6 +958,24 @@ int kbe_prelu_mask(const float* x, const float* slope, const float* mask, int B,
     KBE_REQUIRE(x && slope && out && B > 0 && C > 0 && H > 0 && W > 0, "kbe_prelu_mask: bad arguments");
     hipLaunchKernelGGL(k_prelu_mask, dim3(blocks_for((size_t) H * W), B), dim3(kBlock), 0, (hipStream_t) stream, x, slope, mask, C, (size_t) H * W, out);
     return launched("kbe_prelu_mask");
+}
+
+int kbe_bias_act(const float* x, const float* bias, const float* slope, const float* res1, const float* res2, int B, int C, int H, int W, float* out,
+                 kbe_stream_t stream)
+{
+    KBE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && (size_t) B * C <= 65535, "kbe_bias_act: bad arguments");
+    const size_t HW = (size_t) H * W;
+    const bool vec = HW % 4 == 0 && (((uintptr_t) x | (uintptr_t) out | (uintptr_t) res1 | (uintptr_t) res2) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_bias_act<true>, dim3(blocks_for(HW / 4), B * C), dim3(kBlock), 0, (hipStream_t) stream, x, bias, slope, res1, res2, HW, C, out);
+    else hipLaunchKernelGGL(k_bias_act<false>, dim3(blocks_for(HW), B * C), dim3(kBlock), 0, (hipStream_t) stream, x, bias, slope, res1, res2, HW, C, out);
+    return launched("kbe_bias_act");
+}
+
+int kbe_upsample2x_act(const float* x, const float* slope, int B, int C, int H, int W, float* out, kbe_stream_t stream)
+{
+    KBE_REQUIRE(x && out && x != out && B > 0 && C > 0 && H > 0 && W > 0 && (size_t) B * C <= 65535 && 2 * H <= 65535, "kbe_upsample2x_act: bad arguments");
+    hipLaunchKernelGGL(k_upsample2x_act, dim3(blocks_for((size_t) W), 2 * H, B * C), dim3(kBlock), 0, (hipStream_t) stream, x, slope, C, H, W, out);
+    return launched("kbe_upsample2x_act");
 }
 
 }  // extern "C"

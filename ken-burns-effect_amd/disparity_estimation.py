@@ -81,8 +81,8 @@ class Disparity(nn.Module):
                 self.add_module(_edge(row, col, row - 1, col), Upsample([hi, lo, lo]))
         self.moduleDisparity = Basic('conv-relu-conv', [ROW_FEATURES[0], ROW_FEATURES[0], 1])
 
-    def _run(self, r0, c0, r1, c1, x):
-        return self._modules[_edge(r0, c0, r1, c1)](x)
+    def _run(self, r0, c0, r1, c1, x, extra=None):
+        return self._modules[_edge(r0, c0, r1, c1)](x, extra)
 
     def forward(self, tensorImage, tensorSemantics):
         """image [B,3,H,W], semantics [B,512,H/16,W/16] -> disparity [B,1,H/2,W/2]"""
@@ -95,11 +95,11 @@ class Disparity(nn.Module):
             level.append(nxt)
         for r in range(rows):
             lateral = self._run(r, 0, r, 1, level[r])
-            level[r] = lateral if r == 0 else lateral + self._run(r - 1, 1, r, 1, level[r - 1])
+            level[r] = lateral if r == 0 else self._run(r - 1, 1, r, 1, level[r - 1], extra=lateral)       # lateral + the stream from above
         for col in (2, 3):
             for r in range(rows - 1, -1, -1):
                 lateral = self._run(r, col - 1, r, col, level[r])
                 if r != rows - 1:
-                    lateral = lateral + _match(self._run(r + 1, col, r, col, level[r + 1]), lateral)
+                    lateral = self._run(r + 1, col, r, col, level[r + 1], extra=lateral)       # lateral + _match(the stream from below, lateral)
                 level[r] = lateral
         return self.moduleDisparity(level[0])

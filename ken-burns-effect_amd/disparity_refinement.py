@@ -10,7 +10,7 @@ runs once per image; H and W must be multiples of 4 (``kbe.py:108-114`` crops fo
 import torch
 import torch.nn as nn
 
-from .pointcloud_inpainting import Basic as _ResidualBasic, Downsample, Upsample, _act, _conv3
+from .pointcloud_inpainting import Basic as _ResidualBasic, Downsample, Upsample, _act, _conv3, _fused_layers, _main_fused
 
 
 class _PlainBasic(nn.Module):
@@ -25,7 +25,8 @@ class _PlainBasic(nn.Module):
         self.moduleMain = nn.Sequential(*layers)
 
     def forward(self, tensorInput):
-        return self.moduleMain(tensorInput)
+        K = _fused_layers(tensorInput)
+        return self.moduleMain(tensorInput) if K is None else _main_fused(K, self.moduleMain, tensorInput)
 
 
 def _standardise(t):

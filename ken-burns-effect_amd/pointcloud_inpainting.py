@@ -15,6 +15,7 @@ The network is a 4-row x 4-column GridNet: rows carry 32/64/128/256 features at 
 1/4, 1/8 resolution; columns 0-1 stream downwards, columns 2-3 stream upwards.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -34,6 +35,45 @@ def _act(channels):
     return nn.PReLU(num_parameters=channels, init=0.25)
 
 
+def _fused_layers(x):
+    """The kernel set when the element-wise passes around this block's convolutions can ride in fused HIP passes (kbe_bias_act,
+    kbe_upsample2x_act; include/kbe.h), else None: inference in fp32 on the GPU only -- under autograd, autocast or on the CPU the
+    blocks run as the stock modules they are made of.  ``KBE_FUSED_LAYERS=0`` turns it off (measurements, the parity test)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or torch.is_grad_enabled() or torch.is_autocast_enabled():
+        return None
+    if os.environ.get('KBE_FUSED_LAYERS', '1') == '0':
+        return None
+    K = common._K()
+    return K if hasattr(K, 'bias_act') else None
+
+
+def _conv_act(K, conv, act, x, res1=None, res2=None):
+    """act(conv(x)) + res1 + res2 with the bias add, the activation and the residuals in ONE pass over the convolution's output
+    (MIOpen's Winograd kernels take no bias: PyTorch adds it -- and everything behind it -- in passes of their own)."""
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return K.bias_act(y, conv.bias, None if act is None else act.weight, res1, res2, out=y)
+
+
+def _main_fused(K, seq, x, res1=None, res2=None):
+    """A block's ``moduleMain`` -- [bilinear x2] [act] conv act conv -- then ``+ res1 + res2``: three or four passes besides the
+    convolutions instead of five to eight.  A ``res2`` of another size (the stream from an odd-sized row below) is added behind
+    the crop, as before."""
+    mods = list(seq)
+    x = x.contiguous()
+    if isinstance(mods[0], nn.Upsample):
+        x = K.upsample2x_act(x, mods[1].weight)
+        mods = mods[2:]
+    elif isinstance(mods[0], nn.PReLU):
+        x = K.bias_act(x, None, mods[0].weight)
+        mods = mods[1:]
+    conv1, act, conv2 = mods
+    y = _conv_act(K, conv1, act, x)
+    if res2 is not None and res2.shape[2:] != (
+            (y.size(2) + 2 * conv2.padding[0] - conv2.kernel_size[0]) // conv2.stride[0] + 1, (y.size(3) + 2 * conv2.padding[1] - conv2.kernel_size[1]) // conv2.stride[1] + 1):
+        return res2 + _match(_conv_act(K, conv2, None, y, res1), res2)
+    return _conv_act(K, conv2, None, y, res1, res2)
+
+
 class Basic(nn.Module):
     """Residual pair of 3x3 convolutions; ``strType`` picks whether an activation comes first.
     A 1x1 ``moduleShortcut`` exists only when input and output widths differ."""
@@ -49,9 +89,14 @@ class Basic(nn.Module):
         self.moduleMain = nn.Sequential(*layers)
         self.moduleShortcut = None if cin == cout else nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0)
 
-    def forward(self, tensorInput):
+    def forward(self, tensorInput, extra=None):
+        """``extra``: what the caller would add to the result (the GridNet's stream from the neighbouring row)."""
         skip = tensorInput if self.moduleShortcut is None else self.moduleShortcut(tensorInput)
-        return self.moduleMain(tensorInput) + skip
+        K = _fused_layers(tensorInput)
+        if K is not None:
+            return _main_fused(K, self.moduleMain, tensorInput, skip.contiguous(), extra)
+        out = self.moduleMain(tensorInput) + skip
+        return out if extra is None else extra + out
 
 
 class Downsample(nn.Module):
@@ -62,8 +107,12 @@ class Downsample(nn.Module):
         cin, cmid, cout = intChannels
         self.moduleMain = nn.Sequential(_act(cin), _conv3(cin, cmid, stride=2), _act(cmid), _conv3(cmid, cout))
 
-    def forward(self, tensorInput):
-        return self.moduleMain(tensorInput)
+    def forward(self, tensorInput, extra=None):
+        K = _fused_layers(tensorInput)
+        if K is not None:
+            return _main_fused(K, self.moduleMain, tensorInput, None, extra)
+        out = self.moduleMain(tensorInput)
+        return out if extra is None else extra + out
 
 
 class Upsample(nn.Module):
@@ -75,8 +124,13 @@ class Upsample(nn.Module):
         self.moduleMain = nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False),
                                         _act(cin), _conv3(cin, cmid), _act(cmid), _conv3(cmid, cout))
 
-    def forward(self, tensorInput):
-        return self.moduleMain(tensorInput)
+    def forward(self, tensorInput, extra=None):
+        """``extra`` (the lateral stream of the row above): added to the result, which is cropped to its size first (_match)."""
+        K = _fused_layers(tensorInput)
+        if K is not None:
+            return _main_fused(K, self.moduleMain, tensorInput, None, extra)
+        out = self.moduleMain(tensorInput)
+        return out if extra is None else extra + _match(out, extra)
 
 
 def _edge(r0, c0, r1, c1):
@@ -122,8 +176,16 @@ class Inpaint(nn.Module):
         self.moduleImage = Basic('conv-relu-conv', [ROW_FEATURES[0], ROW_FEATURES[0], 3])
         self.moduleDisparity = Basic('conv-relu-conv', [ROW_FEATURES[0], ROW_FEATURES[0], 1])
 
-    def _run(self, r0, c0, r1, c1, x):
-        return self._modules[_edge(r0, c0, r1, c1)](x)
+    def _run(self, r0, c0, r1, c1, x, extra=None):
+        return self._modules[_edge(r0, c0, r1, c1)](x, extra)
+
+    def _context(self, x):
+        """``moduleContext`` (conv - act - conv - act), each convolution's bias add and activation in one pass where they can be."""
+        K = _fused_layers(x)
+        if K is None:
+            return self.moduleContext(x)
+        c = self.moduleContext
+        return _conv_act(K, c[2], c[3], _conv_act(K, c[0], c[1], x.contiguous()))
 
     def _grid(self, tensorFirst):
         """The GridNet body (pointcloud_inpainting.py:133-172): returns the top-row features of the last column."""
@@ -133,12 +195,12 @@ class Inpaint(nn.Module):
             level.append(self._run(r - 1, 0, r, 0, level[r - 1]))
         for r in range(rows):                                       # column 1: lateral, plus the stream from above
             lateral = self._run(r, 0, r, 1, level[r])
-            level[r] = lateral if r == 0 else lateral + self._run(r - 1, 1, r, 1, level[r - 1])
+            level[r] = lateral if r == 0 else self._run(r - 1, 1, r, 1, level[r - 1], extra=lateral)       # lateral + the stream from above
         for col in (2, 3):                                          # columns 2, 3: lateral, plus the stream from below
             for r in range(rows - 1, -1, -1):
                 lateral = self._run(r, col - 1, r, col, level[r])
                 if r != rows - 1:
-                    lateral = lateral + _match(self._run(r + 1, col, r, col, level[r + 1]), lateral)
+                    lateral = self._run(r + 1, col, r, col, level[r + 1], extra=lateral)       # lateral + _match(the stream from below, lateral)
                 level[r] = lateral
         return level[0]
 
@@ -150,7 +212,7 @@ class Inpaint(nn.Module):
             tensorImage, tensorDisparity = self.normalize_images_disp(tensorImage, tensorDisparity, not_normed=True)
         if tensorData is None:
             if tensorContext is None:
-                tensorContext = self.moduleContext(torch.cat([tensorImage, tensorDisparity], 1))
+                tensorContext = self._context(torch.cat([tensorImage, tensorDisparity], 1))
             tensorData = torch.cat([tensorImage, tensorDisparity, tensorContext], 1)
 
         fast = self.compute_dtype is not None and tensorMasks.is_cuda and not self.training
@@ -178,7 +240,7 @@ class Inpaint(nn.Module):
         tensorPoints = K.depth_to_points(tensorDepth, dblFocal, valid=tensorValid).view(1, 3, -1)
 
         tensorImage, tensorDisparity = self.normalize_images_disp(tensorImage, tensorDisparity, not_normed=True)
-        tensorContext = self.moduleContext(torch.cat([tensorImage, tensorDisparity], 1))
+        tensorContext = self._context(torch.cat([tensorImage, tensorDisparity], 1))
         features = torch.cat([tensorImage, tensorDisparity, tensorContext], 1).view(1, 68, -1)
 
         tensorRender, tensorExisting = K.render_pointcloud(tensorPoints + tensorShift, features, width, height, dblFocal,

@@ -242,6 +242,40 @@ def test_pconv_epilogue_with_its_neighbours_fused_and_prelu_mask(K):
         assert_bits_equal(c(K.prelu_mask(x.cuda(), sl_in, None)), c(torch.nn.functional.prelu(x.cuda(), sl_in)), 'prelu alone')
 
 
+def test_bias_act_and_upsample_act_against_the_separate_torch_passes(K):
+    """kbe_bias_act: the bias add, the PReLU and up to two residual adds behind a convolution of the plain networks in one pass --
+    against the same steps as separate torch operations, bit for bit (each is one fp32 operation per element either way), with
+    every combination of operands, a pixel count that is a multiple of four (vector path) and one that is not.
+    kbe_upsample2x_act: bilinear x2 (align_corners=False) + PReLU against F.interpolate + F.prelu: PyTorch's kernel is built with
+    contraction to fused multiply-adds, this one is not -- a few units in the last place of the blend; odd sizes and one-pixel
+    borders included."""
+    F = torch.nn.functional
+    gen = torch.Generator().manual_seed(17)
+    for (B, C, H, W) in [(1, 5, 12, 20), (2, 3, 7, 9), (1, 64, 33, 47), (1, 1, 1, 1)]:
+        x = torch.randn(B, C, H, W, generator=gen).cuda()
+        bias, slope = torch.randn(C, generator=gen).cuda(), (torch.rand(C, generator=gen) * 0.5 - 0.1).cuda()
+        r1, r2 = torch.randn(B, C, H, W, generator=gen).cuda(), torch.randn(B, C, H, W, generator=gen).cuda()
+        for use_b in (False, True):
+            for use_s in (False, True):
+                for n_res in (0, 1, 2):
+                    want = x + bias.view(1, -1, 1, 1) if use_b else x
+                    want = F.prelu(want, slope) if use_s else want
+                    want = want + r1 if n_res >= 1 else want
+                    want = want + r2 if n_res >= 2 else want
+                    got = K.bias_act(x, bias if use_b else None, slope if use_s else None, r1 if n_res >= 1 else None, r2 if n_res >= 2 else None)
+                    assert_bits_equal(c(got), c(want), 'bias_act %s bias=%s slope=%s residuals=%d' % ((B, C, H, W), use_b, use_s, n_res))
+        y = x.clone()
+        assert K.bias_act(y, bias, slope, r1, out=y).data_ptr() == y.data_ptr()
+        assert_bits_equal(c(y), c(F.prelu(x + bias.view(1, -1, 1, 1), slope) + r1), 'bias_act in place')
+        for sl in (slope, None):
+            up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+            want = F.prelu(up, sl) if sl is not None else up
+            got = K.upsample2x_act(x, sl)
+            assert got.shape == (B, C, 2 * H, 2 * W)
+            err = float((got - want).abs().max())
+            assert err <= 4e-7 * max(1.0, float(x.abs().max())), 'upsample2x_act %s: %.3g' % ((B, C, H, W), err)
+
+
 def test_crop_resize_matches_written_algorithm(K, oracle):
     rng = np.random.default_rng(5)
     # even / odd crops (sub-pixel 0.5 and 0), the full frame (replicated border taps), widths that are not a

@@ -380,6 +380,51 @@ def test_disparity_and_refine_networks_on_miopen_match_reference():
         assert_bits_equal(c(coarse), z['coarse'], 'inputs untouched')
 
 
+def test_networks_with_their_element_wise_passes_fused_against_the_stock_modules(monkeypatch):
+    """The plain networks' blocks run their bias adds, activations, residual adds and x2 upsamplings in fused HIP passes
+    (pointcloud_inpainting._main_fused; the tests above put that path against the reference's fixtures).  Here the same networks
+    with KBE_FUSED_LAYERS=0 -- the stock nn.Sequential modules -- on the same inputs, at sizes whose rows are odd further down
+    the grid (the cropped stream from below): the outputs must agree to the last few bits of the upsampling's blend."""
+    from ken_burns_effect_amd import synthetic
+    from ken_burns_effect_amd.disparity_estimation import Disparity
+    from ken_burns_effect_amd.disparity_refinement import Refine, RefinePretrained
+    from ken_burns_effect_amd.pointcloud_inpainting import Inpaint
+    gen = torch.Generator().manual_seed(5)
+
+    def both(fn):
+        with torch.no_grad():
+            monkeypatch.setenv('KBE_FUSED_LAYERS', '1')
+            fused = fn()
+            monkeypatch.setenv('KBE_FUSED_LAYERS', '0')
+            stock = fn()
+        monkeypatch.delenv('KBE_FUSED_LAYERS')
+        return fused, stock
+
+    for (H, W) in [(96, 128), (100, 140)]:                      # 100 x 140: rows of 50 x 70, 25 x 35, 13 x 18 in the Inpaint grid
+        inp = synthetic.seeded_fill_(Inpaint().eval(), 3).cuda()
+        image, disp = torch.rand(1, 3, H, W, generator=gen).cuda(), (torch.rand(1, 1, H, W, generator=gen) * 50 + 5).cuda()
+        mask = (torch.rand(1, 1, H, W, generator=gen) > 0.2).float().cuda()
+        fused, stock = both(lambda: inp(tensorMasks=mask, tensorImage=image, tensorDisparity=disp))
+        for key in ('tensorImage', 'tensorDisparity'):
+            err, scale = float((fused[key] - stock[key]).abs().max()), max(1.0, float(stock[key].abs().max()))
+            print('Inpaint %dx%d %s: fused against stock %.3g (scale %.3g)' % (H, W, key, err, scale))
+            assert err <= 1e-5 * scale
+    for (H, W) in [(64, 96), (72, 104)]:
+        dnet = synthetic.seeded_fill_(Disparity().eval(), 11).cuda()
+        image, sem = torch.rand(1, 3, H, W, generator=gen).cuda(), torch.rand(1, 512, (H + 15) // 16, (W + 15) // 16, generator=gen).cuda()
+        fused, stock = both(lambda: dnet(image, sem))
+        err, scale = float((fused - stock).abs().max()), max(1.0, float(stock.abs().max()))
+        print('Disparity %dx%d: fused against stock %.3g (scale %.3g)' % (H, W, err, scale))
+        assert fused.shape == stock.shape and err <= 1e-5 * scale
+        for cls in (Refine, RefinePretrained):
+            rnet = synthetic.seeded_fill_(cls().eval(), 13).cuda()
+            coarse = torch.rand(1, 1, H // 4, W // 4, generator=gen).cuda() * 30
+            fused, stock = both(lambda: rnet(image, coarse))
+            err, scale = float((fused - stock).abs().max()), max(1.0, float(stock.abs().max()))
+            print('%s %dx%d: fused against stock %.3g (scale %.3g)' % (cls.__name__, H, W, err, scale))
+            assert err <= 1e-5 * scale
+
+
 # ---------------------------------------------------------------------------------------
 # a15 / f2: Pipeline at BASELINE configs[1] (512 x 512, 64 frames, seeded weights)
 # ---------------------------------------------------------------------------------------
