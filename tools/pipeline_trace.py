@@ -21,7 +21,7 @@ if len(sys.argv) > 1:
         calls[name] += 1
 
     def kind(n):
-        if n.startswith('(anonymous namespace)::k_') or 'kbe::' in n:
+        if '(anonymous namespace)::k_' in n[:40] or 'kbe::' in n:
             return 'this library'
         if 'copyBuffer' in n or 'fillBuffer' in n:
             return 'runtime copies / fills'
@@ -35,7 +35,8 @@ if len(sys.argv) > 1:
     print('GPU time per call: %.2f ms in %d launches (sum of kernel durations; kernels of different streams overlap)' % (total / 1e3, sum(calls.values()) // CALLS))
     for k, t in sorted(kinds.items(), key=lambda kv: -kv[1]):
         print('  %6.2f ms  %4.1f %%  %s' % (t / 1e3, 100 * t / total, k))
-    for n, t in sorted(per.items(), key=lambda kv: -kv[1])[:40]:
+    only = os.environ.get('KIND')                # e.g. KIND=PyTorch: the launches of that kind only
+    for n, t in sorted(((n, t) for n, t in per.items() if not only or kind(n).startswith(only)), key=lambda kv: -kv[1])[:int(os.environ.get('TOP', '40'))]:
         print('%8.1f us  %5d launches per call  avg %7.1f us  %s' % (t, calls[n] // CALLS, t * CALLS / calls[n], n[:150]))
     sys.exit(0)
 
