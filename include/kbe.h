@@ -420,10 +420,14 @@ KBE_API int kbe_laplacian_valid(const float* in, const float* scale_dev, int pla
    What follows a layer inside the partial-convolution GridNet's blocks (models/partial_inpainting.py:16-52) can ride in the
    same pass (round 4; both optional, NULL = as before): residual [B,Cout,Ho,Wo] -- out += residual, the block's `+ skip` --
    and then prelu_slope [Cout] -- out = prelu(out), the next layer's activation, whose `input * mask_in` needs no pass of its
-   own because out is already 0 wherever um, the next layer's mask, is 0. */
+   own because out is already 0 wherever um, the next layer's mask, is 0.
+   raw_without_bias != 0: `raw` is the convolution WITHOUT its bias (MIOpen's Winograd kernels take none: PyTorch adds it in a
+   broadcasting pass of its own, 21 us per layer at 1024^2) and the epilogue forms raw + bias first, with the rounding that
+   pass would have made -- the same values, one pass less. */
 KBE_API int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int mask_channels, int B,
                                int Cin, int H, int W, int Cout, int Ho, int Wo, int k, int stride, int pad,
-                               float* out, float* um, const float* prelu_slope, const float* residual, kbe_stream_t stream);
+                               float* out, float* um, const float* prelu_slope, const float* residual, int raw_without_bias,
+                               kbe_stream_t stream);
 
 /* out = prelu(x, slope) * mask in one pass: a block's first activation and the `input * mask_in` of PartialConv2d.forward
    (utils/partial_conv.py:61).  x, out [B,C,H,W] (may alias); slope [C]; mask [B,1,H,W] or NULL (no multiplication). */

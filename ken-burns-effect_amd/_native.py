@@ -735,9 +735,13 @@ class HipKernels:
         self._check(self.lib.kbe_upsample2x_act(_ptr(x), _ptr(None if slope is None else _f32c(slope)), _i(B), _i(C), _i(H), _i(W), _ptr(out), _stream()), 'kbe_upsample2x_act')
         return out
 
-    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None, act_slope=None, residual=None):
+    pconv_epilogue_adds_bias = True         # (PartialConv2d.forward: run the convolution without its bias)
+
+    def pconv_epilogue(self, raw, bias, mask, kernel_size, stride, padding, in_channels=None, in_size=None, act_slope=None, residual=None,
+                       raw_without_bias=False):
         """raw [B,Cout,Ho,Wo] = conv(x * mask); mask [B,Cin|1,H,W] or None (then in_channels/in_size say what x was).
-        act_slope [Cout] / residual [B,Cout,Ho,Wo] (optional): out = prelu(out + residual) in the same pass (include/kbe.h)."""
+        act_slope [Cout] / residual [B,Cout,Ho,Wo] (optional): out = prelu(out + residual) in the same pass (include/kbe.h).
+        raw_without_bias: the convolution was run without its bias; the epilogue adds it first (same values, one pass less)."""
         raw = _f32c(raw)
         B, Cout, Ho, Wo = raw.shape
         if mask is not None:
@@ -754,7 +758,8 @@ class HipKernels:
         self._check(self.lib.kbe_pconv_epilogue(_ptr(raw), _ptr(None if bias is None else _f32c(bias)), _ptr(mask), _i(Cm), _i(B),
                                                 _i(Cin), _i(H), _i(W), _i(Cout), _i(Ho), _i(Wo), _i(int(kernel_size)),
                                                 _i(int(stride)), _i(int(padding)), _ptr(out), _ptr(um),
-                                                _ptr(None if act_slope is None else _f32c(act_slope)), _ptr(residual), _stream()),
+                                                _ptr(None if act_slope is None else _f32c(act_slope)), _ptr(residual),
+                                                _i(1 if raw_without_bias and bias is not None else 0), _stream()),
                     'kbe_pconv_epilogue')
         return out, um
 

@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restri
                                                            const float* __restrict__ mask, int Cm, int Cin, int H, int W, int Cout,
                                                            int Ho, int Wo, int k, int stride, int pad,
                                                            float* __restrict__ out, float* __restrict__ um_out,
-                                                           const float* __restrict__ slope, const float* __restrict__ residual)
+                                                           const float* __restrict__ slope, const float* __restrict__ residual, int add_bias)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -607,7 +607,10 @@ __global__ void __launch_bounds__(kBlock) k_pconv_epilogue(const float* __restri
         float v;
         if (bias) {
             const float bv = bias[co];
-            v = ((r - bv) * ratio + bv) * um;
+            // (add_bias: the convolution ran WITHOUT its bias -- MIOpen's Winograd kernels take none, PyTorch would add it in a
+            // pass of its own -- and the sum the reference's formula starts from, rounding included, is formed here)
+            const float rb = add_bias ? r + bv : r;
+            v = ((rb - bv) * ratio + bv) * um;
         } else {
             v = r * ratio;
         }
@@ -943,13 +946,13 @@ int kbe_laplacian_valid(const float* in, const float* scale_dev, int planes, int
 
 int kbe_pconv_epilogue(const float* raw, const float* bias, const float* mask, int mask_channels, int B, int Cin, int H, int W,
                        int Cout, int Ho, int Wo, int k, int stride, int pad, float* out, float* um, const float* prelu_slope,
-                       const float* residual, kbe_stream_t stream)
+                       const float* residual, int raw_without_bias, kbe_stream_t stream)
 {
     KBE_REQUIRE(raw && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k > 0 && stride > 0 && pad >= 0,
                 "kbe_pconv_epilogue: bad arguments");
     KBE_REQUIRE(!mask || mask_channels == 1 || mask_channels == Cin, "kbe_pconv_epilogue: mask must have 1 or Cin channels");
     hipLaunchKernelGGL(k_pconv_epilogue, dim3(blocks_for((size_t) Ho * Wo), B), dim3(kBlock), 0, (hipStream_t) stream, raw,
-                       bias, mask, mask_channels, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um, prelu_slope, residual);
+                       bias, mask, mask_channels, Cin, H, W, Cout, Ho, Wo, k, stride, pad, out, um, prelu_slope, residual, raw_without_bias);
     return launched("kbe_pconv_epilogue");
 }
 

@@ -45,7 +45,11 @@ class PartialConv2d(nn.Conv2d):
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
             raise NotImplementedError('the fused partial convolution is inference-only: call it under torch.no_grad()')
         fresh = mask_in is not None or self.last_size != tuple(input.shape)
-        raw = F.conv2d(input * mask_in if mask_in is not None and not premasked else input, self.weight, self.bias, self.stride, self.padding)
+        # (the convolution without its bias where the epilogue can add it: MIOpen's Winograd kernels take none and PyTorch would
+        # add it in a pass of its own)
+        K = common._K()
+        late_bias = self.bias is not None and getattr(K, 'pconv_epilogue_adds_bias', False)
+        raw = F.conv2d(input * mask_in if mask_in is not None and not premasked else input, self.weight, None if late_bias else self.bias, self.stride, self.padding)
         if fresh:
             self.last_size = tuple(input.shape)
             self._mask = mask_in
@@ -54,7 +58,9 @@ class PartialConv2d(nn.Conv2d):
             raise ValueError('single-channel PartialConv2d wants a [*,1,H,W] mask')
         cin = self.in_channels if self.multi_channel else 1
         extra = {} if act_slope is None and residual is None else dict(act_slope=act_slope, residual=residual)
-        output, um = common._K().pconv_epilogue(raw, self.bias, mask, self.kernel_size[0], self.stride[0], self.padding[0],
+        if late_bias:
+            extra['raw_without_bias'] = True
+        output, um = K.pconv_epilogue(raw, self.bias, mask, self.kernel_size[0], self.stride[0], self.padding[0],
                                                 in_channels=cin, in_size=tuple(input.shape[2:]), **extra)
         self.update_mask = um
         if self.return_mask:

@@ -101,7 +101,11 @@ class Upsample(_Pair):
 
     def forward(self, tensorInput, mask_in=None):
         mask = (self.upsample(mask_in) > 0.5).float()
-        return self._pair(self.upsample(tensorInput), mask)
+        # (the feature maps' x2 bilinear upsampling through kbe_upsample2x_act where the fused passes are in use: PyTorch's
+        # upsample_bilinear2d runs at a quarter of the memory's rate)
+        K = common._K() if (tensorInput.is_cuda and tensorInput.dtype == torch.float32 and self._fused()) else None
+        up = K.upsample2x_act(tensorInput.contiguous()) if K is not None and hasattr(K, 'upsample2x_act') else self.upsample(tensorInput)
+        return self._pair(up, mask)
 
 
 def _crop_like(x, like, value=None):

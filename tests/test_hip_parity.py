@@ -235,6 +235,12 @@ def test_pconv_epilogue_with_its_neighbours_fused_and_prelu_mask(K):
         assert_bits_equal(c(added), c(plain + res), 'epilogue + residual')
         both, _ = K.pconv_epilogue(raw, bias, m.cuda(), k, s, p, act_slope=slope, residual=res)
         assert_bits_equal(c(both), c(torch.nn.functional.prelu(plain + res, slope)), 'epilogue + residual + PReLU')
+        # the convolution run without its bias, the epilogue adding it first: what the separate broadcasting add would have made
+        raw_nb = torch.nn.functional.conv2d(x * m, torch.from_numpy(z['w_' + tag]), None, stride=s, padding=p).cuda()
+        late, um3 = K.pconv_epilogue(raw_nb, bias, m.cuda(), k, s, p, act_slope=slope, residual=res, raw_without_bias=True)
+        early, _ = K.pconv_epilogue(raw_nb + bias.view(1, -1, 1, 1), bias, m.cuda(), k, s, p, act_slope=slope, residual=res)
+        assert torch.equal(um, um3)
+        assert_bits_equal(c(late), c(early), 'epilogue adding the bias itself')
         # the block's first activation and the mask multiplication: masks of one channel (how the GridNet carries them)
         sl_in = (torch.rand(cin, generator=gen) * 0.5 - 0.1).cuda()
         m1 = m[:, :1].contiguous().cuda()
