@@ -332,6 +332,7 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
         net.normalize_images_disp(image.cuda(), disp.cuda(), not_normed=True)
         fused = net(tensorData=data, tensorMasks=mask)
         fused = {k: v.clone() for k, v in fused.items() if torch.is_tensor(v)}
+        fused_again = {k: v.clone() for k, v in net(tensorData=data, tensorMasks=mask).items() if torch.is_tensor(v)}
         fused_forward = partial_conv.PartialConv2d.forward
         partial_conv.PartialConv2d.forward = bench.partial_conv_reference_forward
         for m in net.modules():
@@ -340,7 +341,8 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
         try:
             ref = net(tensorData=data, tensorMasks=mask)
             ref = {k: v.clone() for k, v in ref.items() if torch.is_tensor(v)}
-            again = net(tensorData=data, tensorMasks=mask)          # the same formulation once more: what MIOpen's own run-to-run noise is
+            # the same formulation twice more: what MIOpen's own run-to-run noise is
+            again = [{k: v.clone() for k, v in net(tensorData=data, tensorMasks=mask).items() if torch.is_tensor(v)} for _ in range(2)]
         finally:
             partial_conv.PartialConv2d.forward = fused_forward
     assert torch.equal(fused['tensorMaskOut'], ref['tensorMaskOut']) and torch.equal(fused['tensorExisting'], ref['tensorExisting'])
@@ -348,8 +350,11 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
     # MIOpen's fp32 solvers at this size are not bit-reproducible from run to run (split-K accumulation by atomics): two runs of the
     # SAME formulation differ by up to ~5e-5 in the image after thirty layers (measured: 3e-5 - 5e-5), which is where the two
     # formulations sit as well -- so the bar is twice the fixture test's tolerance plus twice that noise, measured here
-    noise_i = float((again['tensorImage'] - ref['tensorImage']).abs().max())
-    noise_d = float((again['tensorDisparity'] - ref['tensorDisparity']).abs().max())
+    # (the largest of four pairs of runs of one formulation -- a single pair's maximum over three million pixels scatters by a
+    # factor of two, and the test flaked once on a pair that happened to agree well)
+    pairs = [(again[0], ref), (again[1], ref), (again[0], again[1]), (fused_again, fused)]
+    noise_i = max(float((a['tensorImage'] - b['tensorImage']).abs().max()) for a, b in pairs)
+    noise_d = max(float((a['tensorDisparity'] - b['tensorDisparity']).abs().max()) for a, b in pairs)
     print('run-to-run noise of the reference formulation: image %.3g, disparity %.3g' % (noise_i, noise_d))
     _close(fused['tensorImage'], c(ref['tensorImage']), 2 * TOL_IMAGE + 2 * noise_i, 'partial Inpaint image at 1024^2')
     dref = c(ref['tensorDisparity'])
