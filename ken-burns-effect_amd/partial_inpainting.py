@@ -103,7 +103,7 @@ class Upsample(_Pair):
         mask = (self.upsample(mask_in) > 0.5).float()
         # (the feature maps' x2 bilinear upsampling through kbe_upsample2x_act where the fused passes are in use: PyTorch's
         # upsample_bilinear2d runs at a quarter of the memory's rate)
-        K = common._K() if (tensorInput.is_cuda and tensorInput.dtype == torch.float32 and self._fused()) else None
+        K = common._K() if (tensorInput.is_cuda and tensorInput.dtype == torch.float32 and tensorInput.device.index == torch.cuda.current_device() and self._fused()) else None
         up = K.upsample2x_act(tensorInput.contiguous()) if K is not None and hasattr(K, 'upsample2x_act') else self.upsample(tensorInput)
         return self._pair(up, mask)
 

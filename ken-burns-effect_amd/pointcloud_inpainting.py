@@ -41,8 +41,8 @@ def _fused_layers(x):
     blocks run as the stock modules they are made of.  ``KBE_FUSED_LAYERS=0`` turns it off (measurements, the parity test)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or torch.is_grad_enabled() or torch.is_autocast_enabled():
         return None
-    if os.environ.get('KBE_FUSED_LAYERS', '1') == '0':
-        return None
+    if os.environ.get('KBE_FUSED_LAYERS', '1') == '0' or x.device.index != torch.cuda.current_device():
+        return None                 # (the C ABI launches on the CURRENT device's stream: a tensor elsewhere takes the stock modules)
     K = common._K()
     return K if hasattr(K, 'bias_act') else None
 
