@@ -168,6 +168,9 @@ KBE_API int kbe_fill_disocclusion(const float* input, const float* depth, int B,
  * ------------------------------------------------------------------------------------- */
 KBE_API size_t kbe_frame_scratch_bytes(int W, int H, int N);
 KBE_API int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream);
+/* The same for `n` sets `stride` bytes apart (stride >= kbe_frame_scratch_bytes(W, H), a multiple of 16), in ONE launch: a video on a
+   new cloud initialises 16-32 of them. */
+KBE_API int kbe_frame_scratch_init_sets(void* scratch, size_t stride, int n, int W, int H, kbe_stream_t stream);
 
 KBE_API int kbe_render_frame(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double focal, double baseline, const float* shift3, void* scratch,

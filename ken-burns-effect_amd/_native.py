@@ -21,7 +21,7 @@ SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_selftest_division', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
-    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act',
+    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act', 'kbe_frame_scratch_init_sets',
 )
 
 ABI_VERSION = 9
@@ -285,9 +285,8 @@ class HipKernels:
         stride = int(self.lib.kbe_video_scratch_stride(_i(W), _i(H), _i(N)))
         state['lanes'] = lanes
         state['scratch'] = torch.empty(lanes * stride, dtype=torch.uint8, device=dev)
-        for l in range(lanes):
-            self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch'].data_ptr() + l * stride), _i(W), _i(H), _stream()),
-                        'kbe_frame_scratch_init')
+        self._check(self.lib.kbe_frame_scratch_init_sets(ctypes.c_void_p(state['scratch'].data_ptr()), _z(stride), _i(lanes), _i(W), _i(H), _stream()),
+                    'kbe_frame_scratch_init_sets')
         # Two routes for the scatter of a frame, same results (tests/test_hip_parity.py::test_fused_scatter_equals_the_bucket_path):
         #   fused   k_place -> k_frame on the packed cloud (kbe_cloud_pack, once per cloud): every point projected once, its
         #           12-byte placement stored in place, a tile pulls the sub-blocks listed for it, z-tile in LDS; no per-point
@@ -346,9 +345,8 @@ class HipKernels:
         stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
         if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
             state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=state['points'].device)
-            for l in range(sets):
-                self._check(self.lib.kbe_frame_scratch_init(ctypes.c_void_p(state['scratch_groups'].data_ptr() + l * stride), _i(state['W']), _i(state['H']),
-                                                            _stream()), 'kbe_frame_scratch_init')
+            self._check(self.lib.kbe_frame_scratch_init_sets(ctypes.c_void_p(state['scratch_groups'].data_ptr()), _z(stride), _i(sets), _i(state['W']), _i(state['H']),
+                                                             _stream()), 'kbe_frame_scratch_init_sets')
         return state['scratch_groups'], stride
 
     def render_frame_group(self, state, cameras, baseline, out, stages=7, zbuf_flags=None, fill_rect=None):

@@ -50,6 +50,17 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
     if (gtid < (size_t) HOLE_COUNT_INTS) hole_count[gtid] = 0;
 }
 
+// k_scratch_init for the sets `stride` bytes apart, one launch (blockIdx.y = the set; the offsets are those of carve())
+__global__ void k_scratch_init_sets(char* base, size_t stride, size_t zkeys, size_t zkeys_b, size_t hw, size_t tile_count, int n_tiles, size_t hole_count)
+{
+    char* const set = base + (size_t) blockIdx.y * stride;
+    uint32_t* const za = (uint32_t*) (set + zkeys), * const zb = (uint32_t*) (set + zkeys_b);
+    const size_t step = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = gtid; i < hw; i += step) { za[i] = KBE_ZKEY_EMPTY; zb[i] = KBE_ZKEY_EMPTY; }
+    for (size_t i = gtid; i < (size_t) n_tiles; i += step) ((int*) (set + tile_count))[i * CNT_STRIDE] = 0;
+    if (gtid < (size_t) HOLE_COUNT_INTS) ((int*) (set + hole_count))[gtid] = 0;
+}
+
 // the hole counters / list totals (HOLE_COUNT_INTS ints) of `n` scratch sets `stride` bytes apart
 // ... and both banks of their per-tile list counters (`tile_ints` ints at `tile_first` of the first set; blockIdx.y = the set): a
 // video that ended in an error after a launch that had placed ahead leaves the counters of one bank standing
@@ -800,6 +811,17 @@ int kbe_frame_scratch_init(void* scratch, int W, int H, kbe_stream_t stream)
     hipLaunchKernelGGL(k_scratch_init, dim3(1024), dim3(256), 0, (hipStream_t) stream, sc.zkeys, sc.zkeys_b, (size_t) W * H, sc.tile_count,
                        2 * sc.tiles_x * sc.tiles_y, sc.hole_count);
     return launched("kbe_frame_scratch_init");
+}
+
+int kbe_frame_scratch_init_sets(void* scratch, size_t stride, int n, int W, int H, kbe_stream_t stream)
+{
+    KBE_REQUIRE(scratch && n > 0 && n <= 65535 && W > 0 && H > 0 && ((uintptr_t) scratch & 15) == 0 && (stride & 15) == 0 && stride >= scratch_bytes(W, H),
+                "kbe_frame_scratch_init_sets: bad arguments");
+    const Scratch sc = carve(scratch, W, H);
+    auto off = [&](const void* p) { return (size_t) ((const char*) p - (const char*) scratch); };
+    hipLaunchKernelGGL(k_scratch_init_sets, dim3(256, n), dim3(256), 0, (hipStream_t) stream, (char*) scratch, stride, off(sc.zkeys), off(sc.zkeys_b), (size_t) W * H,
+                       off(sc.tile_count), 2 * sc.tiles_x * sc.tiles_y, off(sc.hole_count));
+    return launched("kbe_frame_scratch_init_sets");
 }
 
 }  // extern "C"
