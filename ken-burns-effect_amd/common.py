@@ -272,6 +272,8 @@ def build_pointcloud(objectSettings, objectCommon, moduleInpaint):
         # common.py:208-215 renders this pose and discards the result; skipped.
         if not objectSettings['dolly']:
             process_inpaint(1.1 * tensorShift, objectCommon, moduleInpaint, focal)
+    if getattr(moduleInpaint, '_kept_source', None) is not None:
+        moduleInpaint._kept_source = None          # (what pointcloud_inpainting kept of the image between the two passes: 68 feature planes)
 
 
 def frame_cameras(objectSettings, objectCommon):

@@ -235,13 +235,25 @@ class Inpaint(nn.Module):
         K = common._K()
         width, height = objectCommon['intWidth'], objectCommon['intHeight']
 
-        tensorDepth = (dblFocal * objectCommon['dblBaseline']) / (tensorDisparity + 0.0000001)
-        tensorValid = K.laplacian_valid(tensorDisparity, tensorDisparity.max(), 0.03)
-        tensorPoints = K.depth_to_points(tensorDepth, dblFocal, valid=tensorValid).view(1, 3, -1)
+        # process_kenburns' set-up calls this twice with the SAME image and disparity (common.py:181-219: one pass per end pose):
+        # what depends on them alone -- the points, the normalisation, the context features -- is kept from the first call.
+        # The kept entry holds the two input tensors themselves (so that their addresses cannot be handed to other tensors)
+        # and their versions (an in-place change makes it stale), and the versions of the context network's parameters.
+        kept = getattr(self, '_kept_source', None) if not torch.is_grad_enabled() else None
+        stamp = (tensorImage._version, tensorDisparity._version, float(dblFocal), float(objectCommon['dblBaseline'])) + \
+            tuple(p._version for p in self.moduleContext.parameters())
+        if kept is not None and kept[0] is tensorImage and kept[1] is tensorDisparity and kept[2] == stamp:
+            tensorPoints, features, self.tensorMean, self.tensorStd = kept[3]
+        else:
+            tensorDepth = (dblFocal * objectCommon['dblBaseline']) / (tensorDisparity + 0.0000001)
+            tensorValid = K.laplacian_valid(tensorDisparity, tensorDisparity.max(), 0.03)
+            tensorPoints = K.depth_to_points(tensorDepth, dblFocal, valid=tensorValid).view(1, 3, -1)
 
-        tensorImage, tensorDisparity = self.normalize_images_disp(tensorImage, tensorDisparity, not_normed=True)
-        tensorContext = self._context(torch.cat([tensorImage, tensorDisparity], 1))
-        features = torch.cat([tensorImage, tensorDisparity, tensorContext], 1).view(1, 68, -1)
+            imageIn, disparityIn = tensorImage, tensorDisparity
+            tensorImage, tensorDisparity = self.normalize_images_disp(tensorImage, tensorDisparity, not_normed=True)
+            tensorContext = self._context(torch.cat([tensorImage, tensorDisparity], 1))
+            features = torch.cat([tensorImage, tensorDisparity, tensorContext], 1).view(1, 68, -1)
+            self._kept_source = None if torch.is_grad_enabled() else (imageIn, disparityIn, stamp, (tensorPoints, features, self.tensorMean, self.tensorStd))
 
         tensorRender, tensorExisting = K.render_pointcloud(tensorPoints + tensorShift, features, width, height, dblFocal,
                                                            objectCommon['dblBaseline'])

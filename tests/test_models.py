@@ -64,6 +64,51 @@ def test_pointcloud_inpainting_matches_reference(net, oracle, monkeypatch):
     assert np.abs(out['tensorDisparity'].numpy() - z['pi_disparity']).max() < 5e-4 * max(1.0, np.abs(z['pi_disparity']).max())
 
 
+def test_pointcloud_inpainting_keeps_what_depends_on_the_image_alone_and_notices_changes(net, oracle, monkeypatch):
+    """process_kenburns' set-up calls pointcloud_inpainting twice with the same image and disparity: the second call takes the
+    points, the normalisation and the context features from the first (the entry holds the input tensors themselves).  Same
+    results as a module that kept nothing; a disparity changed IN PLACE, other tensors of equal content, or a call under autograd
+    do not take the kept entry."""
+    from ken_burns_effect_amd import common as C
+    monkeypatch.setattr(C, '_kernel_set', oracle.OracleKernels(schedule='serial'))
+    z = load_golden('inpaint')
+    image, disp = _t(z['image']), _t(z['disparity'])
+    H, W = image.shape[2:]
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H}
+    shift_a, shift_b = _t(z['pi_shift']), -0.5 * _t(z['pi_shift'])
+    calls = []
+    real = net._context
+    monkeypatch.setattr(net, '_context', lambda x: (calls.append(1), real(x))[1])
+
+    def fresh(i, d, s):
+        net._kept_source = None
+        return net.pointcloud_inpainting(i, d, s, oc)
+    with torch.no_grad():
+        want_a, want_b = fresh(image, disp, shift_a), fresh(image, disp, shift_b)
+        net._kept_source, n0 = None, len(calls)
+        got_a = net.pointcloud_inpainting(image, disp, shift_a, oc)
+        got_b = net.pointcloud_inpainting(image, disp, shift_b, oc)
+        assert len(calls) == n0 + 1, 'the second call of a pair runs no context network'
+        for got, want in ((got_a, want_a), (got_b, want_b)):
+            assert all(torch.equal(got[k], want[k]) for k in ('tensorImage', 'tensorDisparity', 'tensorExisting'))
+        # equal content in other tensors: not the kept entry
+        net.pointcloud_inpainting(image.clone(), disp, shift_b, oc)
+        assert len(calls) == n0 + 2
+        # the disparity changed in place: stale
+        net.pointcloud_inpainting(image, disp, shift_b, oc)
+        n1 = len(calls)
+        disp.mul_(1.25)
+        changed = net.pointcloud_inpainting(image, disp, shift_b, oc)
+        assert len(calls) == n1 + 1
+        want_changed = fresh(image, disp, shift_b)
+        assert torch.equal(changed['tensorDisparity'], want_changed['tensorDisparity']) and not torch.equal(changed['tensorDisparity'], want_b['tensorDisparity'])
+    net._kept_source = None
+    n2 = len(calls)
+    net.pointcloud_inpainting(image, disp, shift_b, oc)
+    net.pointcloud_inpainting(image, disp, shift_b, oc)
+    assert len(calls) == n2 + 2 and net._kept_source is None, 'under autograd nothing is kept'
+
+
 def test_train_mode_does_not_clamp(net):
     z = load_golden('inpaint')
     net.train()
