@@ -719,8 +719,8 @@ class HipKernels:
         assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
         B, C, H, W = x.shape
         out = torch.empty_like(x) if out is None else out
-        for r in (res1, res2):
-            assert r is None or (r.shape == x.shape and r.dtype == torch.float32 and r.is_contiguous())
+        res1, res2 = (None if r is None else _f32c(r) for r in (res1, res2))
+        assert all(r is None or r.shape == x.shape for r in (res1, res2))
         self._check(self.lib.kbe_bias_act(_ptr(x), _ptr(None if bias is None else _f32c(bias)), _ptr(None if slope is None else _f32c(slope)), _ptr(res1), _ptr(res2),
                                           _i(B), _i(C), _i(H), _i(W), _ptr(out), _stream()), 'kbe_bias_act')
         return out
