@@ -46,7 +46,7 @@ __global__ void k_scratch_init(uint32_t* zkeys, uint32_t* zkeys_b, size_t hw, in
 {
     const size_t stride = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += stride) { zkeys[i] = KBE_ZKEY_EMPTY; if (zkeys_b) zkeys_b[i] = KBE_ZKEY_EMPTY; }
-    for (size_t i = gtid; i < (size_t) n_tiles; i += stride) tile_count[i * CNT_STRIDE] = 0;
+    for (size_t i = gtid; i < (size_t) n_tiles; i += stride) { tile_count[i * CNT_STRIDE] = 0; tile_count[i * CNT_STRIDE + 1] = 0; }      // (+ 1: the arrivals at a shared list, kbe_fused.hip)
     if (gtid < (size_t) HOLE_COUNT_INTS) hole_count[gtid] = 0;
 }
 
@@ -57,7 +57,7 @@ __global__ void k_scratch_init_sets(char* base, size_t stride, size_t zkeys, siz
     uint32_t* const za = (uint32_t*) (set + zkeys), * const zb = (uint32_t*) (set + zkeys_b);
     const size_t step = (size_t) gridDim.x * blockDim.x, gtid = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = gtid; i < hw; i += step) { za[i] = KBE_ZKEY_EMPTY; zb[i] = KBE_ZKEY_EMPTY; }
-    for (size_t i = gtid; i < (size_t) n_tiles; i += step) ((int*) (set + tile_count))[i * CNT_STRIDE] = 0;
+    for (size_t i = gtid; i < (size_t) n_tiles; i += step) { ((int*) (set + tile_count))[i * CNT_STRIDE] = 0; ((int*) (set + tile_count))[i * CNT_STRIDE + 1] = 0; }
     if (gtid < (size_t) HOLE_COUNT_INTS) ((int*) (set + hole_count))[gtid] = 0;
 }
 

@@ -201,27 +201,59 @@ __device__ __forceinline__ int row_min(int v)
 // In two steps, so that a caller can do other work while the list atomic is under way: place_point_begin returns the list entry
 // the lane owes -- the tile and the slot its atomic returned -- and place_point_end writes it.
 struct ListSlot { int t, pos; };
+// Whose candidate list a placement feeds (KBE_SHARED_LISTS; wave-uniform).  mode 0: the frame's own.  The frames a launch places
+// ahead are consecutive cameras of a path -- same focal length, shifts on one line (the host checks: launch_frames_fused) -- and
+// list almost the same sub-blocks for the same tiles: the group then shares ONE set of lists, made by the row of its first
+// frame (mode 2) from the box of the sub-block's corners under the group's FIRST and LAST camera (a point's position is a
+// ratio of two functions linear in the step: monotone between the two, so every frame in between stays inside; SHARE_MARGIN
+// pixels cover the rounding of the frames' own fp32 arithmetic and of the shifts), and the other rows make none (mode 1).
+#ifndef KBE_SHARED_LISTS
+#define KBE_SHARED_LISTS 1
+#endif
+struct ShareMode { int mode; float dsx, dsy, dsz; };         // dsx, dsy, dsz: the last camera's shift minus this (the first) one's
+constexpr float SHARE_MARGIN = 0.25f;
 __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
-                                                      int* tile_count, int* cand_lists, unsigned* bin_flag)
+                                                      int* tile_count, int* cand_lists, unsigned* bin_flag, const ShareMode& share)
 {
     ListSlot owed = { -1, 0 };
     float x = p.x, y = p.y, z = p.z, ox = 0.0f, oy = 0.0f;
     apply_shift(cam, x, y, z);
     bool ok = project_xy(cam, x, y, z, ox, oy);
-    const int nwx = (int) floorf(ox), nwy = (int) floorf(oy);
+    const bool seen = ok;                                       // in front of the near plane, at a finite position
+    int nwx = (int) floorf(ox), nwy = (int) floorf(oy);
     ok = ok && ((unsigned) (nwx + 1) <= (unsigned) cam.W) & ((unsigned) (nwy + 1) <= (unsigned) cam.H);      // a corner inside the image: -1 <= nw < size
     Placement pl;
     pl.ox = ok ? ox : PLACE_NONE;
     pl.oy = ok ? oy : PLACE_NONE;
     pl.err = project_err_fast(cam, ok ? z : 1024.0f);
     place[i] = pl;
+    int nex = nwx, ney = nwy;                                   // the corner's range over the frames the list serves: [nwx, nex] x [nwy, ney]
+    if (KBE_SHARED_LISTS && share.mode == 1) return owed;       // uniform
+    if (KBE_SHARED_LISTS && share.mode == 2) {
+        // the point under the group's last camera, to the accuracy a box needs (a reciprocal instead of the division)
+        const float xb = x + share.dsx, yb = y + share.dsy, zb = z + share.dsz;
+        const bool seen_b = zb >= 0.001f;
+        const float t = cam.focal_f * __builtin_amdgcn_rcpf(zb);
+        const float oxb = __builtin_fmaf(xb, t, cam.cx_f), oyb = __builtin_fmaf(yb, t, cam.cy_f);
+        // no bound where the point passes the near plane inside the group, comes closer to it than a thousandth of the focal
+        // length (a shift's last bit then moves it by more than the margin), or lands nowhere finite: the whole image
+        const float z_safe = 1.0e-3f * cam.focal_f;
+        const bool loose = (seen != seen_b) | (seen & !(z >= z_safe)) | (seen_b & !(zb >= z_safe)) | (seen_b & !((fabsf(oxb) < 1.0e9f) & (fabsf(oyb) < 1.0e9f)));
+        const float fw = (float) (cam.W - 1), fh = (float) (cam.H - 1);
+        float lox = fminf(ox, oxb) - SHARE_MARGIN, hix = fmaxf(ox, oxb) + SHARE_MARGIN;
+        float loy = fminf(oy, oyb) - SHARE_MARGIN, hiy = fmaxf(oy, oyb) + SHARE_MARGIN;
+        ok = seen & seen_b & (hix >= -1.0f) & (lox < fw + 1.0f) & (hiy >= -1.0f) & (loy < fh + 1.0f);
+        lox = fmaxf(lox, -1.0f); hix = fminf(hix, fw); loy = fmaxf(loy, -1.0f); hiy = fminf(hiy, fh);
+        if (loose) { ok = seen | seen_b; lox = -1.0f; hix = fw; loy = -1.0f; hiy = fh; }
+        nwx = (int) floorf(lox); nex = (int) floorf(hix); nwy = (int) floorf(loy); ney = (int) floorf(hiy);
+    }
 
     // the tiles the sub-block reaches: per lane the first and last tile its point matters to (monotone in the corner, so the
     // minimum / maximum over the row are those of the box); lanes that are out take no part
     static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "tile sizes are powers of two");
     constexpr int BIG = 1 << 24;
-    const int tx0 = max(row_min(ok ? (nwx - 1) >> __builtin_ctz(TW) : BIG), 0), tx1 = min(-row_min(ok ? -((nwx + 2) >> __builtin_ctz(TW)) : BIG), tiles_x - 1);
-    const int ty0 = max(row_min(ok ? (nwy - 1) >> __builtin_ctz(TH) : BIG), 0), ty1 = min(-row_min(ok ? -((nwy + 2) >> __builtin_ctz(TH)) : BIG), tiles_y - 1);
+    const int tx0 = max(row_min(ok ? (nwx - 1) >> __builtin_ctz(TW) : BIG), 0), tx1 = min(-row_min(ok ? -((nex + 2) >> __builtin_ctz(TW)) : BIG), tiles_x - 1);
+    const int ty0 = max(row_min(ok ? (nwy - 1) >> __builtin_ctz(TH) : BIG), 0), ty1 = min(-row_min(ok ? -((ney + 2) >> __builtin_ctz(TH)) : BIG), tiles_y - 1);
     const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;               // uniform over the row; no point in: tx0 = BIG, w < 0
     const bool some = w > 0 && h > 0;
     const int sub = i / kCloudSub, j = lane & (kCloudSub - 1);
@@ -266,9 +298,9 @@ __device__ __forceinline__ void place_point_end(const ListSlot& owed, int i, int
     if (owed.t >= 0 && owed.pos < LIST_CAP) cand_lists[(size_t) owed.t * LIST_CAP + owed.pos] = i / kCloudSub;     // beyond: the tile sees count > LIST_CAP and scans
 }
 __device__ __forceinline__ void place_point(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
-                                            int* tile_count, int* cand_lists, unsigned* bin_flag)
+                                            int* tile_count, int* cand_lists, unsigned* bin_flag, const ShareMode& share)
 {
-    place_point_end(place_point_begin(p, i, lane, cam, tiles_x, tiles_y, place, tile_count, cand_lists, bin_flag), i, cand_lists);
+    place_point_end(place_point_begin(p, i, lane, cam, tiles_x, tiles_y, place, tile_count, cand_lists, bin_flag, share), i, cand_lists);
 }
 
 __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
@@ -276,7 +308,7 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
     const PlaceArgs& a = jobs.a[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;        // Np is a multiple of 64: whole waves only
     if (i >= jobs.pc.Np) return;
-    place_point(jobs.pc.pd[i], i, threadIdx.x & 63, a.cam, jobs.tiles_x, jobs.tiles_y, a.place, a.tile_count, a.cand, a.bin_flag);
+    place_point(jobs.pc.pd[i], i, threadIdx.x & 63, a.cam, jobs.tiles_x, jobs.tiles_y, a.place, a.tile_count, a.cand, a.bin_flag, ShareMode{ 0, 0.0f, 0.0f, 0.0f });
 }
 
 // what a pass over candidate blocks does with each point
@@ -342,7 +374,18 @@ __device__ __forceinline__ Camera load_camera(const __attribute__((address_space
 // blockIdx.y takes frames blockIdx.y, blockIdx.y + gridDim.y, ... of `nx`, its waves the frames' units of 64 points in turn.
 // k_place alone is a streaming launch that waits for memory 70 % of its life (the point, then its list slots); k_frame is bound
 // by instruction issue: one launch lets the one's waits hide under the other's arithmetic whatever else the chip is doing.
-__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane, int units_up_front)
+// the mode of frame j of the `n_next` a launch places (shared: the launch's flag)
+__device__ __forceinline__ ShareMode share_mode(PlaceArgsPtr nx, int n_next, int j, bool shared)
+{
+    ShareMode m = { 0, 0.0f, 0.0f, 0.0f };
+    if (KBE_SHARED_LISTS && shared) {
+        m.mode = j == 0 ? 2 : 1;
+        if (j == 0) { m.dsx = nx[n_next - 1].cam.sx - nx[0].cam.sx; m.dsy = nx[n_next - 1].cam.sy - nx[0].cam.sy; m.dsz = nx[n_next - 1].cam.sz - nx[0].cam.sz; }
+    }
+    return m;
+}
+
+__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane, int units_up_front, bool shared)
 {
     const CloudPoint* const pd = pcp->pd;
     const int n_units = pcp->Np / kCloudBlock;
@@ -354,6 +397,7 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
         int* const tile_count = a->tile_count;
         int* const cand = a->cand;
         unsigned* const bin_flag = a->bin_flag;
+        const ShareMode share = share_mode(nx, n_next, j, shared);
         const int u0 = first + (j == (int) blockIdx.y ? units_up_front * step : 0);      // (the row's first frame: its first units were placed up front)
         if (u0 >= n_units) continue;
         CloudPoint p = pd[u0 * kCloudBlock + lane];
@@ -361,7 +405,7 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
             const CloudPoint q = p;
             const int un = u + step < n_units ? u + step : u;
             p = pd[un * kCloudBlock + lane];
-            place_point(q, u * kCloudBlock + lane, lane, cam, tiles_x, tiles_y, place, tile_count, cand, bin_flag);
+            place_point(q, u * kCloudBlock + lane, lane, cam, tiles_x, tiles_y, place, tile_count, cand, bin_flag, share);
         }
     }
 }
@@ -434,6 +478,8 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     // addresses clamped: a row with no frame to place reads the cloud's first block)
     constexpr int NU = AHEAD ? UNITS : 0;
     const int n_next = AHEAD ? jp->n_next : 0;
+    // (KBE_SHARED_LISTS) bit 0: this launch's frames read ONE set of lists, the first frame's; bit 1: so will the frames it places
+    const int share_flags = KBE_SHARED_LISTS ? jp->pad_ : 0;
     const bool ahead = NU > 0 && (int) blockIdx.y < n_next;             // uniform: this row has a frame to place
     const int a_units = ahead ? pcp->Np / kCloudBlock : 1;
     const int a_first = blockIdx.x * WAVES + wave, a_step = gridDim.x * WAVES;
@@ -465,11 +511,12 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     if (ahead) {
         PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
         const Camera ncam = load_camera(&na->cam);
+        const ShareMode nshare = share_mode((PlaceArgsPtr) jp->nx, n_next, blockIdx.y, (share_flags & 2) != 0);
         KBE_PROBE(12);
 #pragma unroll
         for (int d = 0; d < NU; d++)
             if (a_first + d * a_step < a_units)
-                a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag);
+                a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag, nshare);
     }
     const bool listed = !wide & (count <= LIST_CAP);            // uniform
     KBE_PROBE(1);
@@ -477,7 +524,14 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     KBE_PROBE(2);
     if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
-    if (tid == 0) tile_count[tile * CNT_STRIDE] = 0;    // ready for the next frame's k_place
+    if (tid == 0) {                                     // ready for the next frame's k_place
+        if (KBE_SHARED_LISTS && (share_flags & 1)) {
+            // the list is the group's: the last of its frames' workgroups to get here (each has read the count) zeroes it, and
+            // the arrivals' own counter next to it
+            if (atomicAdd(&tile_count[tile * CNT_STRIDE + 1], 1) == (int) gridDim.y - 1) { tile_count[tile * CNT_STRIDE + 1] = 0; tile_count[tile * CNT_STRIDE] = 0; }
+        }
+        else tile_count[tile * CNT_STRIDE] = 0;
+    }
     KBE_STOP_AFTER(1);                                          // (dev) the list
 
     // ---- what a tile does with one placed point per lane {ox, oy, dblError}: by `flags` PASS_Z the min-splat of its dblError
@@ -560,7 +614,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             if (more) fetch_points();
         }
     }
-    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane, NU);
+    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane, NU, (share_flags & 2) != 0);
     KBE_PROBE(3);
     if (KBE_AHEAD_AT == 3) ahead_finish();
     __syncthreads();
@@ -807,7 +861,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");
         const int n_left = jp->n_next;
-        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU);
+        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU, KBE_SHARED_LISTS && (jp->pad_ & 2) != 0);
     }
     KBE_PROBE(9);
 #if defined(KBE_FRAME_PROBE)
@@ -905,7 +959,40 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         b.bin_flag = (unsigned*) f.sc.hole_count + flag_of(f);
         return b;
     };
-    pj.pc = pc; fj.pc = pc; fj.n_next = n_next; fj.pad_ = 0;
+    // (KBE_SHARED_LISTS) one set of candidate lists for a group of frames placed ahead (ShareMode, above): the group's cameras must
+    // differ in their shifts only, the shifts lying on one line in the order of the frames -- what consecutive steps of a camera
+    // path are.  Decided from the group's cameras alone, so that the launch that places a group and the launch that renders it
+    // agree without being told.
+    auto shareable = [&](const FusedTarget* g, int m) {
+        if (!KBE_SHARED_LISTS || m < 2) return false;
+        // a group's list is a tenth or two longer than a frame's own, and a list beyond LIST_CAP sends its tile down the slow
+        // path: only clouds whose AVERAGE list (1.55 candidates per point of the tile's share, in sub-blocks) leaves a factor of
+        // four to the capacity share (the bench cloud: 54 of 512; 16.8 M points on 2048^2: 198, its densest tiles 480-500 --
+        // shared they reached 515-555 and eighteen tiles of a video scanned the whole cloud)
+        const Scratch& sc = g[0].sc;
+        if (1.55 * (double) pc.Np / kCloudSub / ((double) sc.tiles_x * sc.tiles_y) > LIST_CAP / 4.0) return false;
+        const Camera& c0 = g[0].cam;
+        const Camera& c1 = g[m - 1].cam;
+        const double d[3] = { (double) c1.sx - c0.sx, (double) c1.sy - c0.sy, (double) c1.sz - c0.sz };
+        const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        double big = 1.0;
+        for (int k = 0; k < m; k++) big = fmax(big, fmax(fabs((double) g[k].cam.sx), fmax(fabs((double) g[k].cam.sy), fabs((double) g[k].cam.sz))));
+        if (big > 100.0) return false;
+        double last = 0.0;
+        for (int k = 0; k < m; k++) {
+            const Camera& c = g[k].cam;
+            if (c.focal_f != c0.focal_f || c.fb != c0.fb || c.half_w != c0.half_w || c.half_h != c0.half_h || c.W != c0.W || c.H != c0.H ||
+                c.fp32_centre != c0.fp32_centre || !c.has_shift || !c0.has_shift || !c0.fp32_centre) return false;
+            const double e[3] = { (double) c.sx - c0.sx, (double) c.sy - c0.sy, (double) c.sz - c0.sz };
+            const double lam = dd > 0.0 ? (e[0] * d[0] + e[1] * d[1] + e[2] * d[2]) / dd : 0.0;
+            if (lam < last - 1.0e-9 || lam > 1.0 + 1.0e-9) return false;                     // in the order of the frames, between the two ends
+            for (int q = 0; q < 3; q++) if (fabs(e[q] - lam * d[q]) > 1.0e-6 * big) return false;  // on the line, to the shifts' own rounding
+            last = lam;
+        }
+        return true;
+    };
+    const bool shared_now = placed && shareable(t, n), shared_next = n_next > 0 && shareable(next, n_next);
+    pj.pc = pc; fj.pc = pc; fj.n_next = n_next; fj.pad_ = (shared_now ? 1 : 0) | (shared_next ? 2 : 0);
     for (int k = 0; k < KBE_FRAME_JOBS; k++) {
         const FusedTarget& f = t[k < n ? k : 0];
         const Scratch& sc = f.sc;
@@ -920,6 +1007,8 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         a.render = f.render_f32; a.existing = f.existing_f32; a.zee = f.zee_f32; a.zee_pre = f.zee_pre_f32; a.spill = sc.buckets;
         fj.nx[k] = place_args(n_next > 0 ? next[k < n_next ? k : 0] : f);
     }
+    if (shared_now)         // every frame reads the lists the group's first frame's set holds
+        for (int k = 1; k < KBE_FRAME_JOBS; k++) { fj.a[k].tile_count = fj.a[0].tile_count; fj.a[k].cand = fj.a[0].cand; fj.a[k].bin_flag = fj.a[0].bin_flag; fj.a[k].bin_flag_next = fj.a[0].bin_flag_next; }
     if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
     if (n == 1 && n_next <= 1) {
         FrameJob1 f1;
