@@ -240,6 +240,9 @@ __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float 
 // the LDS read takes as it is.  The
 // trip count is the longest of the four lists, not their sum.  FAST: every z of the tile is in the band where
 // `zee + 1.0` is exact in fp32 (plus_one_is_exact); otherwise the comparison runs in fp64 where it has to.
+#ifndef KBE_GATHER_PORT2
+#define KBE_GATHER_PORT2 0
+#endif
 template <bool FAST, class Args>
 __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid, int x0, int y0,
                                        PixAcc (&acc)[PIX_PER_THREAD])
@@ -257,15 +260,38 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
         // corner k of a point is this pixel  <=>  its north-west corner is (X - (k & 1), Y - (k >> 1)).  That pins
         // floor(ox), floor(oy), so the bilinear weight of common.py:481-484 needs two subtractions and one
         // product: (ex - ox | ox - fx) * (ey - oy | oy - fy) with fx = (float) nwx, ex = (float) (nwx + 1).
+        // KBE_GATHER_PORT2 (FAST tiles): the same arithmetic in instructions a SIMD issues through its SECOND port (DESIGN.md
+        // section 4: plain two-operand fp32 / integer / logic instructions on vector registers co-issue with the first port's,
+        // which the launch is bound by) -- 1: the four channels as separate v_mul_f32 + v_add_f32 instead of packed pairs
+        // (packed fp32 takes the first port); 2: also the z test as a subtraction whose sign masks the weight instead of a
+        // compare and a select.  r.z <= zlimf  <=>  r.z < the float above zlimf  <=>  r.z - that float is negative (both
+        // finite, or r.z = +inf on the dummy record: the difference then is +inf; zlimf = zee + 1 with zee in [2^19, 1e6]).
+        const float zl2 = __int_as_float(__float_as_int(zlimf) + 1);
+        float ar = acc[m].rg.x, ag = acc[m].rg.y, ab = acc[m].bd.x, ad = acc[m].bd.y, aw = acc[m].w;
         auto add = [&](int k, const float4& r, const float4& c) {
-            const bool pass = exact ? (r.z <= zlimf) : ((double) r.z <= zlim);             // :639
             const float wx = (k & 1) ? (r.x - (Xf - 1.0f)) : ((Xf + 1.0f) - r.x);          // k & 1 ? ox - fx : ex - ox
             const float wy = (k >> 1) ? (r.y - (Yf - 1.0f)) : ((Yf + 1.0f) - r.y);
-            const float w = pass ? wx * wy : 0.0f;
-            const f4 cv = *(const f4*) &c;
-            acc[m].rg += cv.xy * w;                                         // :641 product rounded, then added (v_pk_mul_f32, v_pk_add_f32)
-            acc[m].bd += cv.zw * w;
-            acc[m].w += w;                                                  // the `ones` channel (:429)
+            float w;
+            if (FAST && KBE_GATHER_PORT2 >= 2) {
+                const float below = r.z - zl2;
+                int sign;
+                w = wx * wy;
+                // (as the instructions: the compiler turns `(x >> 31) & y` back into a compare and a select)
+                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sign) : "v"(below));
+                asm("v_and_b32 %0, %1, %2" : "=v"(w) : "v"(w), "v"(sign));
+            } else {
+                const bool pass = exact ? (r.z <= zlimf) : ((double) r.z <= zlim);         // :639
+                w = pass ? wx * wy : 0.0f;
+            }
+            if (FAST && KBE_GATHER_PORT2 >= 1) {
+                ar += c.x * w; ag += c.y * w; ab += c.z * w; ad += c.w * w;                 // :641 product rounded, then added
+                aw += w;
+            } else {
+                const f4 cv = *(const f4*) &c;
+                acc[m].rg += cv.xy * w;                                     // :641 product rounded, then added (v_pk_mul_f32, v_pk_add_f32)
+                acc[m].bd += cv.zw * w;
+                acc[m].w += w;                                              // the `ones` channel (:429)
+            }
         };
         int nx[4];
 #pragma unroll
@@ -283,6 +309,7 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
                 nx[k] = __float_as_int(r[k].w);
             }
         } while (min(min(nx[0], nx[1]), min(nx[2], nx[3])) < REC_NULL);      // some list goes on
+        if (FAST && KBE_GATHER_PORT2 >= 1) { acc[m].rg.x = ar; acc[m].rg.y = ag; acc[m].bd.x = ab; acc[m].bd.y = ad; acc[m].w = aw; }
     }
 }
 

@@ -317,7 +317,8 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
     with a fifth of the pixels missing, in blobs and single pixels), every PartialConv2d through the fused epilogue
     (kbe_pconv_epilogue) against the same network with every layer in the reference's formulation (the mask's own convolution
     and five element-wise passes, /root/reference/utils/partial_conv.py:58-77; bench.partial_conv_reference_forward): the
-    propagated masks equal, image and disparity within twice the tolerance of the 32 x 40 fixture test above."""
+    propagated masks equal; image and disparity: the root mean square of the difference within the tolerance of the 32 x 40
+    fixture test above, the worst of the million pixels within four times it (+ MIOpen's run-to-run noise, measured here)."""
     import bench
     from ken_burns_effect_amd import partial_conv, synthetic
     from ken_burns_effect_amd.partial_inpainting import Inpaint
@@ -356,9 +357,23 @@ def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_fo
     noise_i = max(float((a['tensorImage'] - b['tensorImage']).abs().max()) for a, b in pairs)
     noise_d = max(float((a['tensorDisparity'] - b['tensorDisparity']).abs().max()) for a, b in pairs)
     print('run-to-run noise of the reference formulation: image %.3g, disparity %.3g' % (noise_i, noise_d))
-    _close(fused['tensorImage'], c(ref['tensorImage']), 2 * TOL_IMAGE + 2 * noise_i, 'partial Inpaint image at 1024^2')
+    # Two bars.  (1) The TYPICAL pixel: the root mean square of the difference stays below the fixture test's tolerance -- a
+    # systematic difference between the formulations would show here whatever the extremes do.  (2) The WORST of a million
+    # pixels: four times that tolerance (+ twice the measured noise).  The 32 x 40 fixture's bar of 2 TOL is a maximum over 1 280
+    # pixels; the maximum over 820 times as many samples of the same distribution sits higher, and where the box's MIOpen picks
+    # deterministic solvers (noise 0: the round's last collection) the two formulations still call DIFFERENT convolutions -- with
+    # and without the bias, on masked and unmasked inputs -- whose accumulation orders differ: measured maxima 3e-5 - 4.9e-5.
+    d_i = fused['tensorImage'] - ref['tensorImage']
+    rms_i = float(d_i.double().pow(2).mean().sqrt())
+    print('partial Inpaint image at 1024^2: rms difference %.3g (bar %.3g)' % (rms_i, TOL_IMAGE))
+    assert rms_i <= TOL_IMAGE
+    _close(fused['tensorImage'], c(ref['tensorImage']), 4 * TOL_IMAGE + 2 * noise_i, 'partial Inpaint image at 1024^2')
     dref = c(ref['tensorDisparity'])
-    _close(fused['tensorDisparity'], dref, 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(dref).max())) + 2 * noise_d, 'partial Inpaint disparity at 1024^2')
+    tol_d = TOL_DISPARITY_REL * max(1.0, float(np.abs(dref).max()))
+    rms_d = float((fused['tensorDisparity'] - ref['tensorDisparity']).double().pow(2).mean().sqrt())
+    print('partial Inpaint disparity at 1024^2: rms difference %.3g (bar %.3g)' % (rms_d, tol_d))
+    assert rms_d <= tol_d
+    _close(fused['tensorDisparity'], dref, 4 * tol_d + 2 * noise_d, 'partial Inpaint disparity at 1024^2')
 
 
 # ---------------------------------------------------------------------------------------
