@@ -31,8 +31,10 @@ FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take 
                                  # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
                                  # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
 FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
-FUSED_HOST_GROUP = 8   # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_VIDEO_GROUP): transfer groups
-                       # of 16 frames are then two EQUAL launches, and equal groups place ahead (the scatter alone: 19.4 us per frame with 8 or 12)
+FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
+                       # launch's 4 KB of kernel arguments hold.  A launch alone on a stream costs ~5 us besides its frames (ramp and tail: 8 / 12
+                       # frames per launch 16.5 / 16.1 us per frame), and delivered to host memory -- the link binds -- a video runs at the same rate
+                       # with 8 or 12 (17.4-17.6 k frames/s, --steps 75 16.1-16.3 k, --steps 20 13.8-13.9 k either way: tools/gpu_r04_group12.sh)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 PROBE_MIN_FRAMES = 128 # delivered videos from this length on have their lanes measured (HipKernels.delivery_lanes); shorter ones take the a-priori estimate
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)

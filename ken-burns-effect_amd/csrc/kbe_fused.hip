@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
 }
 
 // what a pass over candidate blocks does with each point
-enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4, PASS_SPILL = 8, PASS_COLOUR = 16 };
+enum : int { PASS_Z = 1, PASS_COUNT = 2, PASS_INSERT = 4, PASS_SPILL = 8, PASS_COLOUR = 16, PASS_IN_IMAGE = 32 };
 
 #if defined(KBE_FRAME_STOP)      // dev build only (tools/gpu_variant_pmc.sh): the kernel ends after stage KBE_FRAME_STOP, to cost the stages
 #define KBE_STOP_AFTER(n) do { if (KBE_FRAME_STOP == (n)) return; } while (0)
@@ -494,8 +494,25 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             for (int d = 0; d < NU; d++) place_point_end(a_owed[d], (a_first + d * a_step) * kCloudBlock + lane, cand_next);
         }
     };
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
-    for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
+#ifndef KBE_LDS_WIDE
+#define KBE_LDS_WIDE 1
+#endif
+    // (KBE_LDS_WIDE: the bin heads and the z keys four entries per store -- 294 ds_write_b128 for the workgroup, one per thread and
+    // a second one for 38 of them, instead of 1 173 single stores in two loops of three trips with their bound tests: a wave's
+    // ~25 vector instructions become ~8, on a launch bound by vector issue)
+    constexpr int HEAD4 = (int) (sizeof(L.head) / 16), ZK4 = KH * KW / 4;
+    static_assert(!KBE_LDS_WIDE || ((KH * KW) % 4 == 0 && offsetof(TileLds, head) % 16 == 0 && offsetof(TileLds, zpre) % 16 == 0 && sizeof(L.head) % 16 == 0 &&
+                                    HEAD4 <= TILE_THREADS && HEAD4 + ZK4 <= 2 * TILE_THREADS && ZK4 >= TILE_THREADS - HEAD4), "four entries per store");
+    if (KBE_LDS_WIDE) {
+        const int4 nul4 = make_int4(REC_NULL, REC_NULL, REC_NULL, REC_NULL);
+        const uint4 emp4 = make_uint4(KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY);               // common.py:430
+        if (tid < HEAD4) ((int4*) L.head)[tid] = nul4;
+        else ((uint4*) zk)[tid - HEAD4] = emp4;
+        if (tid < ZK4 - (TILE_THREADS - HEAD4)) ((uint4*) zk)[TILE_THREADS - HEAD4 + tid] = emp4;
+    } else {
+        for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+        for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
+    }
     if (tid == 0) {
         L.nrec = 0;
         F.n_ovf = 0;
@@ -549,8 +566,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         // north-west corner within [x0 - 2, x0 + TW] x [y0 - 2, y0 + TH]: its winner corner can be a pixel of tile + halo
         const bool in_z = ok & ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2));
         // ... within [x0 - 1, x0 + TW - 1] x [y0 - 1, y0 + TH - 1] and touching the image: it can colour a tile pixel
+        // (PASS_IN_IMAGE: a PLACED point -- k_place kept its position only if a corner lies inside the image and wrote PLACE_NONE
+        // otherwise, which fails the range test: the two image tests are those of place_point_begin over again)
         const bool in_r = ok & ((unsigned) (rx - 1) <= (unsigned) TW) & ((unsigned) (ry - 1) <= (unsigned) TH) &
-                          ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H);
+                          ((flags & PASS_IN_IMAGE) ? true : ((unsigned) (p.nwx + 1) <= (unsigned) W) & ((unsigned) (p.nwy + 1) <= (unsigned) H));
 #if defined(KBE_FRAME_STATS)
         { const unsigned long long mz = __ballot(in_z); if (lane == 0 && (flags & PASS_Z)) atomicAdd(&g_frame_stats[3], (unsigned long long) __popcll(mz)); }
 #endif
@@ -593,6 +612,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         }
     };
 
+#ifndef KBE_PLACED_IN_IMAGE
+#define KBE_PLACED_IN_IMAGE 1
+#endif
+    constexpr int KBE_PASS_PLACED = KBE_PLACED_IN_IMAGE ? PASS_IN_IMAGE : 0;
     // ---- the normal path: the points of the listed sub-blocks, their placements and colours requested above (a 96- and a
     // 128-bit load per point).  About a third of the points are near misses that belong to a neighbouring tile: they cost
     // a floor and a range test.  Records beyond REC_CAP (a few tiles in a hundred: two surfaces over one another at a depth
@@ -608,8 +631,8 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             for (int d = 0; d < DEPTH; d++)
                 if (st0 + d * WAVES < n_steps) {
                     const bool valid = (st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub < n_cand;
-                    if (LAZY) placed_point(PASS_Z | PASS_INSERT | PASS_SPILL, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                    else placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
+                    if (LAZY) placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | KBE_PASS_PLACED, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                    else placed_point(PASS_Z | PASS_INSERT | PASS_SPILL | PASS_COLOUR | KBE_PASS_PLACED, pl[d].ox, pl[d].oy, pl[d].err, valid, ix[d], 0, make_float4(cc[d].r, cc[d].g, cc[d].b, cc[d].depth));
                 }
             if (more) fetch_points();
         }
@@ -640,6 +663,16 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     // one decision per tile whether the fp32-only degrid and z test apply
     auto decode_z = [&]() {
         bool band = true;
+        if (KBE_LDS_WIDE) {
+            // four keys per thread (the first 153 threads); the band test on the keys, which order as the floats do: smallest and
+            // largest of the four against the keys of the band's ends
+            if (tid < ZK4) {
+                const uint4 k = ((const uint4*) zk)[tid];
+                ((float4*) L.zpre)[tid] = make_float4(zkey_decode(k.x), zkey_decode(k.y), zkey_decode(k.z), zkey_decode(k.w));
+                const uint32_t lo = min(min(k.x, k.y), min(k.z, k.w)), hi = max(max(k.x, k.y), max(k.z, k.w));
+                band = (lo >= zkey_encode(524288.0f)) & (hi <= zkey_encode(1000000.0f));          // degrid_fast_ok of all four
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < ZPER; u++) {
             const int i = tid + u * TILE_THREADS;
@@ -648,6 +681,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 L.zpre[i] = z;
                 band = band && degrid_fast_ok(z);
             }
+        }
         }
         const unsigned long long odd = __ballot(!band);
         if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;

@@ -202,7 +202,8 @@ struct PixAcc { f2 rg, bd; float w; };
 struct TileLds {
     float4 rec[REC_CAP + 1];    // ox, oy, dblError, link to the next record of the bin; slot REC_DUMMY: see gather
     float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time
-    int head[BH * BW];          // link to the first record of each bin.  A link is the record's BYTE offset, REC_NULL = none
+    int head[(BH * BW + 3) & ~3];   // link to the first record of each bin.  A link is the record's BYTE offset, REC_NULL = none (rounded up to whole
+                                // 16-byte words, so that this array and the next can be written four entries at a time: KBE_LDS_WIDE)
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo; after the degrid: uint8 staging area + per-wave partials
     float zee[TH * TW];         // degridded z-buffer
     int nrec;
@@ -444,7 +445,22 @@ __device__ __forceinline__ void tile_epilogue(const Args& a, TileLds& L, PixAcc 
     }
     // uint8 rows leave as dwords when the row segment is 4-byte aligned and complete
     const bool dword_rows = (W & 3) == 0 && (TW * 3) % 4 == 0 && x0 + TW <= W;
-    if (dword_rows) {
+#ifndef KBE_EPILOGUE_WIDE
+#define KBE_EPILOGUE_WIDE 1
+#endif
+    if (KBE_EPILOGUE_WIDE && (W & 15) == 0 && (TW * 3) % 16 == 0 && x0 + TW <= W && ((uintptr_t) a.frame & 15) == 0) {
+        // ... as 16-byte words where the row segments are 16-byte aligned (a tile row is 96 bytes: six of them): 96 stores for the
+        // tile, by the workgroup's LAST threads (the z decode in front of the degrid is the first threads' work) -- a trip for 96
+        // threads instead of two trips with their index arithmetic for all 256
+        constexpr int Q_PER_ROW = TW * 3 / 16;
+        static_assert(TH * Q_PER_ROW <= TILE_THREADS, "one 16-byte store per thread");
+        const int i = TILE_THREADS - 1 - tid;
+        if (i < TH * Q_PER_ROW) {
+            const int ly = i / Q_PER_ROW, k = i - ly * Q_PER_ROW;
+            if (y0 + ly < H)
+                *(uint4*) (a.frame + ((__umul24((uint32_t) (y0 + ly), (uint32_t) W) + (uint32_t) x0) * 3u + 16u * (uint32_t) k)) = ((const uint4*) s_u8)[ly * Q_PER_ROW + k];
+        }
+    } else if (dword_rows) {
         constexpr int DW_PER_ROW = TW * 3 / 4;
         for (int i = tid; i < TH * DW_PER_ROW; i += TILE_THREADS) {
             const int ly = i / DW_PER_ROW, k = i - ly * DW_PER_ROW;

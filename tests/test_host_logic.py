@@ -285,9 +285,9 @@ def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     zoom = [(512.0 - 40.0 * i, (0.0, 0.0, -20.0 * i)) for i in range(8)]
     inpainted = {'W': 1024, 'H': 1024, 'N': 1137109, 'cloud_focal': 512.0, 'fused': True}
     raw = {'W': 1024, 'H': 1024, 'N': 1048576, 'cloud_focal': 512.0, 'fused': True}
-    # the fused route: four frames per launch left in HBM, eight where the link binds (KBE_VIDEO_GROUP: bits 5-8); a zoom-out takes
+    # the fused route: four frames per launch left in HBM, twelve where the link binds (KBE_VIDEO_GROUP: bits 5-8); a zoom-out takes
     # the bucket route
-    assert shape(inpainted, still) == (3 << 1, 4, True) and shape(inpainted, still, to_host=True) == (7 << 5, 8, True)
+    assert shape(inpainted, still) == (3 << 1, 4, True) and shape(inpainted, still, to_host=True) == (11 << 5, 12, True)
     assert shape(inpainted, zoom) == (0, 1, False)
     assert shape(raw, still) == (3 << 1, 4, True)
     assert shape(raw, zoom) == (1 | (3 << 1), 4, False)
