@@ -87,8 +87,11 @@ def measured_traffic(workload=''):
     if not files:
         return {}, None
     try:
-        k = json.load(open(files[-1]))['kernels']
-        return {name: v['hbm_bytes'] for name, v in k.items()}, os.path.relpath(files[-1], ROOT)
+        doc = json.load(open(files[-1]))
+        per = {name: v['hbm_bytes'] for name, v in doc['kernels'].items()}
+        # the group launches by frames per launch (tools/pmc_group_report.py): {'k_frame_group_ahead': {'12': {...}}}
+        per['by_frames_per_launch'] = {k: v for k, v in doc.get('by_frames_per_launch', {}).items() if isinstance(v, dict)}
+        return per, os.path.relpath(files[-1], ROOT)
     except Exception:
         return {}, None
 
@@ -101,7 +104,10 @@ def measured_instructions():
     if not files:
         return {}, None
     try:
-        return json.load(open(files[-1]))['kernels'], os.path.relpath(files[-1], ROOT)
+        doc = json.load(open(files[-1]))
+        per = dict(doc['kernels'])
+        per['by_frames_per_launch'] = {k: v for k, v in doc.get('by_frames_per_launch', {}).items() if isinstance(v, dict)}
+        return per, os.path.relpath(files[-1], ROOT)
     except Exception:
         return {}, None
 
@@ -672,14 +678,24 @@ def main():
             r = r.split(':')[0]
             t = kt[r + (':scatter_group' if frames > 1 else ':scatter') + ('_ahead' if one_launch else '')]
             tr = sum(per_kernel[k] for k in names) if all(k in per_kernel for k in names) else None
+            tr_launch = None if tr is None else frames * tr
+            # a group launch measured as such (the frames of a group share their candidate lists: the one-frame launch's figures
+            # times the frames overstate it)
+            group_name = 'k_frame_group_ahead' if one_launch else ('k_frame_group' if names == ['k_place', 'k_frame'] else None)
+            g_traffic = per_kernel.get('by_frames_per_launch', {}).get(group_name, {}).get(str(frames)) if frames > 1 and one_launch else None
+            g_insts = insts.get('by_frames_per_launch', {}).get(group_name, {}).get(str(frames)) if frames > 1 and one_launch else None
+            if g_traffic:
+                tr_launch = g_traffic['hbm_bytes']
             out = {'route': r, 'kernel': ' + '.join(n.replace('k_frame', 'k_frame_group').replace('k_tiles', 'k_tiles_group').replace('k_project', 'k_project_group')
                                                     if frames > 1 else n for n in names), 'frames_per_launch': frames,
                    'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / frames, 2), 'algorithmic_bytes': frames * scatter_bytes,
                    'achieved': frames * scatter_bytes / t / 1e9, 'frac': frames * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
-                   'traffic': None if tr is None else frames * tr}
-            if all(k in insts for k in names):
+                   'traffic': tr_launch}
+            if g_traffic:
+                out['traffic_note'] = 'PMC on launches of %d frames' % frames
+            if g_insts or all(k in insts for k in names):
                 # the other roofline these launches live under: wave-level VALU instructions per frame over the chip's issue rate
-                n_valu = sum(insts[k]['valu'] for k in names)
+                n_valu = g_insts['valu'] / frames if g_insts else sum(insts[k]['valu'] for k in names)
                 out['valu_issue'] = {'insts_per_frame': n_valu, 'us_at_peak': round(n_valu / VALU_ISSUE_PER_US, 2),
                                      'frac': n_valu / VALU_ISSUE_PER_US / (t * 1e6 / frames)}
             return out

@@ -49,6 +49,15 @@ for fused in 1 0; do
   KBE_FUSED=$fused KBE_LANES=1 KBE_FILL_GROUP=1 FRAMES=17 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/pi_$fused -o c --output-format csv -- python $R/tools/frame_once.py > $OUT/pmc_insts_$fused.log 2>&1
 done
 python $R/tools/pmc_insts.py /tmp/pi_1/c_counter_collection.csv /tmp/pi_0/c_counter_collection.csv > $OUT/scatter_insts.json
+# 3b'. the scatter's GROUP launches under the same counters (tools/ahead_time.py: 1, 2, 4, 8, 12 frames per launch alone on a stream): what
+# bench.py prices the launch of the timed region with -- the frames of a group share their candidate lists, which the one-frame launch cannot show
+for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" FETCH_SIZE WRITE_SIZE; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rm -rf /tmp/pg_$tag
+  REPS=6 timeout 600 rocprofv3 --pmc $c -d /tmp/pg_$tag -o c --output-format csv -- python $R/tools/ahead_time.py > $OUT/pmc_group_$tag.log 2>&1
+  python $R/tools/pmc_by_grid.py /tmp/pg_$tag/c_counter_collection.csv k_frame_group_ahead k_frame_group --json > $OUT/pmc_group_$tag.json
+done
+python $R/tools/pmc_group_report.py $OUT/pmc_group_SQ_INSTS_VALU.json $OUT/pmc_group_FETCH_SIZE.json $OUT/pmc_group_WRITE_SIZE.json $OUT/hbm_traffic.json $OUT/scatter_insts.json > $OUT/scatter_group_counters.txt
 # 3c. configs[4] on one lane: HBM bytes per launch of its scatter (FETCH_SIZE in 2 KB units, WRITE_SIZE in 1 KB units: tools/pmc_report.py's calibration)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pd_$c
