@@ -25,7 +25,8 @@
  *   - Inputs must be finite.  A point whose projection overflows int range is dropped (the
  *     reference's behaviour there is platform-defined; see DESIGN.md "Deviations").
  *   - Sizes: W*H < 2^31 pixels (2^30 for the frame loop); the frame loop (kbe_render_frame*, kbe_render_video, kbe_render_pointcloud_tiled)
- *     takes clouds of up to 2^30 points and rasters with W, H < 2^24 (its index arithmetic uses 24-bit multiplies).
+ *     takes clouds of up to 2^30 points (2^28 on the packed cloud's route: 32-bit byte offsets) and rasters with W, H < 2^24 (its index
+ *     arithmetic uses 24-bit multiplies).
  *
  * Numerical contract: identical to oracle/kbe_oracle.c (which is pinned bit-for-bit to the
  * reference kernel text): z-buffer and winner indices bit-exact; degrid uses the out-of-place

@@ -30,6 +30,7 @@ DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over 
 FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
                                  # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
                                  # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
+FUSED_MAX_POINTS = 1 << 28       # the packed cloud's route addresses points by 32-bit byte offsets (KBE_FUSED_MAX_POINTS, kbe_tiles.h): larger clouds take the bucket route
 FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
                        # launch's 4 KB of kernel arguments hold.  A launch alone on a stream costs ~5 us besides its frames (ramp and tail: 8 / 12
@@ -300,7 +301,7 @@ class HipKernels:
         # dolly zoom-out (the image shrinks, the density grows along the video) 97 / 151.  KBE_FUSED = auto (default: fused
         # unless the cloud has more than 1.5 points per pixel; render_video also looks at the camera path) | 1 | 0.
         mode = os.environ.get('KBE_FUSED', 'auto')
-        state['fused'] = (N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode != '0'
+        state['fused'] = ((N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode != '0') and N <= FUSED_MAX_POINTS
         state['cloud_focal'] = float(focal) if focal else 512.0
         if state['fused']:
             self._pack(state)

@@ -358,7 +358,7 @@ __device__ __forceinline__ void tiles_body(const TileArgs& a)
         // (24-bit multiply: full rate, the 32-bit one is quarter rate; y, W < 2^24)
         zk[u] = *(const uint32_t*) ((const char*) a.zkeys + ((__umul24((uint32_t) y, (uint32_t) W) + (uint32_t) x) << 2));
     }
-    for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+    lds_reset_heads(L, tid);
     if (tid == 0) {
         L.nrec = 0;
         lds_dummy_record(L);
@@ -387,10 +387,7 @@ __device__ __forceinline__ void tiles_body(const TileArgs& a)
     __syncthreads();
     // one decision per tile: every z of tile + halo in [2^19, 1e6] (any scene whose points are farther than
     // F*B/475712 from the camera) -> fp32-only, branch-free degrid and z test
-    bool fast = true;
-#pragma unroll
-    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
-    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
+    const bool fast = lds_tile_is_fast(L);
     tile_degrid(a, L, tid, x0, y0, fast);
 
     PixAcc acc[PIX_PER_THREAD];
@@ -403,7 +400,7 @@ __device__ __forceinline__ void tiles_body(const TileArgs& a)
             const int n = min(REC_CAP, count - r0);
             if (r0 > 0) {
                 __syncthreads();                                // the previous round's gather is done with the lists
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+                lds_reset_heads(L, tid);
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const int i = tid + u * TILE_THREADS;
@@ -473,7 +470,7 @@ __device__ __forceinline__ void tiles_body(const TileArgs& a)
             if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
                 gather<false>(a, L, tid, x0, y0, acc);
                 __syncthreads();
-                for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
+                lds_reset_heads(L, tid);
                 if (tid == 0) L.nrec = 0;
                 __syncthreads();
             }
@@ -591,10 +588,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
     }
     if (tid == 0) lds_dummy_record(L);
     __syncthreads();
-    bool fast = true;
-#pragma unroll
-    for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
-    fast = (bool) __builtin_amdgcn_readfirstlane((int) fast);
+    const bool fast = lds_tile_is_fast(L);
     for (int i = tid; i < TH * TW; i += TILE_THREADS) {
         const int ly = i / TW, lx = i - ly * TW;
         const int x = x0 + lx, y = y0 + ly;
@@ -622,7 +616,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                     cc[u] = fetch_chunk(a, i < n ? __float_as_int(rr[u].w) : 0, c0);
                 }
                 __syncthreads();                                        // zee written / the previous gather is done with the lists
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+                lds_reset_heads(L, tid);
                 __syncthreads();
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
@@ -637,7 +631,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
             // the bucket overflowed (an extreme pile-up of points on this tile): re-derive the tile's records from the
             // whole cloud, REC_CAP at a time.  Slow, but any cloud renders correctly.
             __syncthreads();
-            for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
+            lds_reset_heads(L, tid);
             if (tid == 0) L.nrec = 0;
             __syncthreads();
             const int n_round = (a.N + TILE_THREADS - 1) / TILE_THREADS * TILE_THREADS;
@@ -667,7 +661,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_
                 if (L.nrec + TILE_THREADS > REC_CAP || i0 + TILE_THREADS >= n_round) {      // uniform
                     gather<false>(a, L, tid, x0, y0, acc);
                     __syncthreads();
-                    for (int j = tid; j < BH * BW; j += TILE_THREADS) L.head[j] = REC_NULL;
+                    lds_reset_heads(L, tid);
                     if (tid == 0) L.nrec = 0;
                     __syncthreads();
                 }
@@ -941,7 +935,7 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
                            const float* shift3, void* scratch, uint8_t* frame_u8, float* render_f32, float* existing_f32,
                            float* zee_f32, float* zee_pre_f32, int stages, const int* fill_rect, int parity, kbe_stream_t stream)
 {
-    KBE_REQUIRE(packed && scratch && frame_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
+    KBE_REQUIRE(packed && scratch && frame_u8 && N >= 0 && N <= KBE_FUSED_MAX_POINTS && W > 0 && H > 0 && (size_t) W * H <= (1u << 30) &&
                 W < (1 << 24) && H < (1 << 24) && ((uintptr_t) scratch & 15) == 0 && cloud_focal > 0.0 && parity >= -1 && parity <= 1,
                 "kbe_render_frame_fused: bad arguments");
     static const FillDirs dirs = make_fill_dirs();
@@ -978,7 +972,7 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
                                  const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* parities, int stages,
                                  const int* fill_rect, kbe_stream_t stream)
 {
-    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && N >= 0 && N <= KBE_FUSED_MAX_POINTS && W > 0 && H > 0 &&
                 (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_fused: bad arguments");
     static const FillDirs dirs = make_fill_dirs();
     const hipStream_t s = (hipStream_t) stream;
@@ -1024,7 +1018,7 @@ int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, 
                                  const double* next_focals, const float* next_shifts, void* const* next_scratch, const int* next_turns, int stages,
                                  const int* fill_rect, kbe_stream_t stream)
 {
-    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && turns && N >= 0 && N <= (1 << 30) && W > 0 && H > 0 &&
+    KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && turns && N >= 0 && N <= KBE_FUSED_MAX_POINTS && W > 0 && H > 0 &&
                 (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_ahead: bad arguments");
     KBE_REQUIRE(n_next >= 0 && n_next <= KBE_FRAME_JOBS && (n_next == 0 || (next_focals && next_shifts && next_scratch && next_turns)), "kbe_render_frame_group_ahead: bad next group");
     KBE_REQUIRE(n_next == 0 || fused_can_place_ahead(N, W, H, n_frames, n_next), "kbe_render_frame_group_ahead: too many placements for the tile launch (kbe_render_frame_group_ahead_ok)");
@@ -1138,6 +1132,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     const int wide_group = ((flags >> 5) & 15) + 1;
     const int group = batch <= 0 ? (wide_group > 1 ? wide_group : ((flags >> 1) & 3) + 1) : 1;
     KBE_REQUIRE(group <= (packed ? KBE_FRAME_JOBS : KBE_FILL_JOBS), "kbe_render_video: more frames per launch than the route's launches take");
+    KBE_REQUIRE(!packed || N <= KBE_FUSED_MAX_POINTS, "kbe_render_video: the packed cloud's route takes up to 2^28 points (more: the plain cloud's route)");
     // the fused route always takes the group form (one frame per launch is a group of one): its tile launches also make the
     // placements of the lane's NEXT group (launch_frames_fused) unless KBE_VIDEO_NO_AHEAD says otherwise
     const bool pairs = group > 1 || (packed && batch <= 0);

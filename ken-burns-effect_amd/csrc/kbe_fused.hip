@@ -210,6 +210,19 @@ struct ListSlot { int t, pos; };
 #ifndef KBE_SHARED_LISTS
 #define KBE_SHARED_LISTS 1
 #endif
+// 32-bit byte offsets on the launch's uniform bases (placements, points, colours): with a signed index every such address was a
+// sign extension, a 64-bit multiply-add and a 64-bit add.  The route takes at most 2^28 points (KBE_FUSED_MAX_POINTS): x 16 fits.
+#ifndef KBE_OFFSETS_32
+#define KBE_OFFSETS_32 1
+#endif
+template <class T> __device__ __forceinline__ T* at_offset32(T* base, uint32_t index)
+{
+    return KBE_OFFSETS_32 ? (T*) ((char*) base + index * (uint32_t) sizeof(T)) : base + (int) index;
+}
+template <class T> __device__ __forceinline__ const T* at_offset32(const T* base, uint32_t index)
+{
+    return KBE_OFFSETS_32 ? (const T*) ((const char*) base + index * (uint32_t) sizeof(T)) : base + (int) index;
+}
 struct ShareMode { int mode; float dsx, dsy, dsz; };         // dsx, dsy, dsz: the last camera's shift minus this (the first) one's
 constexpr float SHARE_MARGIN = 0.25f;
 __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
@@ -226,7 +239,7 @@ __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i
     pl.ox = ok ? ox : PLACE_NONE;
     pl.oy = ok ? oy : PLACE_NONE;
     pl.err = project_err_fast(cam, ok ? z : 1024.0f);
-    place[i] = pl;
+    *at_offset32(place, (uint32_t) i) = pl;
     int nex = nwx, ney = nwy;                                   // the corner's range over the frames the list serves: [nwx, nex] x [nwy, ney]
     if (KBE_SHARED_LISTS && share.mode == 1) return owed;       // uniform
     if (KBE_SHARED_LISTS && share.mode == 2) {
@@ -400,11 +413,11 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
         const ShareMode share = share_mode(nx, n_next, j, shared);
         const int u0 = first + (j == (int) blockIdx.y ? units_up_front * step : 0);      // (the row's first frame: its first units were placed up front)
         if (u0 >= n_units) continue;
-        CloudPoint p = pd[u0 * kCloudBlock + lane];
+        CloudPoint p = *at_offset32(pd, (uint32_t) (u0 * kCloudBlock + lane));
         for (int u = u0; u < n_units; u += step) {                      // wave-uniform; the next unit's point requested before this one is worked on
             const CloudPoint q = p;
             const int un = u + step < n_units ? u + step : u;
-            p = pd[un * kCloudBlock + lane];
+            p = *at_offset32(pd, (uint32_t) (un * kCloudBlock + lane));
             place_point(q, u * kCloudBlock + lane, lane, cam, tiles_x, tiles_y, place, tile_count, cand, bin_flag, share);
         }
     }
@@ -463,14 +476,22 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     Placement pl[DEPTH]; CloudColour cc[DEPTH]; int ix[DEPTH], ent[DEPTH];
     auto fetch_entries = [&](int st0) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[min((st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub, LIST_CAP - 1)];
+        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[(uint32_t) min((st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub, LIST_CAP - 1)];
     };
     auto fetch_points = [&]() {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             ix[d] = (int) (min((uint32_t) ent[d], last_sub) * kCloudSub) + (lane & (kCloudSub - 1));
+#if KBE_OFFSETS_32
+            // (32-bit byte offsets on the launch's uniform bases: as `place[ix]` with a signed index every address was a sign extension,
+            // a 64-bit multiply-add and a 64-bit add; the packed cloud holds at most 2^26 points -- cloud_open -- so x 16 fits)
+            const uint32_t o16 = (uint32_t) ix[d] << 4;
+            pl[d] = *(const Placement*) ((const char*) place + (o16 - (o16 >> 2)));
+            if (!LAZY) cc[d] = *(const CloudColour*) ((const char*) colours + o16);
+#else
             pl[d] = place[ix[d]];
             if (!LAZY) cc[d] = colours[ix[d]];
+#endif
         }
     };
     fetch_entries(wave);
@@ -486,7 +507,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     CloudPoint a_pt[NU > 0 ? NU : 1];
     ListSlot a_owed[NU > 0 ? NU : 1];
 #pragma unroll
-    for (int d = 0; d < NU; d++) a_pt[d] = pcp->pd[min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane];
+    for (int d = 0; d < NU; d++) a_pt[d] = *at_offset32(pcp->pd, (uint32_t) (min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane));
     auto ahead_finish = [&]() {
         if (ahead) {
             int* const cand_next = ((PlaceArgsPtr) jp->nx + blockIdx.y)->cand;
@@ -510,7 +531,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         else ((uint4*) zk)[tid - HEAD4] = emp4;
         if (tid < ZK4 - (TILE_THREADS - HEAD4)) ((uint4*) zk)[TILE_THREADS - HEAD4 + tid] = emp4;
     } else {
-        for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+        lds_reset_heads(L, tid);
         for (int i = tid; i < KH * KW; i += TILE_THREADS) zk[i] = KBE_ZKEY_EMPTY;             // common.py:430
     }
     if (tid == 0) {
@@ -686,12 +707,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         const unsigned long long odd = __ballot(!band);
         if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
     };
-    auto tile_is_fast = [&]() {
-        bool fast = true;
-#pragma unroll
-        for (int w = 0; w < TILE_THREADS / 64; w++) fast = fast && L.odd_z[w] == 0;
-        return (bool) __builtin_amdgcn_readfirstlane((int) fast);
-    };
+    auto tile_is_fast = [&]() { return lds_tile_is_fast(L); };
     auto fetch_rgbd = [&](int id) {
         const CloudColour c = colours[id];
         return make_float4(c.r, c.g, c.b, c.depth);
@@ -741,7 +757,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         for (int r0 = 0; r0 < n_spill; r0 += REC_CAP) {         // uniform
             const int n = min(REC_CAP, n_spill - r0);
             __syncthreads();                                    // the previous gather is done with the lists
-            for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+            lds_reset_heads(L, tid);
             float4 rr[PER], cc[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -821,7 +837,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             if (state == S_ZWIN) flags = PASS_Z;
             else if (state == S_COUNT) flags = PASS_COUNT;
             else if (state == S_RUN) {
-                for (int i = tid; i < BH * BW; i += TILE_THREADS) L.head[i] = REC_NULL;
+                lds_reset_heads(L, tid);
                 if (tid == 0) { L.nrec = 0; F.run_end = n_win; }
                 __syncthreads();
                 // the run ends in front of the first candidate whose prefix sum exceeds done + REC_CAP

@@ -134,6 +134,7 @@ constexpr int KBE_FILL_JOBS = 4;
 #ifndef KBE_FRAME_JOBS_MAX
 #define KBE_FRAME_JOBS_MAX 12        // (12 x sizeof(FrameArgs) = 3.8 KB of kernel arguments: the launch takes 4 KB)
 #endif
+constexpr int KBE_FUSED_MAX_POINTS = 1 << 28;     // the packed cloud's route addresses a point's 16 bytes by a 32-bit byte offset (kbe_fused.hip: KBE_OFFSETS_32)
 constexpr int KBE_FRAME_JOBS = KBE_FRAME_JOBS_MAX;      // frames a launch of the fused scatter (k_place, k_frame) takes at most
 struct FillTarget {                 // a frame to be filled, on the host
     Scratch sc;
@@ -206,9 +207,16 @@ struct TileLds {
                                 // 16-byte words, so that this array and the next can be written four entries at a time: KBE_LDS_WIDE)
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo; after the degrid: uint8 staging area + per-wave partials
     float zee[TH * TW];         // degridded z-buffer
+    int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code); 16-byte aligned: read as one word
     int nrec;
-    int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code)
 };
+static_assert(TILE_THREADS / 64 == 4 && offsetof(TileLds, odd_z) % 16 == 0, "the four waves' flags are one 16-byte word");
+// every z of tile + halo in the band (all four waves say so): wave-uniform
+__device__ __forceinline__ bool lds_tile_is_fast(const TileLds& L)
+{
+    const int4 o = *(const int4*) L.odd_z;
+    return (bool) __builtin_amdgcn_readfirstlane((int) ((o.x | o.y | o.z | o.w) == 0));
+}
 
 constexpr int REC_DUMMY = REC_CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, its own successor
 constexpr int REC_NULL = REC_DUMMY * 16;    // "no record" as a link: the dummy's byte offset, so that every link can be read as it is
@@ -217,6 +225,14 @@ __device__ __forceinline__ void lds_dummy_record(TileLds& L)
 {
     L.rec[REC_DUMMY] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(REC_NULL));
     L.rgbd[REC_DUMMY] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// every bin's list emptied: 141 16-byte stores by the workgroup's first threads (the array is padded to whole 16-byte words) instead
+// of three trips of single stores with their bound tests for all 256
+__device__ __forceinline__ void lds_reset_heads(TileLds& L, int tid)
+{
+    static_assert(sizeof(L.head) % 16 == 0 && offsetof(TileLds, head) % 16 == 0 && sizeof(L.head) / 16 <= TILE_THREADS, "one 16-byte store per thread");
+    if (tid < (int) (sizeof(L.head) / 16)) ((int4*) L.head)[tid] = make_int4(REC_NULL, REC_NULL, REC_NULL, REC_NULL);
 }
 
 // threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
