@@ -613,7 +613,9 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 // atomic optimizer builds a dozen instructions of lane counting for a case that cannot occur here)
                 int base = lds_add_rtn_uniform(&L.nrec, n_r);
                 const int limit = REC_CAP;
-                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                // (the lanes of `m` below this one: v_mbcnt_lo / _hi on the ballot -- two instructions; written as a population count of
+                // m & lanes-below the compiler makes two ands and two counts of it)
+                const int slot = base + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
                 if (in_r && slot < limit) {
                     const int next = atomicExch((int*) ((char*) L.head + mad_u24((uint32_t) (ry - 1), BW * 4u, (uint32_t) (rx - 1) << 2)), slot << 4);
                     L.rec[slot] = make_float4(ox, oy, err, __int_as_float(next));
@@ -626,7 +628,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                     int sbase = 0;
                     if (lane == 0) sbase = atomicAdd(&F.n_ovf, __popcll(ms));
                     sbase = __builtin_amdgcn_readfirstlane(sbase);
-                    const int o = sbase + __popcll(ms & ((1ull << lane) - 1ull));
+                    const int o = sbase + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
                     if (sp && o < BUCKET_CAP) spill[o] = make_float4(ox, oy, err, __int_as_float(idx));
                 }
             }
