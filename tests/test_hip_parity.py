@@ -973,6 +973,11 @@ def test_invalid_arguments_return_errors_not_crashes(K):
     rc = K.lib.kbe_render_frame_stages(z16, z16, z16, 1, 1 << 24, 1, ctypes.c_double(512.0), ctypes.c_double(120.0), None, z16, z16,
                                        None, None, None, None, 7, None, 0, 0, None)
     assert rc == -1 and b'kbe_render_frame' in K.lib.kbe_last_error()
+    # the packed cloud's route addresses a point's 16 bytes by a 32-bit byte offset: clouds of more than 2^28 points are refused
+    # there (the plain cloud's route takes them: _native.FUSED_MAX_POINTS)
+    rc = K.lib.kbe_render_frame_fused(z16, (1 << 28) + 64, ctypes.c_double(512.0), 64, 64, ctypes.c_double(512.0), ctypes.c_double(120.0), None, z16, z16,
+                                      None, None, None, None, 7, None, -1, None)
+    assert rc == -1 and b'kbe_render_frame_fused' in K.lib.kbe_last_error()
 
 
 @pytest.mark.gpu
