@@ -665,6 +665,56 @@ def test_pipelined_groups_through_the_slow_paths(K, kind):
     assert kind == 'empty' or any(w.any() for w in want), 'the frames show something'
 
 
+@pytest.mark.parametrize('kind', ['rough', 'near_plane'])
+def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, kind):
+    """The frames a tile launch places ahead share ONE set of candidate lists when they are consecutive cameras of a straight
+    path (same focal length, shifts on a line: kbe_fused.hip, launch_frames_fused's `shareable`): a sub-block is listed for the box
+    of its corners under the group's first and last camera.  On clouds where that box is large or has no bound -- a depth map of
+    noise between 3 and 900 under a camera that moves by whole tiles per group ('rough'), and rows of points that pass the near
+    plane INSIDE a group ('near_plane': z between 0.5 and 40, the camera advancing by 4 per frame) -- groups of 12, 5, 12, 2
+    frames, pipelined, render the frames of the same groups with their per-frame lists (placement launches in front)."""
+    g0 = torch.Generator().manual_seed(5)
+    W, H = 160, 120
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    z = 3.0 + 897.0 * torch.rand(H, W, generator=g0) ** 2
+    if kind == 'near_plane':
+        z = 300.0 + 200.0 * torch.rand(H, W, generator=g0)
+        z[20:60] = 0.5 + 39.5 * torch.rand(40, W, generator=g0)
+    pts = torch.stack([(xs - W / 2 + 0.5) * z / 512.0, (ys - H / 2 + 0.5) * z / 512.0, z]).reshape(1, 3, -1)
+    N = W * H
+    img, dep = torch.rand(1, 3, N, generator=g0), torch.rand(1, 1, N, generator=g0) * 500 + 100
+    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+    assert state['fused']
+    K._pack(state)
+    cams = [(512.0, (0.9 * i - 12.0, 6.0 - 0.5 * i, -4.0 * i)) for i in range(31)]       # one straight path, equal steps
+    sizes = [12, 5, 12, 2]
+    groups, at = [], 0
+    for n in sizes:
+        groups.append(cams[at:at + n])
+        at += n
+    want = []
+    for g in groups:
+        buf = torch.zeros(len(g), H, W, 3, dtype=torch.uint8, device='cuda')
+        K.render_frame_group_fused(state, g, 120, buf)
+        want.append(c(buf))
+    for rep in range(2):
+        turns, placed = [0] * 12, False
+        for i, g in enumerate(groups):
+            n = len(g)
+            nxt = groups[i + 1] if i + 1 < len(groups) else None
+            ok = nxt is not None and bool(K.lib.kbe_render_frame_group_ahead_ok(N, W, H, n, len(nxt)))
+            assert ok or nxt is None
+            now = turns[:n]
+            for k in range(n):
+                turns[k] += 1
+            buf = torch.zeros(n, H, W, 3, dtype=torch.uint8, device='cuda')
+            K.render_frame_group_ahead(state, g, 120, buf, turn=now, placed=placed, next_cameras=nxt if ok else None, next_turn=turns[:len(nxt)] if ok else None)
+            placed = ok
+            d = np.abs(c(buf).astype(np.int32) - want[i].astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, '%s, pass %d group %d: max %d, %.2e differ' % (kind, rep, i, d.max(), (d > 0).mean())
+    assert all(w.any() for w in want), 'the frames show something'
+
+
 @pytest.mark.parametrize('group,n_frames,lanes', [('1', 9, '4'), ('2', 7, '2'), ('12', 30, '2'), ('5', 23, '3')])
 def test_video_whose_tile_launches_place_ahead_equals_the_video_with_placement_launches(K, monkeypatch, group, n_frames, lanes):
     """kbe_render_video on the fused route: by default a lane's tile launch makes the placements of the lane's next group;
