@@ -283,7 +283,10 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
  * `next`), else a placement launch is made in front of the tile launch.  n_next > 0: the tile launch makes the placements
  * of the frames next_* (the cameras, sets and turns the next call will render with; a set that both groups use has
  * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
- * than the raster keeps its placement launch).  Everything else as kbe_render_frame_group_fused; same results. */
+ * than the raster keeps its placement launch).  A group placed ahead whose cameras are consecutive steps of ONE straight path
+ * (same focal length, shifts on a line in frame order) shares one set of candidate lists, kept in the scratch set of its first frame:
+ * the library decides that from the cameras alone in both calls, so the `next` cameras of one call must be the cameras of the next
+ * call (they already must).  Everything else as kbe_render_frame_group_fused; same results. */
 KBE_API int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_next);
 KBE_API int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
                                          const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
