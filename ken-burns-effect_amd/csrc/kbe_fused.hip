@@ -1,5 +1,7 @@
 // kbe_fused.hip -- the fused scatter: render_pointcloud (common.py:428-686) of one frame in ONE launch, from the packed
 // cloud (kbe_cloud.h).  Host side: kbe_render_frame_fused / kbe_render_video in kbe_frame.hip, through launch_frame_fused.
+#include <stdlib.h>
+#include <string.h>
 #include "kbe_cloud.h"
 #include "kbe_tiles.h"
 
@@ -92,8 +94,8 @@ template <int J> struct FrameJobsT {
 };
 static_assert(sizeof(FrameJobsT<KBE_FRAME_JOBS>) <= 4096, "a launch takes 4 KB of kernel arguments");
 
-struct FrameLds {
-    TileLds T;
+template <int CAP> struct FrameLdsT {
+    TileLdsT<CAP> T;
     int n_ovf;              // records that did not fit the first round and went to the tile's spill area
     int wave_sum[TILE_THREADS / 64];
     int run_end;
@@ -428,14 +430,16 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
 // UNITS: how many of a wave's units of the next frames' placement are requested with the tile's list and placed up front (the
 // rest behind the epilogue): three for a cloud of about a point per pixel (a wave's share of an equal group is 2.2 units), eight
 // for one much denser than the raster (configs[4]: 8 units per wave)
-template <int J, bool AHEAD, int UNITS = AHEAD_UNITS>
+// CAP: the records the tile holds in LDS at once (REC_CAP, or LEAN_CAP with a sixth workgroup on the CU: below)
+template <int J, bool AHEAD, int UNITS = AHEAD_UNITS, int CAP = REC_CAP>
 __device__ __forceinline__ void frame_body(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
 {
     constexpr bool LAZY = KBE_LAZY_COLOURS == 1 || (KBE_LAZY_COLOURS == 2 && UNITS > AHEAD_UNITS);
     FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
     PackedCloudPtr pcp = &jp->pc;
-    __shared__ FrameLds F;
-    TileLds& L = F.T;
+    typedef TileLdsT<CAP> Lds;
+    __shared__ FrameLdsT<CAP> F;
+    Lds& L = F.T;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_tile_rot(blockIdx.x, gridDim.x, job);
@@ -522,10 +526,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     // a second one for 38 of them, instead of 1 173 single stores in two loops of three trips with their bound tests: a wave's
     // ~25 vector instructions become ~8, on a launch bound by vector issue)
     constexpr int HEAD4 = (int) (sizeof(L.head) / 16), ZK4 = KH * KW / 4;
-    static_assert(!KBE_LDS_WIDE || ((KH * KW) % 4 == 0 && offsetof(TileLds, head) % 16 == 0 && offsetof(TileLds, zpre) % 16 == 0 && sizeof(L.head) % 16 == 0 &&
+    static_assert(!KBE_LDS_WIDE || ((KH * KW) % 4 == 0 && offsetof(Lds, head) % 16 == 0 && offsetof(Lds, zpre) % 16 == 0 && sizeof(L.head) % 16 == 0 &&
                                     HEAD4 <= TILE_THREADS && HEAD4 + ZK4 <= 2 * TILE_THREADS && ZK4 >= TILE_THREADS - HEAD4), "four entries per store");
     if (KBE_LDS_WIDE) {
-        const int4 nul4 = make_int4(REC_NULL, REC_NULL, REC_NULL, REC_NULL);
+        const int4 nul4 = make_int4(Lds::kNull, Lds::kNull, Lds::kNull, Lds::kNull);
         const uint4 emp4 = make_uint4(KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY);               // common.py:430
         if (tid < HEAD4) ((int4*) L.head)[tid] = nul4;
         else ((uint4*) zk)[tid - HEAD4] = emp4;
@@ -612,7 +616,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 // ONE LDS atomic for the wave (written as the instruction: around `if (lane == 0) atomicAdd(..)` the compiler's
                 // atomic optimizer builds a dozen instructions of lane counting for a case that cannot occur here)
                 int base = lds_add_rtn_uniform(&L.nrec, n_r);
-                const int limit = REC_CAP;
+                const int limit = CAP;
                 // (the lanes of `m` below this one: v_mbcnt_lo / _hi on the ballot -- two instructions; written as a population count of
                 // m & lanes-below the compiler makes two ands and two counts of it)
                 const int slot = base + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
@@ -681,7 +685,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 #endif
 
     constexpr int ZPER = (KH * KW + TILE_THREADS - 1) / TILE_THREADS;
-    constexpr int PER = (REC_CAP + TILE_THREADS - 1) / TILE_THREADS;
+    constexpr int PER = (CAP + TILE_THREADS - 1) / TILE_THREADS;
     // keys -> floats in place (a pixel outside the image was never splatted: it reads 1e6 like common.py:430), and the
     // one decision per tile whether the fp32-only degrid and z test apply
     auto decode_z = [&]() {
@@ -727,7 +731,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         // ... or (LAZY: the launch for dense clouds, which is as close to the memory's limit as to the issue rate's) with their
         // points: the colours of the RECORDS only -- the near misses of the candidate list, a third of it, never fetch
         // theirs -- requested here and stored behind the degrid, which needs none of them
-        const int n_held = min(total, REC_CAP);
+        const int n_held = min(total, CAP);
         float4 lc[PER];
         if (LAZY) {
 #pragma unroll
@@ -756,8 +760,8 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         KBE_PROBE(7);
         KBE_STOP_AFTER(5);                                      // (dev) + gather
         // further rounds: the spilled records, REC_CAP at a time (already projected: only lists, colours and the walk)
-        for (int r0 = 0; r0 < n_spill; r0 += REC_CAP) {         // uniform
-            const int n = min(REC_CAP, n_spill - r0);
+        for (int r0 = 0; r0 < n_spill; r0 += CAP) {             // uniform
+            const int n = min(CAP, n_spill - r0);
             __syncthreads();                                    // the previous gather is done with the lists
             lds_reset_heads(L, tid);
             float4 rr[PER], cc[PER];
@@ -844,7 +848,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 __syncthreads();
                 // the run ends in front of the first candidate whose prefix sum exceeds done + REC_CAP
                 for (int c = c0 + tid; c < n_win; c += TILE_THREADS)
-                    if (slow_cnt[c] - done > REC_CAP && (c == c0 || slow_cnt[c - 1] - done <= REC_CAP)) F.run_end = c;
+                    if (slow_cnt[c] - done > CAP && (c == c0 || slow_cnt[c - 1] - done <= CAP)) F.run_end = c;
                 __syncthreads();
                 flags = PASS_INSERT; p0 = c0; p1 = F.run_end;
             }
@@ -876,7 +880,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                 state = n_win > 0 ? S_RUN : S_DONE;
                 if (state == S_DONE && wb + MAXC < n_blocks) { wb += MAXC; state = S_COUNT; }
             } else if (state == S_RUN) {
-                const int n = min(L.nrec, REC_CAP);
+                const int n = min(L.nrec, CAP);
                 for (int i = tid; i < n; i += TILE_THREADS) L.rgbd[i] = fetch_rgbd(__float_as_int(L.rgbd[i].x));
                 __syncthreads();
                 if (fast) gather<true>(a, L, tid, x0, y0, acc);
@@ -933,32 +937,43 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 typedef FrameJobsT<1> FrameJob1;
 typedef FrameJobsT<KBE_FRAME_JOBS> FrameJobs;
 
-// five workgroups per CU (32 KB of LDS each; 96 registers per lane, a few of the gather's spilled): with the tile's list read
-// straight into registers the LDS allows it, and a fifth wave per SIMD covers more of the others' waits than the spills cost
+// Two builds of every tile launch.  ROOMY: REC_CAP records per tile, five workgroups per CU (30.4 KB of LDS each; 96 registers per
+// lane, a few of the gather's spilled) -- with the tile's list read straight into registers the LDS allows it, and a fifth wave per
+// SIMD covers more of the others' waits than the spills cost.  LEAN (round 4's last step; the names without suffix, what a cloud of
+// about a point per pixel takes): LEAN_CAP = 608 records, 26.3 KB -- a SIXTH workgroup per CU at 80 registers per lane (32 spilled).
+// Once the launch's time had become its instruction count, a sixth wave per SIMD paid where it had not
+// before: 15.7 -> 15.0 us per frame at twelve frames per launch on the bench cloud (1.08 points per pixel: a tile reaches 608
+// records on average, so about half of them send a few records through the spill area and take a second round -- and still);
+// a raw cloud (1.0) 14.4 -> 13.4; caps of 576 / 624 measure 15.4 / 15.1, 636 loses the sixth slot (16.1).  Clouds denser than
+// LEAN_MAX_DENSITY points per pixel keep the roomy build (16.8 M points on 2048^2: 287 us per frame roomy, 295 lean).
 #ifndef KBE_FRAME_WAVES
 #define KBE_FRAME_WAVES 5
 #endif
+#ifndef KBE_LEAN_CAP
+#define KBE_LEAN_CAP 608
+#endif
+#ifndef KBE_LEAN_WAVES
+#define KBE_LEAN_WAVES 6
+#endif
+#ifndef KBE_LEAN_MAX_DENSITY
+#define KBE_LEAN_MAX_DENSITY 1.125
+#endif
+constexpr int LEAN_CAP = KBE_LEAN_CAP;
+static_assert(LEAN_CAP >= TILE_THREADS && LEAN_CAP <= REC_CAP, "the lean build holds fewer records than the scratch's tiles are laid out for");
 #define KBE_FRAME_ATTR amdgpu_waves_per_eu(KBE_FRAME_WAVES, KBE_FRAME_WAVES)
+#define KBE_LEAN_ATTR amdgpu_waves_per_eu(KBE_LEAN_WAVES, KBE_LEAN_WAVES)
+#define KBE_ARGS(T) ((const __attribute__((address_space(4))) T*) __builtin_amdgcn_kernarg_segment_ptr())      // the one argument, at offset 0
 
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame(FrameJob1)
-{
-    frame_body<1, false>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);    // the one argument, at offset 0
-}
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_ahead(FrameJob1)
-{
-    frame_body<1, true>((const __attribute__((address_space(4))) FrameJob1*) __builtin_amdgcn_kernarg_segment_ptr(), 0);
-}
-
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_LEAN_ATTR)) k_frame(FrameJob1) { frame_body<1, false, AHEAD_UNITS, LEAN_CAP>(KBE_ARGS(FrameJob1), 0); }
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_roomy(FrameJob1) { frame_body<1, false>(KBE_ARGS(FrameJob1), 0); }
+// AHEAD: ... that also make the placements of the frames the next tile launch renders
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_LEAN_ATTR)) k_frame_ahead(FrameJob1) { frame_body<1, true, AHEAD_UNITS, LEAN_CAP>(KBE_ARGS(FrameJob1), 0); }
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_ahead_roomy(FrameJob1) { frame_body<1, true>(KBE_ARGS(FrameJob1), 0); }
 // several frames of the same cloud and size per launch (blockIdx.y = the frame), as the bucket route's grouped launches
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group(FrameJobs)
-{
-    frame_body<KBE_FRAME_JOBS, false>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
-}
-// ... that also make the placements of the frames the next tile launch renders
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_ahead(FrameJobs)
-{
-    frame_body<KBE_FRAME_JOBS, true>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
-}
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_LEAN_ATTR)) k_frame_group(FrameJobs) { frame_body<KBE_FRAME_JOBS, false, AHEAD_UNITS, LEAN_CAP>(KBE_ARGS(FrameJobs), blockIdx.y); }
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_roomy(FrameJobs) { frame_body<KBE_FRAME_JOBS, false>(KBE_ARGS(FrameJobs), blockIdx.y); }
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_LEAN_ATTR)) k_frame_group_ahead(FrameJobs) { frame_body<KBE_FRAME_JOBS, true, AHEAD_UNITS, LEAN_CAP>(KBE_ARGS(FrameJobs), blockIdx.y); }
+__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_ahead_roomy(FrameJobs) { frame_body<KBE_FRAME_JOBS, true>(KBE_ARGS(FrameJobs), blockIdx.y); }
 
 // ... for a cloud much denser than the raster: eight units of a wave's placements up front (configs[4], 16.8 M points on a 2048^2
 // raster: 8 units per wave; the placement launch of its own that such a cloud used to keep waits for memory 70 % of its life --
@@ -966,7 +981,7 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) 
 constexpr int AHEAD_UNITS_DENSE = 8;
 __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) k_frame_group_ahead_dense(FrameJobs)
 {
-    frame_body<KBE_FRAME_JOBS, true, AHEAD_UNITS_DENSE>((const __attribute__((address_space(4))) FrameJobs*) __builtin_amdgcn_kernarg_segment_ptr(), blockIdx.y);
+    frame_body<KBE_FRAME_JOBS, true, AHEAD_UNITS_DENSE>(KBE_ARGS(FrameJobs), blockIdx.y);
 }
 
 }  // namespace
@@ -1062,18 +1077,23 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
     if (shared_now)         // every frame reads the lists the group's first frame's set holds
         for (int k = 1; k < KBE_FRAME_JOBS; k++) { fj.a[k].tile_count = fj.a[0].tile_count; fj.a[k].cand = fj.a[0].cand; fj.a[k].bin_flag = fj.a[0].bin_flag; fj.a[k].bin_flag_next = fj.a[0].bin_flag_next; }
     if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
+    // the lean build (608 records per tile, six workgroups per CU) for clouds of about a point per pixel, the roomy one beyond
+    // (KBE_FUSED_CAP=lean / roomy: a switch for tests and measurements, read at every launch)
+    const char* const cap_env = getenv("KBE_FUSED_CAP");
+    const int forced = !cap_env ? 0 : (!strcmp(cap_env, "lean") ? 1 : (!strcmp(cap_env, "roomy") ? 2 : 0));
+    const Scratch& sc0 = t[0].sc;
+    const bool lean = forced ? forced == 1 : (double) pc.Np <= KBE_LEAN_MAX_DENSITY * (double) t[0].cam.W * (double) t[0].cam.H;
     if (n == 1 && n_next <= 1) {
         FrameJob1 f1;
         f1.pc = pc; f1.n_next = n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
-        if (n_next) hipLaunchKernelGGL(k_frame_ahead, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
-        else hipLaunchKernelGGL(k_frame, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
+        if (n_next) hipLaunchKernelGGL(lean ? k_frame_ahead : k_frame_ahead_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
+        else hipLaunchKernelGGL(lean ? k_frame : k_frame_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
     } else if (n_next) {                                                        // (also: one frame that places several)
-        const Scratch& sc0 = t[0].sc;
         const bool dense = ahead_units_per_wave(N, sc0.tiles_x * TW, sc0.tiles_y * TH, n, n_next) > (size_t) AHEAD_UNITS + 1;
         if (dense) hipLaunchKernelGGL(k_frame_group_ahead_dense, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
-        else hipLaunchKernelGGL(k_frame_group_ahead, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+        else hipLaunchKernelGGL(lean ? k_frame_group_ahead : k_frame_group_ahead_roomy, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
     }
-    else hipLaunchKernelGGL(k_frame_group, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+    else hipLaunchKernelGGL(lean ? k_frame_group : k_frame_group_roomy, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe

@@ -200,43 +200,51 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // a pixel's five accumulators; r|g and b|depth as pairs so that they update with packed fp32 instructions
 struct PixAcc { f2 rg, bd; float w; };
 
-struct TileLds {
-    float4 rec[REC_CAP + 1];    // ox, oy, dblError, link to the next record of the bin; slot REC_DUMMY: see gather
-    float4 rgbd[REC_CAP + 1];   // the point's r, g, b, depth, fetched once at insert time
-    int head[(BH * BW + 3) & ~3];   // link to the first record of each bin.  A link is the record's BYTE offset, REC_NULL = none (rounded up to whole
+// CAP: records the tile holds at once.  The scratch, the bucket route and the fused route's launches for clouds denser than the
+// raster use REC_CAP (TileLds); the fused route's launches for clouds of about a point per pixel use a smaller one and run six
+// workgroups per CU instead of five (kbe_fused.hip: LEAN_CAP).
+template <int CAP> struct TileLdsT {
+    static constexpr int kCap = CAP;
+    static constexpr int kDummy = CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, its own successor
+    static constexpr int kNull = CAP * 16;      // "no record" as a link: the dummy's byte offset, so that every link can be read as it is
+    float4 rec[CAP + 1];        // ox, oy, dblError, link to the next record of the bin; slot kDummy: see gather
+    float4 rgbd[CAP + 1];       // the point's r, g, b, depth, fetched once at insert time
+    int head[(BH * BW + 3) & ~3];   // link to the first record of each bin.  A link is the record's BYTE offset, kNull = none (rounded up to whole
                                 // 16-byte words, so that this array and the next can be written four entries at a time: KBE_LDS_WIDE)
     float zpre[KH * KW];        // z-buffer before degrid, tile + halo; after the degrid: uint8 staging area + per-wave partials
     float zee[TH * TW];         // degridded z-buffer
     int odd_z[TILE_THREADS / 64];   // per wave: some z of tile + halo is outside [2^19, 1e6] (then: the generic, fp64-capable code); 16-byte aligned: read as one word
     int nrec;
 };
+typedef TileLdsT<REC_CAP> TileLds;
 static_assert(TILE_THREADS / 64 == 4 && offsetof(TileLds, odd_z) % 16 == 0, "the four waves' flags are one 16-byte word");
 // every z of tile + halo in the band (all four waves say so): wave-uniform
-__device__ __forceinline__ bool lds_tile_is_fast(const TileLds& L)
+template <class LDS> __device__ __forceinline__ bool lds_tile_is_fast(const LDS& L)
 {
+    static_assert(offsetof(LDS, odd_z) % 16 == 0, "the four waves' flags are one 16-byte word");
     const int4 o = *(const int4*) L.odd_z;
     return (bool) __builtin_amdgcn_readfirstlane((int) ((o.x | o.y | o.z | o.w) == 0));
 }
 
-constexpr int REC_DUMMY = REC_CAP;          // what an exhausted list reads: dblError = +inf (fails every z test), colours 0, its own successor
-constexpr int REC_NULL = REC_DUMMY * 16;    // "no record" as a link: the dummy's byte offset, so that every link can be read as it is
+constexpr int REC_DUMMY = TileLds::kDummy;
+constexpr int REC_NULL = TileLds::kNull;
 
-__device__ __forceinline__ void lds_dummy_record(TileLds& L)
+template <class LDS> __device__ __forceinline__ void lds_dummy_record(LDS& L)
 {
-    L.rec[REC_DUMMY] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(REC_NULL));
-    L.rgbd[REC_DUMMY] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    L.rec[LDS::kDummy] = make_float4(0.0f, 0.0f, __builtin_inff(), __int_as_float(LDS::kNull));
+    L.rgbd[LDS::kDummy] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // every bin's list emptied: 141 16-byte stores by the workgroup's first threads (the array is padded to whole 16-byte words) instead
 // of three trips of single stores with their bound tests for all 256
-__device__ __forceinline__ void lds_reset_heads(TileLds& L, int tid)
+template <class LDS> __device__ __forceinline__ void lds_reset_heads(LDS& L, int tid)
 {
-    static_assert(sizeof(L.head) % 16 == 0 && offsetof(TileLds, head) % 16 == 0 && sizeof(L.head) / 16 <= TILE_THREADS, "one 16-byte store per thread");
-    if (tid < (int) (sizeof(L.head) / 16)) ((int4*) L.head)[tid] = make_int4(REC_NULL, REC_NULL, REC_NULL, REC_NULL);
+    static_assert(sizeof(L.head) % 16 == 0 && offsetof(LDS, head) % 16 == 0 && sizeof(L.head) / 16 <= TILE_THREADS, "one 16-byte store per thread");
+    if (tid < (int) (sizeof(L.head) / 16)) ((int4*) L.head)[tid] = make_int4(LDS::kNull, LDS::kNull, LDS::kNull, LDS::kNull);
 }
 
 // threads one record into the list of its bin (bin = north-west corner relative to x0-1, y0-1)
-__device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float oy, float err, const float4& rgbd, int x0, int y0)
+template <class LDS> __device__ __forceinline__ void lds_insert(LDS& L, int idx, float ox, float oy, float err, const float4& rgbd, int x0, int y0)
 {
     const int bx = (int) floorf(ox) - (x0 - 1), by = (int) floorf(oy) - (y0 - 1);
     L.rgbd[idx] = rgbd;
@@ -260,8 +268,8 @@ __device__ __forceinline__ void lds_insert(TileLds& L, int idx, float ox, float 
 #ifndef KBE_GATHER_PORT2
 #define KBE_GATHER_PORT2 0
 #endif
-template <bool FAST, class Args>
-__device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid, int x0, int y0,
+template <bool FAST, class Args, class LDS>
+__device__ __forceinline__ void gather(const Args& a, const LDS& L, int tid, int x0, int y0,
                                        PixAcc (&acc)[PIX_PER_THREAD])
 {
 #pragma unroll
@@ -325,7 +333,7 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
                 add(k, r[k], c[k]);
                 nx[k] = __float_as_int(r[k].w);
             }
-        } while (min(min(nx[0], nx[1]), min(nx[2], nx[3])) < REC_NULL);      // some list goes on
+        } while (min(min(nx[0], nx[1]), min(nx[2], nx[3])) < LDS::kNull);      // some list goes on
         if (FAST && KBE_GATHER_PORT2 >= 1) { acc[m].rg.x = ar; acc[m].rg.y = ag; acc[m].bd.x = ab; acc[m].bd.y = ad; acc[m].w = aw; }
     }
 }
@@ -333,8 +341,8 @@ __device__ __forceinline__ void gather(const Args& a, const TileLds& L, int tid,
 
 // degrid (common.py:525-568), out of place: L.zpre (tile + halo, decoded) -> L.zee.  `fast`: every z of tile + halo in
 // [2^19, 1e6] (any scene whose points are farther than F*B/475712 from the camera) -> fp32-only, branch-free
-template <class Args>
-__device__ __forceinline__ void tile_degrid(const Args& a, TileLds& L, int tid, int x0, int y0, bool fast)
+template <class Args, class LDS>
+__device__ __forceinline__ void tile_degrid(const Args& a, LDS& L, int tid, int x0, int y0, bool fast)
 {
     const int W = a.cam.W, H = a.cam.H;
     if (fast && !a.zee_pre) {
@@ -366,8 +374,8 @@ __device__ __forceinline__ void tile_degrid(const Args& a, TileLds& L, int tid, 
 
 // resolve + store of a tile whose pixels hold their accumulated sums: normalise (common.py:686), hole mask (:253),
 // uint8 (:255), validity bitmask / bounding box / coarse bits / hole list for the fill, coalesced stores
-template <class Args>
-__device__ __forceinline__ void tile_epilogue(const Args& a, TileLds& L, PixAcc (&acc)[PIX_PER_THREAD], int tile, int x0, int y0)
+template <class Args, class LDS>
+__device__ __forceinline__ void tile_epilogue(const Args& a, LDS& L, PixAcc (&acc)[PIX_PER_THREAD], int tile, int x0, int y0)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = a.cam.W, H = a.cam.H;

@@ -665,6 +665,53 @@ def test_pipelined_groups_through_the_slow_paths(K, kind):
     assert kind == 'empty' or any(w.any() for w in want), 'the frames show something'
 
 
+@pytest.mark.parametrize('density', [1, 2])
+def test_lean_and_roomy_builds_of_the_tile_launch_render_the_same_frames(K, monkeypatch, density):
+    """Every tile launch of the fused route exists twice (kbe_fused.hip): LEAN -- 608 records per tile in LDS, six workgroups per
+    CU, what clouds of about a point per pixel take -- and ROOMY (736, five).  KBE_FUSED_CAP forces either: the same groups,
+    pipelined and with their placement launches in front, on a cloud of one point per pixel (whose tiles hold about as many
+    records as the lean build has room for: many of them spill a few and take a second round) and on one of two per pixel (every
+    tile spills on either build)."""
+    g0 = torch.Generator().manual_seed(9)
+    W, H = 192, 128
+    n_side = density
+    ys, xs = torch.meshgrid(torch.arange(H * n_side, dtype=torch.float32) / n_side, torch.arange(W, dtype=torch.float32), indexing='ij')
+    z = 500.0 + 300.0 * torch.rand(ys.shape, generator=g0)
+    pts = torch.stack([(xs - W / 2 + 0.5) * z / 512.0, (ys - H / 2 + 0.5) * z / 512.0, z]).reshape(1, 3, -1)
+    N = pts.shape[2]
+    img, dep = torch.rand(1, 3, N, generator=g0), torch.rand(1, 1, N, generator=g0) * 500 + 100
+    monkeypatch.setenv('KBE_FUSED', '1')
+    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+    K._pack(state)
+    cams = [(512.0, (0.4 * i - 2.0, 1.0 - 0.2 * i, -1.5 * i)) for i in range(10)]
+    groups = [cams[0:4], cams[4:9], cams[9:10]]
+    frames = {}
+    for build in ('lean', 'roomy'):
+        monkeypatch.setenv('KBE_FUSED_CAP', build)
+        got = []
+        for g in groups:
+            buf = torch.zeros(len(g), H, W, 3, dtype=torch.uint8, device='cuda')
+            K.render_frame_group_fused(state, g, 120, buf)
+            got.append(c(buf))
+        turns, placed = [0] * 12, False
+        for i, g in enumerate(groups):
+            n = len(g)
+            nxt = groups[i + 1] if i + 1 < len(groups) else None
+            ok = nxt is not None and bool(K.lib.kbe_render_frame_group_ahead_ok(N, W, H, n, len(nxt)))
+            now = turns[:n]
+            for k in range(n):
+                turns[k] += 1
+            buf = torch.zeros(n, H, W, 3, dtype=torch.uint8, device='cuda')
+            K.render_frame_group_ahead(state, g, 120, buf, turn=now, placed=placed, next_cameras=nxt if ok else None, next_turn=turns[:len(nxt)] if ok else None)
+            placed = ok
+            d = np.abs(c(buf).astype(np.int32) - got[i].astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, '%s, group %d pipelined: max %d, %.2e differ' % (build, i, d.max(), (d > 0).mean())
+        frames[build] = got
+    for a, b in zip(frames['lean'], frames['roomy']):
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert a.any() and d.max() <= 1 and (d > 0).mean() < 2e-3, 'lean against roomy: max %d, %.2e differ' % (d.max(), (d > 0).mean())
+
+
 @pytest.mark.parametrize('kind', ['rough', 'near_plane'])
 def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, kind):
     """The frames a tile launch places ahead share ONE set of candidate lists when they are consecutive cameras of a straight
