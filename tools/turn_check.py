@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """The hand-off's turn-taking under several processes' worth of hardware queues: WORLD_SIZE ranks (gloo) share GPU 0, each
 delivers passes of a video to its own pinned host memory on two lanes whose transfers take turns (k_turn: a bounded, advisory
-device-side wait).  Checks per rank: every pass delivers the bytes of the first, and no pass takes longer than twice the median
-(a wait that ran into its bound -- milliseconds -- in steady state would show in pass after pass: the second-slowest pass of a
-rank must stay within twice its median, the slowest within four times).
+device-side wait).  Checks per rank: every pass delivers the frames of the first, and no wait runs into its bound in steady state
+(milliseconds in pass after pass: the second-slowest pass of a rank must stay within 2.5 times the median pass of all ranks, the
+slowest within 8 times).
     python -m torch.distributed.run --nproc-per-node 4 --master-addr 127.0.0.1 tools/turn_check.py"""
 import os
 import sys
@@ -47,16 +47,29 @@ for k in range(passes + 1):         # the first pass after the ranks have met is
     if k > 0:
         times.append(time.perf_counter() - t0)
     d = (out.to(torch.int16) - first.to(torch.int16)).abs()
-    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, 'rank %d: a pass delivered other frames' % rank
-med = float(np.median(times))
-# the bound: a rank's SECOND-slowest pass within twice its median, its slowest within four times.  Ranks that share one GPU are
-# time-sliced: a single pass can lose a slice to a neighbour (seen: 1.2-1.7 x, once 2.3 x); a turn wait running into its bound
-# costs milliseconds in EVERY pass it happens in, so it would show in more than one
-worst = torch.tensor([max(sorted(times)[-2] / med, max(times) / med / 2.0)])
+    # (the frames are CROPPED: behind the order-dependent last ulp of the colour sums -- one count at a value on an integer boundary --
+    # the fixed-point arithmetic of getRectSubPix + resize moves a delivered value by two in rare places: tests/test_hip_parity.py
+    # frames_close)
+    if not (int(d.max()) <= 2 and float((d > 0).float().mean()) < 1e-3 and float((d > 1).float().mean()) < 1e-5):
+        bad = (d > 1).flatten(1).any(1).nonzero().flatten().tolist()
+        f = bad[0] if bad else 0
+        ys, xs = (d[f] > 1).any(-1).nonzero(as_tuple=True)
+        raise AssertionError('rank %d: pass %d delivered other frames: max |diff| %d, %.2e of the values differ; frames with a difference above 1: %s; in frame %d: %d pixels, rows %s..%s, columns %s..%s'
+                             % (rank, k, int(d.max()), float((d > 0).float().mean()), bad[:12], f, len(ys), ys.min().item() if len(ys) else None, ys.max().item() if len(ys) else None,
+                                xs.min().item() if len(xs) else None, xs.max().item() if len(xs) else None))
+# The bound.  Ranks that share one GPU are time-sliced, and with twelve frames per launch the slices are long: a rank runs passes of
+# 3.5 ms while its neighbours are out of step and of 7 ms while they are in step (its own median says little), and about one run
+# in five has ONE pass of 17-26 ms in which three of the four ranks stall together (measured, round 4: 48 runs of this script).  A
+# turn wait running into its bound costs milliseconds in EVERY pass it happens in: it would show in pass after pass.  So, against
+# the median pass of ALL ranks: a rank's SECOND-slowest pass within 2.5 times, its slowest within 8 times.
+every = [None] * world
+dist.all_gather_object(every, times)
+med = float(np.median([t for ts in every for t in ts]))
+worst = torch.tensor([max(sorted(times)[-2] / med / 2.5, max(times) / med / 8.0)])
 dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-print('rank %d: passes of %d frames: median %.2f ms, max %.2f ms (%.2fx): %s' % (rank, n, med * 1e3, max(times) * 1e3, max(times) / med, ' '.join('%.1f' % (t * 1e3) for t in times)), flush=True)
+print('rank %d: passes of %d frames: median %.2f ms (all ranks %.2f), max %.2f ms (%.2fx): %s' % (rank, n, float(np.median(times)) * 1e3, med * 1e3, max(times) * 1e3, max(times) / med, ' '.join('%.1f' % (t * 1e3) for t in times)), flush=True)
 dist.barrier()
 if rank == 0:
-    assert float(worst) <= 2.0, 'second-slowest pass / median, or half of slowest / median: %.2f' % float(worst)
-    print('OK (%d ranks on one GPU, worst pass %.2fx its rank\'s median)' % (world, float(worst)))
+    assert float(worst) <= 1.0, 'second-slowest pass / (2.5 x the median of all ranks), or slowest / (8 x): %.2f' % float(worst)
+    print('OK (%d ranks on one GPU, worst pass at %.2f of its bound)' % (world, float(worst)))
 dist.destroy_process_group()
