@@ -112,6 +112,17 @@ def measured_instructions():
         return {}, None
 
 
+def consecutive_groups(path, n):
+    """The launch groups of a video whose cameras are `path`: group k = cameras [n k, n k + n), the path taken cyclically so that
+    every group has n frames (a 20-step path in groups of twelve: [0..11], [12..19, 0..3]).  What the scatter's launch is priced on
+    since round 5: the frames of a group share candidate lists built for the box between the group's first and last
+    camera, so a launch of n copies of ONE camera is that scheme's best case."""
+    count = max(1, (len(path) + n - 1) // n)
+    return [[path[(k * n + j) % len(path)] for j in range(n)] for k in range(count)]
+
+
+PRODUCT_STEPS = 75      # /root/reference/kbe.py:104: a video of the product is np.linspace(0, 1, 75)
+DRIVER_STEPS = 20       # the driver's `--steps 20`
 GROUP_FRAMES = 4        # frames per launch of the grouped launches (kbe_render_frame_group / _fused) when the timed region uses one
 BUCKET_GROUP_MAX = 4    # kbe_render_frame_group takes up to four frames, kbe_render_frame_group_fused up to eight
 # Wave-level VALU instructions the chip issues per us through ONE issue port per SIMD -- measured (tools/valu_rate.hip,
@@ -124,7 +135,7 @@ BUCKET_GROUP_MAX = 4    # kbe_render_frame_group takes up to four frames, kbe_re
 VALU_ISSUE_PER_US = 570.0e3
 
 
-def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES, fill_flags=0):
+def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES, fill_flags=0, paths=None):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
     launches between two events; the tile kernel is timed alone (back to back on a prepared scratch) --
@@ -191,6 +202,39 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
         out[key] = rounds[len(rounds) // 2]
         out[key + ':rounds'] = rounds
         K.render_frame_group_ahead(state, group, Bl, fgroup_out[:n_ahead], turn=turn[0], placed=True, next_cameras=None, stages=6, fill_rect=empty)  # the sequence ends
+    # ... and on a video's OWN groups: consecutive cameras of a path (`paths`: {label: cameras}), the launch of group k placing group
+    # k + 1 ahead, the path's groups taken round and round.  Timed in whole cycles of the path's groups (>= reps launches), five rounds,
+    # the median round.
+    n = group_frames
+    if K.lib.kbe_render_frame_group_ahead_ok(state['N'], W, H, n, n):
+        for label, path in (paths or {}).items():
+            groups = consecutive_groups(path, n)
+            launches = [K.prepared_group_ahead(state, g, Bl, fgroup_out[:n], groups[(k + 1) % len(groups)], stages=2) for k, g in enumerate(groups)]
+            # turn 0 places group 0 (a placement launch in front); from then on turn t renders group (t - 1) % G and places group t % G
+            K.render_frame_group_ahead(state, groups[-1], Bl, fgroup_out[:n], turn=0, placed=False, next_cameras=groups[0], stages=2)
+            turn = [1]
+
+            def consecutive():
+                launches[(turn[0] - 1) % len(launches)](turn[0], True)
+                turn[0] += 1
+            count = len(groups) * max(1, (reps + len(groups) - 1) // len(groups))
+            rounds = []
+            for _ in range(5):
+                for _ in range(count):
+                    consecutive()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(count):
+                    consecutive()
+                e1.record()
+                e1.synchronize()
+                rounds.append(e0.elapsed_time(e1) / count * 1e-3)
+            rounds.sort()
+            out['fused:scatter_group_ahead:consecutive:' + label] = rounds[len(rounds) // 2]
+            out['fused:scatter_group_ahead:consecutive:' + label + ':rounds'] = rounds
+            K.render_frame_group_ahead(state, groups[(turn[0] - 1) % len(groups)], Bl, fgroup_out[:n], turn=turn[0], placed=True, next_cameras=None, stages=6, fill_rect=empty)
+            del launches
     del fgroup_out
     out['fused:scatter+fill'] = timed(lambda: K.render_frame(state, shift3, focal, Bl, stages=6, fill_rect=fill_rect, fused=True))   # + the 8-byte memset of a frame on its own
     # the bucket route: k_project -> k_tiles, z-buffer and bucket records in HBM.  In a video consecutive frames alternate
@@ -652,8 +696,14 @@ def main():
         route = 'fused' if fused_used else 'bucket'
         group_frames = group_used if group_used > 1 else GROUP_FRAMES
         fill_flags = 32 | (512 if video_flags & 1 else 0)           # KBE_STAGE_FILL_BY_COUNT, + KBE_STAGE_FILL_DIST where the loop fills with the tables
+        # the camera paths the scatter's launch is priced on: this run's own, the product's 75 steps, the driver's 20 (consecutive
+        # cameras in groups of `group_frames`: time_kernels)
+        paths = {}
+        if not args.dolly:
+            for n_steps in dict.fromkeys((args.steps * world_size, PRODUCT_STEPS, DRIVER_STEPS)):
+                paths[str(n_steps)] = common.frame_cameras(dict(settings, dblSteps=np.linspace(0.0, 1.0, max(n_steps, 2)).tolist()[:n_steps]), oc)
         kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames,
-                          fill_flags=fill_flags)
+                          fill_flags=fill_flags, paths=paths)
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch) per frame
@@ -705,6 +755,26 @@ def main():
         grouped = roof(route, group_frames)
         other = roof('bucket' if route == 'fused' else 'fused', group_frames)
         two_launches = roof('fused:two_launches', group_frames) if route == 'fused' and ahead else None
+        # the group launch on consecutive cameras of real paths (the frames of a group share candidate lists built for the box
+        # between the group's first and last camera: identical cameras are the best case).  The line's `roofline` is priced on the
+        # PRODUCT's path (75 steps, /root/reference/kbe.py:104) when the timed region launches groups; this run's own path, the
+        # driver's 20 steps and the identical-camera figure are kept beside it.
+        by_path = {}
+        for label in paths:
+            t = kt.get('fused:scatter_group_ahead:consecutive:' + label)
+            if t:
+                by_path[label] = {'steps': int(label), 'groups': len(consecutive_groups(paths[label], group_frames)), 'frames_per_launch': group_frames,
+                                  'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / group_frames, 2),
+                                  'achieved': group_frames * scatter_bytes / t / 1e9, 'frac': group_frames * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
+                                  'rounds_us': [round(x * 1e6, 2) for x in kt['fused:scatter_group_ahead:consecutive:' + label + ':rounds']]}
+        cameras_note, identical = 'identical (one camera, %d copies per launch)' % frames_per_launch, None
+        if route == 'fused' and ahead and frames_per_launch == group_frames and str(PRODUCT_STEPS) in by_path:
+            c = by_path[str(PRODUCT_STEPS)]
+            identical = {k: main[k] for k in ('us', 'us_per_frame', 'achieved', 'frac')}
+            main = dict(main, us=c['us'], us_per_frame=c['us_per_frame'], achieved=c['achieved'], frac=c['frac'])
+            if 'valu_issue' in main:
+                main['valu_issue'] = dict(main['valu_issue'], frac=main['valu_issue']['us_at_peak'] / c['us_per_frame'])
+            cameras_note = 'consecutive: groups of %d consecutive cameras of a %d-step path, group k placing group k + 1 ahead' % (group_frames, PRODUCT_STEPS)
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
@@ -724,12 +794,13 @@ def main():
                          'achieved': main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': main['frac'],
                          'traffic': main['traffic'], 'traffic_source': traffic_src, 'algorithmic_bytes': main['algorithmic_bytes'],
                          'frames_per_launch': frames_per_launch, 'us': main['us'], 'us_per_frame': main['us_per_frame'],
+                         'cameras': cameras_note, 'by_path': by_path, 'identical_cameras': identical,
                          'formula': '28 N + 20 HW per frame (SURVEY.md 8d)',
                          'valu_issue': main.get('valu_issue'), 'valu_issue_source': insts_src,
                          'one_frame_per_launch': single, 'grouped': grouped, 'other_route': other, 'placement_launch_in_front': two_launches,
                          'note': 'launches timed alone on one stream, back to back (HIP events, 40 repetitions), with the number of frames per '
                                  'launch the timed region uses; fused route: ONE launch per group -- the tile launch of a group also makes the placements '
-                                 'of the next group (here: of the same frames again), so a launch holds all of the scatter\'s work for its frames; '
+                                 'of the next group, so a launch holds all of the scatter\'s work for its frames (`cameras` says which cameras a group holds); '
                                  'the matching rocprofv3 --stats summary is profiles/*scatter_group*_kernel_stats.csv '
                                  '(in the timed region the kernels of several lanes overlap and per-kernel durations stretch)',
                          'kernel_us': {k: ([round(x * 1e6, 2) for x in v] if isinstance(v, list) else round(v * 1e6, 2)) for k, v in kt.items()}},

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 9
+#define KBE_ABI_VERSION 10
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -218,6 +218,11 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
 /* kbe_render_frame_fused with parity -1 only: do not zero the hole counters first (timing aid; the frames of such a run
  * are not valid) */
 #define KBE_STAGE_KEEP_HOLE_COUNT 64
+/* the fused route's tile launches exist in two builds (kbe_fused.hip): LEAN (608 records per tile in LDS, six workgroups per CU)
+ * and ROOMY (736, five).  Default: by the cloud's density (lean up to 1.125 points per pixel).  These force one -- for tests and
+ * measurements; same frames.  (Until ABI 9 the library read an environment variable at every launch instead.) */
+#define KBE_STAGE_FUSED_LEAN 1024
+#define KBE_STAGE_FUSED_ROOMY 2048
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
@@ -363,6 +368,9 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * instead of 6, a 75-frame video 6 instead of 8).  The last group takes what is left.  (Measured: no gain on MI355X -- the larger
  * groups render next to the other lane's transfer and are slowed by it; the Python host side leaves it off.) */
 #define KBE_VIDEO_FAST_RAMP 1024
+/* fused route: force the lean / the roomy build of the tile launches (KBE_STAGE_FUSED_LEAN / _ROOMY for every frame) */
+#define KBE_VIDEO_FUSED_LEAN 2048
+#define KBE_VIDEO_FUSED_ROOMY 4096
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

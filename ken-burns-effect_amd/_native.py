@@ -24,7 +24,7 @@ SYMBOLS = (
     'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act', 'kbe_frame_scratch_init_sets',
 )
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
@@ -133,6 +133,15 @@ def _stream():
     tensors live on that device (`_ptr`), so a caller working on cuda:1 without torch.cuda.set_device(1) gets a KbeError
     instead of device-1 pointers launched on device 0's stream."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fused_build_bits(video=False):
+    """KBE_FUSED_CAP=lean|roomy (tests, measurements): the flag that forces one build of the fused route's tile launches
+    (KBE_STAGE_FUSED_LEAN / _ROOMY, or the kbe_render_video form).  The environment is read HERE, per call; the library reads none."""
+    cap = os.environ.get('KBE_FUSED_CAP')
+    if cap not in ('lean', 'roomy'):
+        return 0
+    return ((2048 if cap == 'lean' else 4096) if video else (1024 if cap == 'lean' else 2048))
 
 
 def stride_of(K, state):
@@ -331,7 +340,7 @@ class HipKernels:
                                                         _i(state['W']), _i(state['H']), _d(float(focal)), _d(float(baseline)),
                                                         _shift(shift3), _ptr(state['scratch'], torch.uint8), _ptr(frame, torch.uint8),
                                                         _ptr(render_f32), _ptr(existing_f32), _ptr(zee_f32), _ptr(zee_pre_f32),
-                                                        _i(int(stages) & ~1), rect, _i(int(parity)), _stream()), 'kbe_render_frame_fused')
+                                                        _i((int(stages) & ~1) | fused_build_bits()), rect, _i(int(parity)), _stream()), 'kbe_render_frame_fused')
             return frame
         self._check(self.lib.kbe_render_frame_stages(_ptr(state['points']), _ptr(state['image']), _ptr(state['depth']),
                                                      _i(state['N']), _i(state['W']), _i(state['H']), _d(float(focal)),
@@ -380,7 +389,7 @@ class HipKernels:
         par = None if parities is None else (ctypes.c_int * n)(*[int(v) for v in parities])
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
         self._check(self.lib.kbe_render_frame_group_fused(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']),
-                                                          _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, par, _i(int(stages)), rect,
+                                                          _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, par, _i(int(stages) | fused_build_bits()), rect,
                                                           _stream()), 'kbe_render_frame_group_fused')
         return out
 
@@ -407,7 +416,7 @@ class HipKernels:
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
         self._check(self.lib.kbe_render_frame_group_ahead(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']),
                                                           _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, turns, _i(1 if placed else 0),
-                                                          _i(m), nf, ns, nsets, nturns, _i(int(stages)), rect, _stream()), 'kbe_render_frame_group_ahead')
+                                                          _i(m), nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), rect, _stream()), 'kbe_render_frame_group_ahead')
         return out
 
     def prepared_group_ahead(self, state, cameras, baseline, out, next_cameras, stages=2):
@@ -428,7 +437,7 @@ class HipKernels:
         turns, nturns = (ctypes.c_int * n)(), (ctypes.c_int * m)()
         fixed = (_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']), _i(state['H']), _d(float(baseline)), _i(n),
                  focals, shifts, sets, frames, turns)
-        tail = (nf, ns, nsets, nturns, _i(int(stages)), None)
+        tail = (nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), None)
         fn, check, zero = self.lib.kbe_render_frame_group_ahead, self._check, _i(0)
         keep = (scratch, out)          # (the arrays hold raw addresses)
 
@@ -608,6 +617,7 @@ class HipKernels:
             flags |= 1024
         if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
             flags |= 512
+        flags |= fused_build_bits(video=True)               # KBE_FUSED_CAP: KBE_VIDEO_FUSED_LEAN / _ROOMY
         keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again
         scratch = state['scratch']
         if group > 1:
@@ -711,6 +721,8 @@ class HipKernels:
         """prelu(x, slope) * mask in one pass (kbe_prelu_mask); mask [B,1,H,W] or None."""
         x = _f32c(x)
         B, C, H, W = x.shape
+        if mask is not None and tuple(mask.shape) != (B, 1, H, W):
+            raise KbeError('prelu_mask: the mask must be [B,1,H,W] = %s, got %s' % ((B, 1, H, W), tuple(mask.shape)))
         out = torch.empty_like(x) if out is None else out
         self._check(self.lib.kbe_prelu_mask(_ptr(x), _ptr(_f32c(slope)), _ptr(None if mask is None else _f32c(mask)), _i(B), _i(C), _i(H), _i(W), _ptr(out),
                                             _stream()), 'kbe_prelu_mask')

@@ -263,17 +263,19 @@ def build_pointcloud(objectSettings, objectCommon, moduleInpaint):
     """The set-up loop of process_kenburns (common.py:175-220): two end poses, each inpainted
     and appended.  Serial by nature (pass 2 sees the points pass 1 appended)."""
     _reset_inpa(objectCommon)
-    for dblStep in (0.0, 1.0):
-        focal, pose = _camera_at(dblStep, objectSettings, objectCommon)
-        pose['tensorPoints'] = objectCommon['tensorInpaPoints']
-        vec = _shift_vector(pose, objectCommon, focal)
-        tensorShift = torch.tensor(vec, dtype=torch.float64).to(torch.float32).view(1, 3, 1)
-        tensorShift = tensorShift.to(objectCommon['tensorInpaPoints'].device)
-        # common.py:208-215 renders this pose and discards the result; skipped.
-        if not objectSettings['dolly']:
-            process_inpaint(1.1 * tensorShift, objectCommon, moduleInpaint, focal)
-    if getattr(moduleInpaint, '_kept_source', None) is not None:
-        moduleInpaint._kept_source = None          # (what pointcloud_inpainting kept of the image between the two passes: 68 feature planes)
+    # (the two passes hand pointcloud_inpainting the same image and disparity: what depends on those alone is kept between them and
+    # released on the way out, whatever happens in between)
+    keeping = moduleInpaint.keeping_source() if hasattr(moduleInpaint, 'keeping_source') else contextlib.nullcontext()
+    with keeping:
+        for dblStep in (0.0, 1.0):
+            focal, pose = _camera_at(dblStep, objectSettings, objectCommon)
+            pose['tensorPoints'] = objectCommon['tensorInpaPoints']
+            vec = _shift_vector(pose, objectCommon, focal)
+            tensorShift = torch.tensor(vec, dtype=torch.float64).to(torch.float32).view(1, 3, 1)
+            tensorShift = tensorShift.to(objectCommon['tensorInpaPoints'].device)
+            # common.py:208-215 renders this pose and discards the result; skipped.
+            if not objectSettings['dolly']:
+                process_inpaint(1.1 * tensorShift, objectCommon, moduleInpaint, focal)
 
 
 def frame_cameras(objectSettings, objectCommon):

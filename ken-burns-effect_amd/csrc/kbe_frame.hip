@@ -954,7 +954,7 @@ int kbe_render_frame_fused(const void* packed, int N, double cloud_focal, int W,
     }
     if (stages & KBE_STAGE_TILES) {
         const FusedTarget t = { cam, sc, scratch_place(scratch, W, H), parity, frame_u8, render_f32, existing_f32, zee_f32, zee_pre_f32, -1 };
-        launch_frames_fused(s, 1, packed, N, cloud_focal, &t);
+        launch_frames_fused(s, 1, packed, N, cloud_focal, &t, false, 0, nullptr, fused_build_of_stages(stages));
         if ((rc = launched("kbe_render_frame_fused/scatter"))) return rc;
     }
     if (stages & KBE_STAGE_FILL) {
@@ -994,7 +994,7 @@ int kbe_render_frame_group_fused(const void* packed, int N, double cloud_focal, 
         targets[k] = FillTarget{ sc, sc.hole_count + (par == 1 ? 1 : 0), frames_u8[k], nullptr, 0, par >= 0 ? sc.hole_count + (par == 1 ? 0 : 1) : nullptr };
     }
     if (stages & KBE_STAGE_TILES) {
-        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft);
+        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, false, 0, nullptr, fused_build_of_stages(stages));
         if ((rc = launched("kbe_render_frame_group_fused/scatter"))) return rc;
     }
     if (stages & KBE_STAGE_FILL) {
@@ -1065,7 +1065,7 @@ int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, 
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
         }
     if (stages & KBE_STAGE_TILES) {
-        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt);
+        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt, fused_build_of_stages(stages));
         if ((rc = launched("kbe_render_frame_group_ahead/scatter"))) return rc;
     }
     if (stages & KBE_STAGE_FILL) {
@@ -1237,7 +1237,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         if (packed)         // the fused scatter on the packed cloud; a lane's frames alternate between its two hole counters
             rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                         (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
-                                        KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags, crop ? rect : nullptr, lane_frames[l]++ & 1,
+                                        KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags | ((flags & KBE_VIDEO_FUSED_LEAN) ? KBE_STAGE_FUSED_LEAN : 0) |
+                                        ((flags & KBE_VIDEO_FUSED_ROOMY) ? KBE_STAGE_FUSED_ROOMY : 0), crop ? rect : nullptr, lane_frames[l]++ & 1,
                                         (kbe_stream_t) ls[l]);
         else {
             // a lane's frames alternate between the two z-buffers (A, B, A, ...), each clearing the other's in its tile
@@ -1319,7 +1320,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                     nt[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), carve(scr, W, H), scratch_place(scr, W, H), k & 1, nullptr, nullptr, nullptr, nullptr, nullptr, k };
                 }
             }
-            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt);
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0));
             lane_placed[l] = n_next > 0;
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };

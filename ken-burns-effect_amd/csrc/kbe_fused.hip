@@ -1008,7 +1008,7 @@ bool fused_can_place_ahead(int N, int W, int H, int n, int n_next)
 // `placed`: the previous tile launch made their placements ahead) and one tile launch, each taking all n frames (frame k: its
 // camera, scratch set, and by `parity` / `turn` the set's bank of placements and lists, hole counter and list total); the tile
 // launch also makes the placements of `next` (n_next frames: the ones the next tile launch on this stream renders)
-void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t, bool placed, int n_next, const FusedTarget* next)
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t, bool placed, int n_next, const FusedTarget* next, int build)
 {
     PlaceJobs pj;
     FrameJobs fj;
@@ -1075,12 +1075,14 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         fj.nx[k] = place_args(n_next > 0 ? next[k < n_next ? k : 0] : f);
     }
     if (shared_now)         // every frame reads the lists the group's first frame's set holds
-        for (int k = 1; k < KBE_FRAME_JOBS; k++) { fj.a[k].tile_count = fj.a[0].tile_count; fj.a[k].cand = fj.a[0].cand; fj.a[k].bin_flag = fj.a[0].bin_flag; fj.a[k].bin_flag_next = fj.a[0].bin_flag_next; }
+        // (... and still zeroes the list total its OWN set counts in two turns on: a set that joins an unshared or group-first turn
+        // later must not count on top of what an earlier such turn left -- totals only grow, and past the budget every tile of the
+        // frame scans the whole cloud: ADVICE r4)
+        for (int k = 1; k < KBE_FRAME_JOBS; k++) { fj.a[k].tile_count = fj.a[0].tile_count; fj.a[k].cand = fj.a[0].cand; fj.a[k].bin_flag = fj.a[0].bin_flag; }
     if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
     // the lean build (608 records per tile, six workgroups per CU) for clouds of about a point per pixel, the roomy one beyond
-    // (KBE_FUSED_CAP=lean / roomy: a switch for tests and measurements, read at every launch)
-    const char* const cap_env = getenv("KBE_FUSED_CAP");
-    const int forced = !cap_env ? 0 : (!strcmp(cap_env, "lean") ? 1 : (!strcmp(cap_env, "roomy") ? 2 : 0));
+    // (`build`: KBE_STAGE_FUSED_LEAN / _ROOMY force one -- a switch for tests and measurements)
+    const int forced = build;
     const Scratch& sc0 = t[0].sc;
     const bool lean = forced ? forced == 1 : (double) pc.Np <= KBE_LEAN_MAX_DENSITY * (double) t[0].cam.W * (double) t[0].cam.H;
     if (n == 1 && n_next <= 1) {

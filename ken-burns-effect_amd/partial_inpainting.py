@@ -47,13 +47,18 @@ class _Pair(nn.Module):
         self.conv2 = _pconv(cmid, cout)
         self._first_act = first_act
 
+    # The fused form skips the second `input * mask` (utils/partial_conv.py:61): right when the masks are 0 / 1 -- the first layer's
+    # update mask is then 0 / 1 and its output 0 outside it -- and wrong for fractional masks.  Inpaint.forward looks at the mask it
+    # is given and turns the fused form off for a call with a fractional one.
+    binary_masks = True
+
     def _fused(self):
         """The element-wise passes around the two layers ride in the layers' own passes (include/kbe.h: kbe_prelu_mask,
         kbe_pconv_epilogue's prelu_slope / residual) when the kernel set has them and PartialConv2d.forward is this package's:
         per pair three passes over the feature maps instead of seven -- [prelu * mask] conv [renormalise + prelu] conv
         [renormalise + skip] against prelu, * mask, conv, renormalise, prelu, * mask, conv, renormalise, + skip.  Same values
         (a PReLU of the 0 the renormalisation leaves outside the mask is 0: the second multiplication has nothing to do)."""
-        return hasattr(common._K(), 'prelu_mask') and getattr(type(self.conv1).forward, 'fuses_neighbours', False) and not torch.is_grad_enabled()
+        return _Pair.binary_masks and hasattr(common._K(), 'prelu_mask') and getattr(type(self.conv1).forward, 'fuses_neighbours', False) and not torch.is_grad_enabled()
 
     def _pair(self, x, mask, skip=None):
         """-> (conv2(act(conv1([act] x))) [+ skip], mask)"""
@@ -149,6 +154,16 @@ class Inpaint(nn.Module):
                 tensorContext = self.moduleContext(torch.cat([tensorImage, tensorDisparity], 1))
             tensorData = torch.cat([tensorImage, tensorDisparity, tensorContext], 1)
 
+        # (one host look at the mask per forward: a fractional mask takes the unfused pairs, which multiply by the mask twice as the
+        # reference does)
+        binary = bool(((tensorMasks == 0) | (tensorMasks == 1)).all())
+        was, _Pair.binary_masks = _Pair.binary_masks, binary
+        try:
+            return self._forward(tensorData, tensorMasks)
+        finally:
+            _Pair.binary_masks = was
+
+    def _forward(self, tensorData, tensorMasks):
         rows = len(ROW_FEATURES)
         feat, mask = [None] * rows, [None] * rows
         feat[0], mask[0] = self.moduleInput(tensorData, mask_in=_one(tensorMasks))

@@ -226,6 +226,16 @@ class Inpaint(nn.Module):
             'tensorDisparity': F.threshold(input=tensorDisparity, threshold=0.0, value=0.0),
         }
 
+    @contextlib.contextmanager
+    def keeping_source(self):
+        """Inside: consecutive pointcloud_inpainting calls on the SAME image and disparity tensors share what depends on those alone
+        (see there); on the way out -- also by an exception -- what was kept is released."""
+        self._keep_source, self._kept_source = True, None
+        try:
+            yield self
+        finally:
+            self._keep_source, self._kept_source = False, None
+
     def pointcloud_inpainting(self, tensorImage, tensorDisparity, tensorShift, objectCommon, dblFocal=None):
         """Warps image, disparity and context features into the view displaced by ``tensorShift`` and
         inpaints what that view cannot see (pointcloud_inpainting.py:185-213)."""
@@ -236,12 +246,16 @@ class Inpaint(nn.Module):
         width, height = objectCommon['intWidth'], objectCommon['intHeight']
 
         # process_kenburns' set-up calls this twice with the SAME image and disparity (common.py:181-219: one pass per end pose):
-        # what depends on them alone -- the points, the normalisation, the context features -- is kept from the first call.
-        # The kept entry holds the two input tensors themselves (so that their addresses cannot be handed to other tensors)
-        # and their versions (an in-place change makes it stale), and the versions of the context network's parameters.
-        kept = getattr(self, '_kept_source', None) if not torch.is_grad_enabled() else None
-        stamp = (tensorImage._version, tensorDisparity._version, float(dblFocal), float(objectCommon['dblBaseline'])) + \
-            tuple(p._version for p in self.moduleContext.parameters())
+        # what depends on them alone -- the points, the normalisation, the context features -- is kept from the first call, but only
+        # INSIDE `with self.keeping_source():` (common.build_pointcloud): the entry holds the two inputs, the points and 68 feature
+        # planes (0.3 GB at 1024^2) and must not outlive the pair of calls.  It holds the two input tensors themselves
+        # (so that their addresses cannot be handed to other tensors) and their versions (an in-place change makes it stale); the
+        # context network's parameters by version, storage, dtype and device (`.to()` / `.half()` replace the storage without
+        # bumping the version); and the fused-layers switch.
+        keeping = getattr(self, '_keep_source', False) and not torch.is_grad_enabled()
+        kept = getattr(self, '_kept_source', None) if keeping else None
+        stamp = (tensorImage._version, tensorDisparity._version, tensorImage.dtype, tensorImage.device, float(dblFocal), float(objectCommon['dblBaseline']),
+                 os.environ.get('KBE_FUSED_LAYERS', '1')) + tuple((p._version, p.data_ptr(), p.dtype, p.device) for p in self.moduleContext.parameters())
         if kept is not None and kept[0] is tensorImage and kept[1] is tensorDisparity and kept[2] == stamp:
             tensorPoints, features, self.tensorMean, self.tensorStd = kept[3]
         else:
@@ -253,7 +267,7 @@ class Inpaint(nn.Module):
             tensorImage, tensorDisparity = self.normalize_images_disp(tensorImage, tensorDisparity, not_normed=True)
             tensorContext = self._context(torch.cat([tensorImage, tensorDisparity], 1))
             features = torch.cat([tensorImage, tensorDisparity, tensorContext], 1).view(1, 68, -1)
-            self._kept_source = None if torch.is_grad_enabled() else (imageIn, disparityIn, stamp, (tensorPoints, features, self.tensorMean, self.tensorStd))
+            self._kept_source = (imageIn, disparityIn, stamp, (tensorPoints, features, self.tensorMean, self.tensorStd)) if keeping else None
 
         tensorRender, tensorExisting = K.render_pointcloud(tensorPoints + tensorShift, features, width, height, dblFocal,
                                                            objectCommon['dblBaseline'])

@@ -112,6 +112,8 @@ def broadcast_cloud(objectCommon, device, src=0):
         hint = {key: int(v) for key, v in ((False, h[12]), (True, h[13])) if int(v) > 0}
         if hint:
             objectCommon['_kbeDeliveryLanes'] = hint
+        else:
+            objectCommon.pop('_kbeDeliveryLanes', None)         # nothing measured for THIS cloud: an earlier video's entry must not stand
     return objectCommon
 
 
@@ -125,7 +127,11 @@ def measure_delivery_lanes(objectSettings, objectCommon):
         return None
     cameras = common.frame_cameras(objectSettings, objectCommon)
     crop = common.crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
+    # (a hint is what ANOTHER rank measured: on the measuring rank an entry left by an earlier video of the same objectCommon --
+    # Pipeline keeps it -- would be handed back unmeasured and broadcast again, whatever the new cloud's N, W, H or crop: ADVICE r4)
+    objectCommon.pop('_kbeDeliveryLanes', None)
     state = common._prepared_cloud(K, objectCommon)
+    state.pop('delivery_lanes_hint', None)
     lanes = K.delivery_lanes(state, cameras, objectCommon['dblBaseline'], crop)
     objectCommon['_kbeDeliveryLanes'] = {K.zooms_out(state, cameras): int(lanes)}
     return lanes

@@ -102,20 +102,45 @@ def get_masks(tensorImage, tensorDisparity, tensorDepth, zoom_settings, camera, 
     return tensorRender, (tensorMasks > 0.0).float(), flat, tensorShift, objects
 
 
+def _miopen_user_db():
+    """Where MIOpen keeps this user's find-db (MIOPEN_USER_DB_PATH, default ~/.config/miopen) and what is in it: {file: size}."""
+    import os
+    root = os.environ.get('MIOPEN_USER_DB_PATH') or os.path.join(os.path.expanduser('~'), '.config', 'miopen')
+    found = {}
+    for base, _, files in os.walk(root):
+        for f in files:
+            try:
+                found[os.path.join(base, f)] = os.path.getsize(os.path.join(base, f))
+            except OSError:
+                pass
+    return root, found
+
+
 class miopen_tuned_once:
     """``with miopen_tuned_once(tag, device):`` -- the block's convolutions run under MIOpen's find step
     (torch.backends.cudnn.benchmark) the first time this machine sees ``tag`` and in PyTorch's immediate mode from then on (the find
     step leaves its measurements in MIOpen's user find-db, which the immediate mode of every later process consults; a marker file
     under KBE_CACHE_DIR, default ~/.cache/kbe/miopen-tuned/, records that it ran).  The find step costs tens of seconds, once per
-    machine and tag -- it says so on stderr.  ``enabled=False`` (or a CPU device): nothing happens."""
+    machine, find-db and tag -- it says so on stderr.  The marker is written only when the find-db GREW during the block (a
+    read-only or disabled db -- MIOPEN_DISABLE_CACHE, MIOPEN_USER_DB_PATH on a read-only mount -- keeps nothing: marking the size
+    tuned would leave it untuned for good) and its name carries the db's path.  In a process group only rank 0 tunes
+    (the others run in immediate mode: several ranks measuring solvers against each other measure each other).  The switch it
+    flips, torch.backends.cudnn.benchmark, is process-global: not for use from several threads at once.
+    ``enabled=False`` (or a CPU device): nothing happens."""
 
     def __init__(self, tag, device, enabled=True):
+        import hashlib
         import os
         self.marker = None
-        if enabled and torch.device(device).type == 'cuda' and torch.cuda.is_available():
+        if enabled and torch.device(device).type == 'cuda' and torch.cuda.is_available() and not os.environ.get('MIOPEN_DISABLE_CACHE'):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+                enabled = False
+        if enabled and torch.device(device).type == 'cuda' and torch.cuda.is_available() and not os.environ.get('MIOPEN_DISABLE_CACHE'):
             root = os.environ.get('KBE_CACHE_DIR') or os.path.join(os.path.expanduser('~'), '.cache', 'kbe')
             dev = torch.cuda.get_device_name(device).replace(' ', '_')
-            name = '%s-%s-torch%s-hip%s' % (tag, dev, torch.__version__, getattr(torch.version, 'hip', None))
+            self.db_root, _ = _miopen_user_db()
+            name = '%s-%s-torch%s-hip%s-db%s' % (tag, dev, torch.__version__, getattr(torch.version, 'hip', None), hashlib.sha1(self.db_root.encode()).hexdigest()[:8])
             self.marker = os.path.join(root, 'miopen-tuned', name.replace('/', '_'))
             if os.path.exists(self.marker):
                 self.marker = None
@@ -126,15 +151,23 @@ class miopen_tuned_once:
         if self.marker is not None:
             import sys
             sys.stderr.write('ken_burns_effect_amd: first "%s" on this machine: MIOpen measures its convolution solvers once (tens of seconds; the '
-                             'results stay in its find-db, marker %s; KBE_MIOPEN_FIND=0 skips this)\n' % (self.tag, self.marker))
+                             'results stay in its find-db under %s, marker %s; KBE_MIOPEN_FIND=0 skips this)\n' % (self.tag, self.db_root, self.marker))
+            _, self.db_before = _miopen_user_db()
             torch.backends.cudnn.benchmark = True
         return self
 
     def __exit__(self, exc_type, exc, tb):
         import os
+        import sys
         if self.marker is not None:
             torch.backends.cudnn.benchmark = self.was
             if exc_type is None:
+                _, after = _miopen_user_db()
+                grew = any(size > self.db_before.get(path, 0) for path, size in after.items())
+                if not grew:
+                    sys.stderr.write('ken_burns_effect_amd: MIOpen kept nothing of that find step under %s (read-only or disabled find-db?): '
+                                     '"%s" is NOT marked tuned\n' % (self.db_root, self.tag))
+                    return False
                 try:
                     os.makedirs(os.path.dirname(self.marker), exist_ok=True)
                     open(self.marker, 'w').write('tuned\n')

@@ -404,8 +404,11 @@ def test_cropped_frames_ignore_holes_outside_the_crop(K, oracle):
     cw, ch = common.crop_size(settings)
     for f, (focal, shift3) in zip(frames, common.frame_cameras(settings, oc)):
         ref = oracle.crop_resize_u8(ok.render_frame(state, shift3, focal, oc['dblBaseline']).numpy(), cw, ch)
+        # (HIP against the oracle through the crop: the raw frames differ by one count on a few values -- the order of the fp32
+        # sums -- and one count at one raw value moves a CROPPED value by up to two in rare places, through the fixed-point
+        # getRectSubPix + resize: frames_close's `cropped` bound, found in round 4 by perturbing a raw frame value by value)
         d = np.abs(f.astype(np.int32) - ref.astype(np.int32))
-        assert d.max() <= 1 and (d > 0).mean() < 2e-3
+        assert d.max() <= 2 and (d > 0).mean() < 2e-3 and (d > 1).mean() < 1e-5, 'max %d, %.2e differ, %.2e by more than one' % (d.max(), (d > 0).mean(), (d > 1).mean())
 
 
 def test_native_frame_loop_equals_per_frame_calls(K):
@@ -709,6 +712,55 @@ def test_lean_and_roomy_builds_of_the_tile_launch_render_the_same_frames(K, monk
     for a, b in zip(frames['lean'], frames['roomy']):
         d = np.abs(a.astype(np.int32) - b.astype(np.int32))
         assert a.any() and d.max() <= 1 and (d > 0).mean() < 2e-3, 'lean against roomy: max %d, %.2e differ' % (d.max(), (d > 0).mean())
+
+
+@pytest.mark.parametrize('build', ['lean', 'roomy', 'no_ahead', 'dense', 'delivered'])
+def test_every_instantiation_of_the_tile_launch_against_the_oracle(K, oracle, monkeypatch, build):
+    """The tile launch of the fused route is ONE template in nine instantiations (kbe_fused.hip: lean / roomy / dense x a launch that
+    places ahead or not x one frame or a group).  The other tests of the group launches compare HIP with HIP; this one holds each
+    non-default instantiation against the ORACLE: a 26-frame video at 512 x 512 left in HBM -- twelve frames
+    per launch, so k_frame_group_ahead* runs, with k_place in front and k_frame_group* at the end -- every third frame against
+    oracle.render_frame on the same cloud (Jacobi schedule): one count on < 0.1 % of the values.  `lean` / `roomy`:
+    KBE_FUSED_CAP; `no_ahead`: KBE_AHEAD=0 (k_place + k_frame_group* per group); `dense`: four points per pixel (an upsampled
+    cloud: k_frame_group_ahead_dense, colours fetched behind the splat); `delivered`: to pinned host memory, cropped (the ramp's
+    groups of 1, 2, 4, ...: k_frame / k_frame_ahead as well)."""
+    from ken_burns_effect_amd import common, synthetic
+    size = 512
+    settings, oc = _scene((size, size), 5)
+    monkeypatch.setenv('KBE_FUSED', '1')
+    monkeypatch.setenv('KBE_FILL_GROUP', '12')
+    monkeypatch.setenv('KBE_LANES', '1')                # one lane: groups of 12, 12, 2 frames follow one another, each launch placing the next group
+    if build in ('lean', 'roomy'):
+        monkeypatch.setenv('KBE_FUSED_CAP', build)
+    if build == 'no_ahead':
+        monkeypatch.setenv('KBE_AHEAD', '0')
+    if build == 'dense':
+        up = 2
+        image_u, disp_u = synthetic.make_rgbd(size * up, size * up, 5)
+        depth_u = ((512.0 * 120) / (disp_u + 1e-7)).cuda()
+        oc['tensorInpaPoints'] = K.depth_to_points(depth_u, 512.0 * up).view(1, 3, -1)
+        oc['tensorInpaImage'] = image_u.cuda().reshape(1, 3, -1)
+        oc['tensorInpaDepth'] = depth_u.reshape(1, 1, -1)
+        oc['_kbeCloudRaster'] = (size * up, size * up * size * up)
+    n = 26
+    cams = common.frame_cameras(dict(settings, dblSteps=np.linspace(0.0, 1.0, n).tolist()), oc)
+    crop = None
+    if build == 'delivered':
+        crop = common.crop_size(settings)
+        frames = common.render_frames(cams, oc, crop)
+    else:
+        frames = c(common.render_frames(cams, oc, None, keep_on_device=True))
+    ok = oracle.OracleKernels('jacobi')
+    state = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), size, size)
+    for i in range(0, n, 3):
+        focal, shift3 = cams[i]
+        ref = ok.render_frame(state, shift3, focal, oc['dblBaseline']).numpy()
+        if crop is not None:
+            ref = oracle.crop_resize_u8(ref, crop[0], crop[1])
+        d = np.abs(frames[i].astype(np.int32) - ref.astype(np.int32))
+        bound = 2 if crop is not None else 1            # (through the crop's fixed point: frames_close)
+        assert ref.any() and d.max() <= bound and (d > 0).mean() < 1e-3 and (d > 1).mean() < 1e-5, \
+            '%s, frame %d: max %d, %.2e of the values differ' % (build, i, d.max(), (d > 0).mean())
 
 
 @pytest.mark.parametrize('kind', ['rough', 'near_plane'])

@@ -312,6 +312,53 @@ def test_partial_inpaint_forward_on_the_gpu_matches_reference(K):
     _close(out['tensorDisparity'], z['fw_disparity'], 2 * TOL_DISPARITY_REL * max(1.0, float(np.abs(z['fw_disparity']).max())), 'partial Inpaint disparity')
 
 
+def test_partial_inpaint_forward_with_a_fractional_mask_takes_the_unfused_pairs(K):
+    """The fused pairs of the partial GridNet skip the second `input * mask` (/root/reference/utils/partial_conv.py:61), which is
+    right for masks of 0 / 1 only.  Inpaint.forward(tensorMasks=...) is a public entry point: with a FRACTIONAL mask the forward
+    must still equal the reference's formulation (bench.partial_conv_reference_forward on every layer) -- it does because such
+    a call takes the unfused pairs -- and a mask that is not [B,1,H,W] is refused by kbe_prelu_mask's wrapper."""
+    import bench
+    from ken_burns_effect_amd import _native, partial_conv, partial_inpainting, synthetic
+    from ken_burns_effect_amd.partial_inpainting import Inpaint
+    net = synthetic.seeded_fill_(Inpaint().eval(), 5).cuda()
+    gen = torch.Generator(device='cpu').manual_seed(4)
+    H, W = 64, 96
+    data = torch.randn(1, 68, H, W, generator=gen).cuda()
+    mask = (torch.rand(1, 1, H, W, generator=gen) * (torch.rand(1, 1, H, W, generator=gen) > 0.2).float()).cuda()      # zeros and fractions
+    image, disp = synthetic.make_rgbd(H, W, 45, 'smooth')
+    seen = []
+    real = partial_inpainting._Pair._fused
+    with torch.no_grad():
+        net.normalize_images_disp(image.cuda(), disp.cuda(), not_normed=True)
+        partial_inpainting._Pair._fused = lambda self: (seen.append(real(self)), seen[-1])[1]
+        try:
+            got = {k: v.clone() for k, v in net(tensorData=data, tensorMasks=mask).items() if torch.is_tensor(v)}
+            assert seen and not any(seen), 'a fractional mask must not take the fused pairs'
+            del seen[:]
+            net(tensorData=data, tensorMasks=(mask > 0).float())
+            assert seen and all(seen), 'a 0 / 1 mask takes them'
+        finally:
+            partial_inpainting._Pair._fused = real
+        assert partial_inpainting._Pair.binary_masks is True
+        fused_forward = partial_conv.PartialConv2d.forward
+        partial_conv.PartialConv2d.forward = bench.partial_conv_reference_forward
+        for m in net.modules():
+            if isinstance(m, partial_conv.PartialConv2d):
+                m.last_size = (None, None, None, None)
+        try:
+            ref = {k: v.clone() for k, v in net(tensorData=data, tensorMasks=mask).items() if torch.is_tensor(v)}
+        finally:
+            partial_conv.PartialConv2d.forward = fused_forward
+            for m in net.modules():
+                if isinstance(m, partial_conv.PartialConv2d):
+                    m.last_size = (None, None, None, None)
+    assert torch.equal(got['tensorMaskOut'], ref['tensorMaskOut'])
+    _close(got['tensorImage'], ref['tensorImage'].cpu().numpy(), 2 * TOL_IMAGE, 'partial Inpaint image, fractional mask')
+    _close(got['tensorDisparity'], ref['tensorDisparity'].cpu().numpy(), 2 * TOL_DISPARITY_REL * max(1.0, float(ref['tensorDisparity'].abs().max())), 'partial Inpaint disparity, fractional mask')
+    with pytest.raises(_native.KbeError):
+        K.prelu_mask(torch.randn(1, 4, 8, 8, device='cuda'), torch.full((4,), 0.25, device='cuda'), torch.ones(1, 4, 8, 8, device='cuda'))
+
+
 def test_partial_inpaint_forward_at_1024_fused_epilogue_against_the_reference_formulation(K):
     """BASELINE configs[3] "4b" at its size: the partial-convolution Inpaint.forward on a 1024 x 1024 input (68 channels, a mask
     with a fifth of the pixels missing, in blobs and single pixels), every PartialConv2d through the fused epilogue

@@ -81,32 +81,48 @@ def test_pointcloud_inpainting_keeps_what_depends_on_the_image_alone_and_notices
     monkeypatch.setattr(net, '_context', lambda x: (calls.append(1), real(x))[1])
 
     def fresh(i, d, s):
-        net._kept_source = None
-        return net.pointcloud_inpainting(i, d, s, oc)
+        return net.pointcloud_inpainting(i, d, s, oc)           # (outside `keeping_source` nothing is kept)
     with torch.no_grad():
         want_a, want_b = fresh(image, disp, shift_a), fresh(image, disp, shift_b)
-        net._kept_source, n0 = None, len(calls)
-        got_a = net.pointcloud_inpainting(image, disp, shift_a, oc)
-        got_b = net.pointcloud_inpainting(image, disp, shift_b, oc)
-        assert len(calls) == n0 + 1, 'the second call of a pair runs no context network'
-        for got, want in ((got_a, want_a), (got_b, want_b)):
-            assert all(torch.equal(got[k], want[k]) for k in ('tensorImage', 'tensorDisparity', 'tensorExisting'))
-        # equal content in other tensors: not the kept entry
-        net.pointcloud_inpainting(image.clone(), disp, shift_b, oc)
-        assert len(calls) == n0 + 2
-        # the disparity changed in place: stale
-        net.pointcloud_inpainting(image, disp, shift_b, oc)
-        n1 = len(calls)
-        disp.mul_(1.25)
-        changed = net.pointcloud_inpainting(image, disp, shift_b, oc)
-        assert len(calls) == n1 + 1
+        assert getattr(net, '_kept_source', None) is None, 'a call outside keeping_source() keeps nothing'
+        with net.keeping_source():
+            n0 = len(calls)
+            got_a = net.pointcloud_inpainting(image, disp, shift_a, oc)
+            got_b = net.pointcloud_inpainting(image, disp, shift_b, oc)
+            assert len(calls) == n0 + 1, 'the second call of a pair runs no context network'
+            for got, want in ((got_a, want_a), (got_b, want_b)):
+                assert all(torch.equal(got[k], want[k]) for k in ('tensorImage', 'tensorDisparity', 'tensorExisting'))
+            # equal content in other tensors: not the kept entry
+            net.pointcloud_inpainting(image.clone(), disp, shift_b, oc)
+            assert len(calls) == n0 + 2
+            # the disparity changed in place: stale
+            net.pointcloud_inpainting(image, disp, shift_b, oc)
+            n1 = len(calls)
+            disp.mul_(1.25)
+            changed = net.pointcloud_inpainting(image, disp, shift_b, oc)
+            assert len(calls) == n1 + 1
+            # the context network's weights replaced without a version bump (what .to() / .half() do): stale
+            n1 = len(calls)
+            for p in net.moduleContext.parameters():
+                p.data = p.data.clone()
+            net.pointcloud_inpainting(image, disp, shift_b, oc)
+            assert len(calls) == n1 + 1
+            assert net._kept_source is not None
+        assert net._kept_source is None, 'leaving keeping_source() releases what was kept'
         want_changed = fresh(image, disp, shift_b)
         assert torch.equal(changed['tensorDisparity'], want_changed['tensorDisparity']) and not torch.equal(changed['tensorDisparity'], want_b['tensorDisparity'])
-    net._kept_source = None
+        # an exception between the two passes releases it too
+        with pytest.raises(RuntimeError):
+            with net.keeping_source():
+                net.pointcloud_inpainting(image, disp, shift_b, oc)
+                assert net._kept_source is not None
+                raise RuntimeError('between the passes')
+        assert net._kept_source is None
     n2 = len(calls)
-    net.pointcloud_inpainting(image, disp, shift_b, oc)
-    net.pointcloud_inpainting(image, disp, shift_b, oc)
-    assert len(calls) == n2 + 2 and net._kept_source is None, 'under autograd nothing is kept'
+    with net.keeping_source():
+        net.pointcloud_inpainting(image, disp, shift_b, oc)
+        net.pointcloud_inpainting(image, disp, shift_b, oc)
+        assert len(calls) == n2 + 2 and net._kept_source is None, 'under autograd nothing is kept'
 
 
 def test_train_mode_does_not_clamp(net):

@@ -2,7 +2,8 @@
 numpy restatement (what the HIP kernel k_crop_resize_u8 is tested against, tests/test_hip_parity.py) versus a second,
 independently written restatement that follows the structure of OpenCV's own implementation
 (tests/opencv_8u_restatement.c).  OpenCV is not installed here: agreement of two restatements catches transcription
-errors, it does not pin parity with cv2 -- DESIGN.md keeps that row "parity unpinned"."""
+errors, it does not pin parity with cv2 -- DESIGN.md keeps that row "parity unpinned".  The last two tests pin it the day an
+image with OpenCV runs them: they call cv2 itself, exactly as common.py:256-257 and pipeline.py:96 do, and are SKIPPED without it."""
 import ctypes
 import os
 import subprocess
@@ -62,3 +63,46 @@ def test_window_sticking_out_of_the_image_replicates_the_border(cvr):
     pad = np.pad(src, ((10, 10), (10, 10), (0, 0)), mode='edge')
     want = pad[10 + 1 - 4:10 + 1 + 5, 10 + 2 - 5:10 + 2 + 6]
     assert np.array_equal(dst, want)
+
+
+def test_against_cv2_itself_when_opencv_is_installed(oracle, cvr):
+    """THE pin of SURVEY 8f row 1: cv2.getRectSubPix + cv2.resize called as /root/reference/utils/common.py:256-257 calls them, on
+    the crops process_kenburns asks for (kbe.py:130-140) at 512^2 and 1024^2 (and an odd size), against the oracle's restatement
+    -- what the HIP kernel k_crop_resize_u8 is tested against byte for byte -- and the second restatement.  Skipped where OpenCV is
+    absent (this image); the first image with OpenCV >= 4 turns the row from "parity unpinned" to pinned, or names the bytes."""
+    cv2 = pytest.importorskip('cv2')
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    from ken_burns_effect_amd import common, synthetic
+    rng = np.random.default_rng(11)
+    for H, W in ((512, 512), (1024, 1024), (300, 400)):
+        noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:H, 0:W]
+        smooth = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) * 255 // max(W + H - 2, 1))], -1).astype(np.uint8)
+        for frame in (noise, smooth):
+            for dolly in (False, True):
+                ofrom, oto = synthetic.default_windows(H, W, dolly)
+                cw, ch = common.crop_size({'objectFrom': ofrom, 'objectTo': oto})
+                want = cv2.getRectSubPix(image=frame, patchSize=(cw, ch), center=(W / 2.0, H / 2.0))
+                want = cv2.resize(src=want, dsize=(W, H), fx=0.0, fy=0.0, interpolation=cv2.INTER_LINEAR)
+                for name, got in (('oracle.crop_resize_u8', oracle.crop_resize_u8(frame, cw, ch)), ('opencv_8u_restatement.c', _second(cvr, np.ascontiguousarray(frame), cw, ch))):
+                    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+                    assert np.array_equal(got, want), '%s vs cv2 %s at %dx%d crop %dx%d: %d of %d bytes differ, max %d' % (name, cv2.__version__, W, H, cw, ch, int((d > 0).sum()), d.size, int(d.max()))
+
+
+def test_min_max_loc_against_cv2_when_opencv_is_installed():
+    """cv2.minMaxLoc as /root/reference/utils/pipeline.py:96 calls it (the border-cropped depth map -> objectDepthrange) against
+    synthetic.depthrange_of: values and the tie-breaking of the two locations (first in row-major order).  Skipped without OpenCV."""
+    cv2 = pytest.importorskip('cv2')
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(HERE))
+    from ken_burns_effect_amd import synthetic
+    rng = np.random.default_rng(12)
+    for H, W in ((300, 400), (512, 512)):
+        depth = rng.random((H, W), dtype=np.float32) * 100 + 1
+        depth[140, 150] = depth[200, 170] = 0.5          # the minimum, twice
+        depth[150, 140] = depth[150, 260] = 500.0        # the maximum, twice
+        want = cv2.minMaxLoc(src=depth[128:-128, 128:-128], mask=None)
+        got = synthetic.depthrange_of(torch.from_numpy(depth).view(1, 1, H, W))
+        assert (float(got[0]), float(got[1]), tuple(got[2]), tuple(got[3])) == (float(want[0]), float(want[1]), tuple(want[2]), tuple(want[3]))

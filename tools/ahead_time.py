@@ -64,7 +64,7 @@ for n in (1, 5, 12):
 torch.cuda.synchronize()
 
 focal, shift3 = cams[len(cams) // 2]
-for n in (1, 2, 4, 8, 12):
+for n in ((1, 2, 4, 8, 12) if os.environ.get('IDENTICAL', '1') == '1' else ()):
     group = [(focal, shift3)] * n
     par = [0]
 
@@ -90,3 +90,83 @@ for n in (1, 2, 4, 8, 12):
     torch.cuda.synchronize()
     K.render_frame_group_fused(state, group, Bl, out[:n], stages=6)
     print('%2d frame(s) per launch: k_place + k_frame %.2f us per frame, pipelined (one launch) %.2f us per frame (arguments prepared: %.2f)' % (n, t_classic, t_ahead, t_prepared))
+
+
+# ---- the launch on a video's OWN groups: group k = cameras [n k, n k + n) of a path of PATHS steps (cyclic), the
+# launch of group k placing group k + 1 ahead -- the frames of a group share their candidate lists, built for the box between the
+# group's first and last camera, so twelve copies of one camera (above) are that scheme's best case
+import ctypes  # noqa: E402
+stats = (ctypes.c_ulonglong * 8)() if hasattr(K.lib, 'kbe_debug_frame_stats') else None
+for steps in [int(v) for v in os.environ.get('PATHS', '1024,75,20').split(',') if v]:
+    path = common.frame_cameras(dict(settings, dblSteps=[i / max(steps - 1, 1) for i in range(steps)]), oc)
+    for n in [int(v) for v in os.environ.get('GROUPS', '12,8,4').split(',') if v]:
+        groups = bench.consecutive_groups(path, n)
+        launches = [K.prepared_group_ahead(state, g, Bl, out[:n], groups[(k + 1) % len(groups)], stages=2) for k, g in enumerate(groups)]
+        turn = [0]
+
+        def run():
+            launches[turn[0] % len(launches)](turn[0], True)
+            turn[0] += 1
+        K.render_frame_group_ahead(state, groups[-1], Bl, out[:n], turn=0, placed=False, next_cameras=groups[0], stages=2)     # group 0's placements
+        turn[0] = 1
+        launches = launches[-1:] + launches[:-1]                    # launch index = turn: turn 1 renders group 0
+        # whole cycles of the path's groups per timed round (at least `reps` launches)
+        cycles = max(1, (reps + len(groups) - 1) // len(groups))
+        per = []
+        for _ in range(5):
+            for _ in range(cycles * len(groups)):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(cycles * len(groups)):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            per.append(e0.elapsed_time(e1) * 1e3 / (cycles * len(groups)) / n)
+        note = ''
+        if stats is not None:
+            K.lib.kbe_debug_frame_stats(stats, 1)
+            for _ in range(len(groups)):
+                run()
+            torch.cuda.synchronize()
+            K.lib.kbe_debug_frame_stats(stats, 1)
+            t = max(1, stats[0])
+            note = ' | per tile: list entries %.1f, candidates %.1f, in z reach %.0f, records %.0f; slow tiles %d, second round %d of %d' % (
+                stats[1] / t * n, stats[2] / t, stats[3] / t, stats[4] / t, stats[5], stats[6], stats[0])
+        # leave the sets clean: the sequence ends with a launch that places nothing
+        g_last = groups[(turn[0] - 1) % len(groups)]
+        K.render_frame_group_ahead(state, g_last, Bl, out[:n], turn=turn[0], placed=True, next_cameras=None, stages=6)
+        torch.cuda.synchronize()
+        K.render_frame_group_fused(state, g_last, Bl, out[:n], stages=6)
+        per.sort()
+        print('consecutive cameras, %4d-step path, %2d frames per launch (%d groups): %.2f us per frame (rounds %s)%s'
+              % (steps, n, len(groups), per[len(per) // 2], ' '.join('%.2f' % v for v in per), note))
+
+
+# ---- what a frame costs ALONG the path: twelve copies of the camera at POSITIONS of a 75-step path (identical cameras: the lists'
+# best case everywhere, so what differs between positions is the frame's own work -- records per tile, second rounds)
+for pos in [float(v) for v in os.environ.get('POSITIONS', '').split(',') if v]:
+    cam = common.frame_cameras(dict(settings, dblSteps=[pos]), oc)[0]
+    n = 12
+    group = [cam] * n
+    launch = K.prepared_group_ahead(state, group, Bl, out[:n], group, stages=2)
+    K.render_frame_group_ahead(state, group, Bl, out[:n], turn=0, placed=False, next_cameras=group, stages=2)
+    turn = [1]
+
+    def at_pos():
+        launch(turn[0], True)
+        turn[0] += 1
+    t = sorted(timed(at_pos, n) for _ in range(3))[1]
+    note = ''
+    if stats is not None:
+        K.lib.kbe_debug_frame_stats(stats, 1)
+        at_pos()
+        torch.cuda.synchronize()
+        K.lib.kbe_debug_frame_stats(stats, 1)
+        tl = max(1, stats[0])
+        note = ' | per tile: candidates %.1f, in z reach %.0f, records %.0f; slow tiles %d, second round %d of %d' % (stats[2] / tl, stats[3] / tl, stats[4] / tl, stats[5], stats[6], stats[0])
+    K.render_frame_group_ahead(state, group, Bl, out[:n], turn=turn[0], placed=True, next_cameras=None, stages=6)
+    torch.cuda.synchronize()
+    K.render_frame_group_fused(state, group, Bl, out[:n], stages=6)
+    print('camera at %.3f of the path, twelve copies per launch: %.2f us per frame%s' % (pos, t, note))
