@@ -10,7 +10,7 @@ cloud (z-splat, degrid, z-tested bilinear accumulate) -> disocclusion fill -> ui
 centred crop + resize -> the finished frame landing in pinned host memory (the `.cpu()` of
 common.py:255; SURVEY.md 8d counts it in the step).  The point cloud is resident in HBM when the
 timed region starts; frames are sharded over ranks (rank r renders steps r, r+N, ... of an N*K-step
-path).  Synthetic seeded RGBD input (no datasets / checkpoints are reachable offline).
+path; --video-frames: of ONE video, strong scaling).  Synthetic seeded RGBD input (no datasets / checkpoints are reachable offline).
 
 Timing: W untimed warm-up frames, then passes of EXACTLY K frames, each bracketed by barrier +
 synchronize on both sides (max over ranks), repeated until >= 0.5 s of timed wall; `value` is K * N /
@@ -143,7 +143,8 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
     from ken_burns_effect_amd import _native
     K = _native.kernels()
     W, H = oc['intWidth'], oc['intHeight']
-    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, oc['dblFocal'], raster=oc.get('_kbeCloudRaster'))
+    state = K.prepare_cloud(oc['tensorInpaPoints'], oc['tensorInpaImage'], oc['tensorInpaDepth'], W, H, oc['dblFocal'], raster=oc.get('_kbeCloudRaster'),
+                            near_depth=oc['objectDepthrange'][0] if oc.get('objectDepthrange') else None)
     focal, shift3 = cams[len(cams) // 2]
     Bl = oc['dblBaseline']
 
@@ -510,6 +511,9 @@ def main():
                                                             'Inpaint forward; a separate line, not the headline metric')
     ap.add_argument('--miopen-find', action='store_true', help='with --pipeline: torch.backends.cudnn.benchmark = True (MIOpen find step with a workspace)')
     ap.add_argument('--upsample', type=int, default=1, help='cloud of (upsample * size)^2 points (BASELINE configs[4]: 2; implies --cloud raw)')
+    ap.add_argument('--video-frames', type=int, default=0,
+                    help='STRONG scaling: one video of this many frames in all, sharded over the ranks (BASELINE configs[2]: 128); a step is still a frame, '
+                         'a pass renders the whole video once, --steps is ignored')
     ap.add_argument('--cloud', choices=['inpaint', 'raw'], default='inpaint',
                     help='inpaint: grow the cloud with the (seeded) Inpaint network as the pipeline does; raw: image pixels only')
     args = ap.parse_args()
@@ -592,7 +596,8 @@ def main():
 
     size = args.size
     ofrom, oto = synthetic.default_windows(size, size, args.dolly)
-    total_steps = args.steps * world_size
+    strong = args.video_frames > 0
+    total_steps = args.video_frames if strong else args.steps * world_size
     settings = {'dblSteps': np.linspace(0.0, 1.0, max(total_steps, 2)).tolist()[:total_steps], 'objectFrom': ofrom,
                 'objectTo': oto, 'boolInpaint': False, 'dolly': args.dolly}
     crop = None if args.no_crop else common.crop_size(settings)
@@ -608,11 +613,12 @@ def main():
     n_points = oc['tensorInpaPoints'].shape[-1]
     _, my_steps = sharding.shard_steps(settings['dblSteps'], rank, world_size)
     cams = common.frame_cameras(dict(settings, dblSteps=my_steps), oc)
+    n_mine = len(cams)                      # args.steps, or this rank's share of --video-frames
 
     # landing buffers of the timed runs are allocated (and every page touched) here, not in the loop
     delivery = 'hbm' if args.device_only else 'pinned_host'
-    host_out = None if args.device_only else torch.zeros(args.steps, size, size, 3, dtype=torch.uint8, pin_memory=True)
-    dev_out = torch.zeros(args.steps, size, size, 3, dtype=torch.uint8, device=device)
+    host_out = None if args.device_only else torch.zeros(max(n_mine, 1), size, size, 3, dtype=torch.uint8, pin_memory=True)
+    dev_out = torch.zeros(max(n_mine, 1), size, size, 3, dtype=torch.uint8, device=device)
 
     def run_host():
         return common.render_frames(cams, oc, crop, host_out=host_out, overlap=not args.no_overlap, batch=args.batch)
@@ -621,7 +627,7 @@ def main():
         return common.render_frames(cams, oc, crop, keep_on_device=True, host_out=dev_out)
 
     # warm-up (untimed): W frames on both routes (clocks, staging buffers, streams, first-touch of the pinned pages)
-    nw = max(args.warmup, 1)
+    nw = max(min(args.warmup, n_mine), 1)
     common.render_frames(cams[:nw], oc, crop, keep_on_device=True, host_out=dev_out[:nw])
     if host_out is not None:
         common.render_frames(cams[:nw], oc, crop, host_out=host_out[:nw], overlap=not args.no_overlap, batch=args.batch)
@@ -676,11 +682,11 @@ def main():
     frames_check = None
     if host_out is not None:
         worst = 0
-        for k in (0, args.steps // 2, args.steps - 1):
+        for k in (0, n_mine // 2, n_mine - 1):
             d = (host_out[k].to(torch.int16) - dev_out[k].cpu().to(torch.int16)).abs()
             worst = max(worst, int(d.max()))
             frames_check = max(frames_check or 0.0, float((d > 0).float().mean()))
-        frames_check = {'max_abs_diff': worst, 'worst_fraction_differing': frames_check, 'frames': [0, args.steps // 2, args.steps - 1],
+        frames_check = {'max_abs_diff': worst, 'worst_fraction_differing': frames_check, 'frames': [0, n_mine // 2, n_mine - 1],
                         'ok': worst <= 1 and frames_check < 1e-3}
         if not frames_check['ok']:
             sys.stderr.write('bench.py: DELIVERED FRAMES DIFFER from the frames left in HBM: %s\n' % frames_check)
@@ -700,7 +706,7 @@ def main():
         # cameras in groups of `group_frames`: time_kernels)
         paths = {}
         if not args.dolly:
-            for n_steps in dict.fromkeys((args.steps * world_size, PRODUCT_STEPS, DRIVER_STEPS)):
+            for n_steps in dict.fromkeys((total_steps, PRODUCT_STEPS, DRIVER_STEPS)):
                 paths[str(n_steps)] = common.frame_cameras(dict(settings, dblSteps=np.linspace(0.0, 1.0, max(n_steps, 2)).tolist()[:n_steps]), oc)
         kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames,
                           fill_flags=fill_flags, paths=paths)
@@ -777,18 +783,20 @@ def main():
             cameras_note = 'consecutive: groups of %d consecutive cameras of a %d-step path, group k placing group k + 1 ahead' % (group_frames, PRODUCT_STEPS)
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
-            'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': args.steps * world_size / elapsed,
-            'unit': 'frames/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': total_steps / elapsed,
+            'unit': 'frames/s', 'n_gpus': world_size, 'steps': total_steps if strong else args.steps, 'warmup': args.warmup,
+            # (weak: K frames per rank and pass; strong, --video-frames: ONE video of K frames per pass, sharded over the ranks)
+            'ms_per_step': elapsed / (total_steps if strong else args.steps) * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%dx%d %s path, %d pts (%s cloud), frame=shift+scatter+fill+u8%s' % (
                            size, size, 'dolly' if args.dolly else 'KBE', n_points, cloud, '' if crop is None else '+crop/resize'),
-                       'delivery': delivery, 'scatter_route': route, 'frames_per_rank': args.steps, 'lanes': lanes if args.device_only else host_lanes,
+                       'delivery': delivery, 'scatter_route': route, 'frames_per_rank': n_mine, 'lanes': lanes if args.device_only else host_lanes,
                        'device_only_lanes': lanes, 'passes': len(times),
                        'pass_ms': {'median': round(elapsed * 1e3, 3), 'min': round(min(times) * 1e3, 3), 'max': round(max(times) * 1e3, 3)},
-                       'sharding': 'frames round-robin over ranks; one cloud broadcast (set-up, cloud_broadcast_ms)',
+                       'sharding': 'frames %s over ranks (sharding.shard_indices); one cloud broadcast (set-up, cloud_broadcast_ms)' % os.environ.get('KBE_SHARD_SHAPE', sharding.SHARD_SHAPE),
+                       'handoff': ('sdma' if _native.handoff_by_sdma() else 'blit (hipMemcpyAsync)') if not args.device_only else None,
                        'collectives': backend if world_size > 1 else None, 'ranks_seen': ranks_seen},
-            'device_only': {'value': args.steps * world_size / elapsed_dev, 'unit': 'frames/s', 'ms_per_step': elapsed_dev / args.steps * 1e3,
+            'device_only': {'value': total_steps / elapsed_dev, 'unit': 'frames/s', 'ms_per_step': elapsed_dev / (total_steps if strong else args.steps) * 1e3,
                             'passes': len(times_dev), 'note': 'same K frames left in HBM (no PCIe hand-off)'},
             'roofline': {'bound': 'hbm', 'kernel': main['kernel'] + ' (the scatter = render_pointcloud, %s route)' % route,
                          'achieved': main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': main['frac'],
@@ -827,7 +835,7 @@ def main():
                 line['invalid'] = 'delivered frames differ from the frames left in HBM'
                 line['value_of_the_wrong_frames'], line['value'] = line['value'], None
         if not args.device_only:
-            line['pcie'] = {'achieved': args.steps * size * size * 3 / elapsed / 1e9, 'unit': 'GB/s per GPU', 'peak': 63.0,
+            line['pcie'] = {'achieved': n_mine * size * size * 3 / elapsed / 1e9, 'unit': 'GB/s per GPU (rank 0)', 'peak': 63.0,
                             'note': 'uint8 frames of %.2f MB over PCIe Gen5 x16 (63 GB/s spec, ~57 measured with hipMemcpyAsync on an idle chip)'
                                     % (size * size * 3 / 1e6)}
         if world_size > 1:

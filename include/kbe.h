@@ -288,16 +288,19 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
  * `next`), else a placement launch is made in front of the tile launch.  n_next > 0: the tile launch makes the placements
  * of the frames next_* (the cameras, sets and turns the next call will render with; a set that both groups use has
  * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
- * than the raster keeps its placement launch).  A group placed ahead whose cameras are consecutive steps of ONE straight path
- * (same focal length, shifts on a line in frame order) shares one set of candidate lists, kept in the scratch set of its first frame:
- * the library decides that from the cameras alone in both calls, so the `next` cameras of one call must be the cameras of the next
- * call (they already must).  Everything else as kbe_render_frame_group_fused; same results. */
+ * than the raster keeps its placement launch).  near_depth > 0 (the depth of the nearest point the caller knows of: the
+ * reference's objectDepthrange[0], common.py:88; 0 = unknown): consecutive frames of a group placed ahead whose cameras differ
+ * in their shifts only share candidate lists in sub-groups of 12, 8, 6, 4, 3 or 2 frames -- as many as keep the nearest point
+ * within 16 pixels between a sub-group's first and last camera -- kept in the scratch set of each sub-group's first frame: the
+ * library decides that from the cameras and near_depth alone in both calls, so the `next` cameras of one call must be the
+ * cameras of the next call (they already must) and near_depth the same.  Everything else as kbe_render_frame_group_fused; same
+ * results. */
 KBE_API int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_next);
 KBE_API int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames,
                                          const double* focals, const float* shifts, void* const* scratch, uint8_t* const* frames_u8,
                                          const int* turns, int placed, int n_next, const double* next_focals, const float* next_shifts,
                                          void* const* next_scratch, const int* next_turns, int stages, const int* fill_rect,
-                                         kbe_stream_t stream);
+                                         double near_depth, kbe_stream_t stream);
 
 /* render_pointcloud (common.py:428-686) for one sample and ANY channel count on the tile machinery of the frame loop
  * (no accumulator in HBM, no floating-point atomic): z-splat + buckets, then per 32x16 tile degrid and a
@@ -368,6 +371,13 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * instead of 6, a 75-frame video 6 instead of 8).  The last group takes what is left.  (Measured: no gain on MI355X -- the larger
  * groups render next to the other lane's transfer and are slowed by it; the Python host side leaves it off.) */
 #define KBE_VIDEO_FAST_RAMP 1024
+/* batch < 0, frames to pinned host memory: the groups leave through an SDMA engine driven through HSA
+ * (hsa_amd_memory_async_copy_on_engine; the copy's dependency signal is released and its completion signal awaited by one-lane
+ * kernels in the lanes' streams, so the call stays asynchronous and `stream` still sees every frame delivered) instead of the
+ * runtime's hipMemcpyAsync, which is a blit kernel on the compute units.  The engine takes the groups in order: no turns.
+ * Falls back to hipMemcpyAsync when HSA does not report an engine for the two buffers.  The one piece of process-wide state the
+ * library keeps belongs to this flag: a pool of HSA signals, reused once the call that used them has run to its end. */
+#define KBE_VIDEO_SDMA 8192
 /* fused route: force the lean / the roomy build of the tile launches (KBE_STAGE_FUSED_LEAN / _ROOMY for every frame) */
 #define KBE_VIDEO_FUSED_LEAN 2048
 #define KBE_VIDEO_FUSED_ROOMY 4096
@@ -376,7 +386,8 @@ KBE_API int kbe_render_video(const float* points, const float* image, const floa
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
                              int raster_w, int raster_n, const void* packed, double cloud_focal, int flags,
-                             kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams);
+                             kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams,
+                             double near_depth);
 
 /* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where
  * point i of points[B,3,N] + shift[B,3] (a DEVICE array, the tensorShift of :690) owns the pixel its z-splat

@@ -14,7 +14,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libkbe_hip.so')
+LIB_PATH = os.environ.get('KBE_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libkbe_hip.so')      # (KBE_LIB_PATH: a variant build of the same ABI -- measurements)
 
 # every symbol include/kbe.h declares (tests check the library exports exactly these)
 SYMBOLS = (
@@ -30,6 +30,9 @@ DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over 
 FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
                                  # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
                                  # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
+GENERIC_MIN_DENSITY = 8.0        # clouds denser than this take the stage-by-stage kernels with global atomics (HipKernels._render_video_generic): beyond ~8 points
+                                 # per pixel a tile's bucket (12 records per pixel) and the fused route's lists overflow on the densest tiles and both tile
+                                 # routes fall off a cliff (9 per pixel: 7-8 ms per 1024^2 frame), while the atomic path scales linearly (~0.1 ns per point)
 FUSED_MAX_POINTS = 1 << 28       # the packed cloud's route addresses points by 32-bit byte offsets (KBE_FUSED_MAX_POINTS, kbe_tiles.h): larger clouds take the bucket route
 FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
@@ -142,6 +145,14 @@ def fused_build_bits(video=False):
     if cap not in ('lean', 'roomy'):
         return 0
     return ((2048 if cap == 'lean' else 4096) if video else (1024 if cap == 'lean' else 2048))
+
+
+HANDOFF_DEFAULT = 'blit'    # until the SDMA hand-off has been measured against it (KBE_HANDOFF=sdma|blit)
+
+
+def handoff_by_sdma():
+    """Do a delivered video's frame groups leave through an SDMA engine (KBE_VIDEO_SDMA) or through hipMemcpyAsync (a blit kernel)?"""
+    return os.environ.get('KBE_HANDOFF', HANDOFF_DEFAULT) == 'sdma'
 
 
 def stride_of(K, state):
@@ -276,7 +287,7 @@ class HipKernels:
         return out
 
     # -- the frame loop on the resident cloud ---------------------------------------------
-    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None):
+    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None, near_depth=None):
         """Makes tensorInpaPoints/Image/Depth resident for the frame loop: contiguous fp32 views (used in
         place, no repacking) plus the per-view scratch (z-buffer, tile buckets, hole list), initialised
         once.  Returns the state render_frame consumes."""
@@ -310,11 +321,30 @@ class HipKernels:
         # dolly zoom-out (the image shrinks, the density grows along the video) 97 / 151.  KBE_FUSED = auto (default: fused
         # unless the cloud has more than 1.5 points per pixel; render_video also looks at the camera path) | 1 | 0.
         mode = os.environ.get('KBE_FUSED', 'auto')
-        state['fused'] = ((N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode != '0') and N <= FUSED_MAX_POINTS
+        state['fused'] = ((N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode not in ('0', 'generic')) and N <= FUSED_MAX_POINTS
+        # ... and a third for clouds far denser than the raster: the reference's own decomposition (z-splat, degrid, accumulate with
+        # global atomics, normalise, fill), one frame at a time -- see GENERIC_MIN_DENSITY
+        state['generic'] = (N > GENERIC_MIN_DENSITY * W * H) if mode == 'auto' else mode == 'generic'
         state['cloud_focal'] = float(focal) if focal else 512.0
+        # the depth of the nearest point (the reference's objectDepthrange[0], common.py:88, when the caller has it; else found
+        # on first need): decides how many consecutive frames of a video share candidate lists (include/kbe.h: near_depth)
+        state['near_depth'] = None if near_depth is None else max(0.0, float(near_depth))
         if state['fused']:
             self._pack(state)
         return state
+
+    @staticmethod
+    def near_depth(state):
+        """The nearest depth of the cloud, for kbe_render_video / kbe_render_frame_group_ahead's `near_depth` (KBE_SHARE_LISTS=0: 0.0,
+        every frame keeps candidate lists of its own).  Found with one reduction and one host synchronisation where the caller of
+        prepare_cloud did not pass it."""
+        if os.environ.get('KBE_SHARE_LISTS') == '0':
+            return 0.0
+        if state.get('near_depth') is None:
+            z = state['points'][2]
+            z = z[z > 0]
+            state['near_depth'] = float(z.min()) if z.numel() else 0.0
+        return state['near_depth']
 
     def _pack(self, state):
         """kbe_cloud_pack, once per cloud (on first use of the fused route)."""
@@ -416,7 +446,7 @@ class HipKernels:
         rect = None if fill_rect is None else (ctypes.c_int * 4)(*[int(v) for v in fill_rect])
         self._check(self.lib.kbe_render_frame_group_ahead(_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']),
                                                           _i(state['H']), _d(float(baseline)), _i(n), focals, shifts, sets, frames, turns, _i(1 if placed else 0),
-                                                          _i(m), nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), rect, _stream()), 'kbe_render_frame_group_ahead')
+                                                          _i(m), nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), rect, _d(self.near_depth(state)), _stream()), 'kbe_render_frame_group_ahead')
         return out
 
     def prepared_group_ahead(self, state, cameras, baseline, out, next_cameras, stages=2):
@@ -437,7 +467,7 @@ class HipKernels:
         turns, nturns = (ctypes.c_int * n)(), (ctypes.c_int * m)()
         fixed = (_ptr(state['packed'], torch.uint8), _i(state['N']), _d(state['cloud_focal']), _i(state['W']), _i(state['H']), _d(float(baseline)), _i(n),
                  focals, shifts, sets, frames, turns)
-        tail = (nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), None)
+        tail = (nf, ns, nsets, nturns, _i(int(stages) | fused_build_bits()), None, _d(self.near_depth(state)))
         fn, check, zero = self.lib.kbe_render_frame_group_ahead, self._check, _i(0)
         keep = (scratch, out)          # (the arrays hold raw addresses)
 
@@ -553,6 +583,27 @@ class HipKernels:
         state['delivery_probe_us'] = render_us
         return cache[key]
 
+    def _render_video_generic(self, state, cameras, baseline, crop, host_out):
+        """The frame loop on the stage-by-stage kernels (kbe_shift_points, kbe_render_pointcloud's z-splat / degrid / accumulate /
+        normalise with global atomics, kbe_fill_disocclusion, kbe_frame_u8, kbe_crop_resize_u8) -- the reference's own decomposition
+        of common.py:238-257, for clouds so much denser than the raster that the tile routes' per-tile capacities overflow
+        (GENERIC_MIN_DENSITY).  Frame by frame from Python: at ~1 ms of GPU work per frame the loop's own cost does not matter."""
+        n, W, H = len(cameras), state['W'], state['H']
+        dev = state['points'].device
+        if 'generic_data' not in state:
+            state['generic_data'] = torch.cat([state['image'], state['depth'].reshape(1, -1)], 0).unsqueeze(0).contiguous()      # [1,4,N]: image; depth
+        pts0, data = state['points'].unsqueeze(0), state['generic_data']
+        out = host_out if host_out.is_cuda else torch.empty(n, H, W, 3, dtype=torch.uint8, device=dev)
+        for i, (focal, shift3) in enumerate(cameras):
+            pts = self.shift_points(pts0, shift3)                                                           # common.py:104-109
+            render, existing = self.render_pointcloud(pts, data, W, H, focal, baseline, tiled=False)        # :428-686
+            render = self.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())              # :253
+            frame = self.frame_u8(render[:, 0:3])                                                           # :255
+            out[i].copy_(frame if crop is None else self.crop_resize_u8(frame, int(crop[0]), int(crop[1])))  # :256-257
+        if not host_out.is_cuda:
+            host_out[:n].copy_(out, non_blocking=True)
+        return host_out
+
     def render_video(self, state, cameras, baseline, crop=None, host_out=None, overlap=True, batch=None):
         """The frame loop for a list of (focal, shift3) cameras, enqueued natively; returns the pinned host
         tensor [n,H,W,3] the frames land in (valid after the current stream is synchronised).  ``host_out`` may
@@ -564,6 +615,10 @@ class HipKernels:
         if host_out is None:
             host_out = torch.empty(n, H, W, 3, dtype=torch.uint8, pin_memory=True)
         assert host_out.dtype == torch.uint8 and host_out.is_contiguous() and host_out.numel() >= n * H * W * 3
+        if state.get('generic'):
+            if not host_out.is_cuda and not host_out.is_pinned():
+                raise KbeError('render_video: host_out must be pinned host memory (or a device tensor)')
+            return self._render_video_generic(state, cameras, baseline, crop, host_out)
         lanes = state['lanes']
         if host_out.is_cuda:
             batch, overlap = 0, False
@@ -618,6 +673,8 @@ class HipKernels:
         if os.environ.get('KBE_AHEAD') == '0':              # KBE_VIDEO_NO_AHEAD: every group of the fused route keeps its own placement launch
             flags |= 512
         flags |= fused_build_bits(video=True)               # KBE_FUSED_CAP: KBE_VIDEO_FUSED_LEAN / _ROOMY
+        if not host_out.is_cuda and batch < 0 and handoff_by_sdma():
+            flags |= 8192                                   # KBE_VIDEO_SDMA
         keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again
         scratch = state['scratch']
         if group > 1:
@@ -638,7 +695,7 @@ class HipKernels:
                                               _ptr(scratch, torch.uint8), _ptr(state['stage'], torch.uint8), _i(batch),
                                               ctypes.c_void_p(host_out.data_ptr()), _i(state['raster_w']), _i(state['raster_n']),
                                               _ptr(state['packed'], torch.uint8) if fused else None, _d(state['cloud_focal']),
-                                              _i(flags), _stream(), copy_stream, _i(lanes), lane_streams), 'kbe_render_video')
+                                              _i(flags), _stream(), copy_stream, _i(lanes), lane_streams, _d(self.near_depth(state) if fused else 0.0)), 'kbe_render_video')
         return host_out
 
     def generate_mask_raw(self, points, shift, W, H, focal, baseline, want_tables=False):

@@ -307,8 +307,11 @@ def _prepared_cloud(K, objectCommon):
     key = (K.name, objectCommon['intWidth'], objectCommon['intHeight']) + tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
     cached = objectCommon.get('_kbePreparedCloud')
     if cached is None or cached[0] != key:
+        kw = {}
+        if getattr(K, 'name', '') == 'hip' and objectCommon.get('objectDepthrange') is not None:
+            kw['near_depth'] = objectCommon['objectDepthrange'][0]      # the closest depth process_shift works with (common.py:88)
         state = K.prepare_cloud(tensors[0], tensors[1], tensors[2], objectCommon['intWidth'], objectCommon['intHeight'],
-                                objectCommon['dblFocal'], raster=objectCommon.get('_kbeCloudRaster'))
+                                objectCommon['dblFocal'], raster=objectCommon.get('_kbeCloudRaster'), **kw)
         cached = (key, state, tensors)        # keeps the tensors alive so that data_ptr stays a valid identity
         objectCommon['_kbePreparedCloud'] = cached
     if '_kbeDeliveryLanes' in objectCommon:   # measured by rank 0 and broadcast with the cloud (sharding.py): no probe on this rank

@@ -33,7 +33,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/amd_hsa_signal.h>
 
 #include "kbe_cloud.h"
 #include "kbe_tiles.h"
@@ -723,6 +727,108 @@ __global__ void __launch_bounds__(64) k_turn(DeliverCtl* ctl, int pass, int max_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The hand-off by an SDMA ENGINE (KBE_VIDEO_SDMA; round 5).  hipMemcpyAsync device-to-host is a blit KERNEL on this runtime:
+// it takes wave slots next to the rendering and sits in the lane's stream, so the lane's next group cannot start before its
+// last one has left.  HSA drives the DMA engines directly (hsa_amd_memory_async_copy_on_engine), and a copy can be ordered
+// against HIP streams from the GPU side alone (tools/sdma_probe.hip): the host enqueues the copy of a group at once with a
+// DEPENDENCY signal the engine polls, a one-lane kernel behind the group's last launch stores 0 into that signal's value, and
+// whoever needs the copy done -- the lane before it renders into the same slots again, `stream` at the end of the call -- runs
+// a one-lane kernel that polls the copy's COMPLETION signal.  The engine takes the copies in the order they were enqueued:
+// the lanes need no turns.  The signals live in a process-wide pool (the one piece of state the library keeps: they must
+// outlive the call, which returns before the copies run) and are reused once the call that used them has run to its end.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_signal_release(volatile int64_t* value)
+{
+    if (threadIdx.x != 0) return;
+    __threadfence_system();
+    __hip_atomic_store((int64_t*) value, (int64_t) 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// bounded (~2 s): an engine that never reports is a dead device, and a kernel that polls for ever would hide that
+__global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, int max_polls)
+{
+    if (threadIdx.x != 0) return;
+    for (int polls = 0; polls < max_polls; polls++) {
+        if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+constexpr int SDMA_MAX_POLLS = 2000000;
+
+struct SdmaPair { hsa_signal_t dep, fin; };
+struct SdmaGeneration { hipEvent_t done; std::vector<SdmaPair> pairs; };
+struct SdmaPool {
+    std::mutex mu;
+    int state = 0;                              // 0 = not tried, 1 = HSA is up, -1 = it is not
+    std::vector<SdmaPair> idle;
+    std::vector<SdmaGeneration> running;
+};
+static SdmaPool& sdma_pool() { static SdmaPool* p = new SdmaPool; return *p; }         // (never destroyed: the signals must not die before the runtime)
+static volatile int64_t* signal_value(hsa_signal_t sg) { return &((amd_signal_t*) sg.handle)->value; }
+struct SdmaCall {                               // one kbe_render_video call's use of the engine
+    bool ok = false;
+    hsa_agent_t gpu = {}, cpu = {};
+    hsa_amd_sdma_engine_id_t engine = HSA_AMD_SDMA_ENGINE_0;
+    std::vector<SdmaPair> used;
+};
+// which agents own the two buffers, and an engine that copies from the one to the other; false: no SDMA hand-off (the caller
+// falls back to hipMemcpyAsync)
+static bool sdma_open(SdmaCall& c, const void* device_buffer, const void* host_buffer)
+{
+    SdmaPool& pool = sdma_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (pool.state == 0) pool.state = hsa_init() == HSA_STATUS_SUCCESS ? 1 : -1;       // (reference-counted: HIP's own runtime holds it up already)
+    if (pool.state < 0) return false;
+    hsa_amd_pointer_info_t dinfo = {}, hinfo = {};
+    dinfo.size = hinfo.size = sizeof(hsa_amd_pointer_info_t);
+    if (hsa_amd_pointer_info(device_buffer, &dinfo, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || dinfo.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+    if (hsa_amd_pointer_info(host_buffer, &hinfo, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || hinfo.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+    hsa_device_type_t dt, ht;
+    if (hsa_agent_get_info(dinfo.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS || dt != HSA_DEVICE_TYPE_GPU) return false;
+    if (hsa_agent_get_info(hinfo.agentOwner, HSA_AGENT_INFO_DEVICE, &ht) != HSA_STATUS_SUCCESS || ht != HSA_DEVICE_TYPE_CPU) return false;
+    uint32_t avail = 0, preferred = 0;
+    if (hsa_amd_memory_copy_engine_status(hinfo.agentOwner, dinfo.agentOwner, &avail) != HSA_STATUS_SUCCESS || !avail) return false;
+    if (hsa_amd_memory_get_preferred_copy_engine(hinfo.agentOwner, dinfo.agentOwner, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
+    const uint32_t pick = (preferred & avail) ? (preferred & avail) : avail;
+    c.engine = (hsa_amd_sdma_engine_id_t) (pick & (~pick + 1u));            // its lowest engine
+    c.gpu = dinfo.agentOwner; c.cpu = hinfo.agentOwner;
+    // the signals of calls that have run to their end are idle again
+    for (size_t g = 0; g < pool.running.size(); ) {
+        if (hipEventQuery(pool.running[g].done) == hipSuccess) {
+            (void) hipEventDestroy(pool.running[g].done);
+            pool.idle.insert(pool.idle.end(), pool.running[g].pairs.begin(), pool.running[g].pairs.end());
+            pool.running[g] = std::move(pool.running.back());
+            pool.running.pop_back();
+        } else {
+            (void) hipGetLastError();       // hipErrorNotReady is not an error here
+            g++;
+        }
+    }
+    return c.ok = true;
+}
+static bool sdma_pair(SdmaCall& c, SdmaPair& p)
+{
+    SdmaPool& pool = sdma_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (!pool.idle.empty()) { p = pool.idle.back(); pool.idle.pop_back(); }
+    else if (hsa_signal_create(1, 0, nullptr, &p.dep) != HSA_STATUS_SUCCESS || hsa_signal_create(1, 0, nullptr, &p.fin) != HSA_STATUS_SUCCESS) return false;
+    hsa_signal_store_relaxed(p.dep, 1);
+    hsa_signal_store_relaxed(p.fin, 1);
+    c.used.push_back(p);
+    return true;
+}
+// the call is enqueued: its signals are idle again once `stream` has run past this point
+static void sdma_close(SdmaCall& c, hipStream_t stream)
+{
+    if (c.used.empty()) return;
+    SdmaPool& pool = sdma_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    SdmaGeneration g;
+    g.pairs.swap(c.used);
+    if (hipEventCreateWithFlags(&g.done, hipEventDisableTiming) == hipSuccess && hipEventRecord(g.done, stream) == hipSuccess) pool.running.push_back(std::move(g));
+    // (else: the pairs are dropped -- a leak of a few signals, never a reuse that is too early)
+}
+
 __global__ void __launch_bounds__(DELIVER_THREADS) k_deliver(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes,
                                                              DeliverCtl* ctl, uint32_t ticket)
 {
@@ -1016,11 +1122,12 @@ int kbe_render_frame_group_ahead_ok(int N, int W, int H, int n_frames, int n_nex
 int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, int W, int H, double baseline, int n_frames, const double* focals,
                                  const float* shifts, void* const* scratch, uint8_t* const* frames_u8, const int* turns, int placed, int n_next,
                                  const double* next_focals, const float* next_shifts, void* const* next_scratch, const int* next_turns, int stages,
-                                 const int* fill_rect, kbe_stream_t stream)
+                                 const int* fill_rect, double near_depth, kbe_stream_t stream)
 {
     KBE_REQUIRE(packed && n_frames >= 1 && n_frames <= KBE_FRAME_JOBS && focals && shifts && scratch && frames_u8 && turns && N >= 0 && N <= KBE_FUSED_MAX_POINTS && W > 0 && H > 0 &&
                 (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24) && cloud_focal > 0.0, "kbe_render_frame_group_ahead: bad arguments");
     KBE_REQUIRE(n_next >= 0 && n_next <= KBE_FRAME_JOBS && (n_next == 0 || (next_focals && next_shifts && next_scratch && next_turns)), "kbe_render_frame_group_ahead: bad next group");
+    KBE_REQUIRE(near_depth >= 0.0 && near_depth < 1.0e30, "kbe_render_frame_group_ahead: near_depth is a depth (0: unknown)");
     KBE_REQUIRE(n_next == 0 || fused_can_place_ahead(N, W, H, n_frames, n_next), "kbe_render_frame_group_ahead: too many placements for the tile launch (kbe_render_frame_group_ahead_ok)");
     static const FillDirs dirs = make_fill_dirs();
     const hipStream_t s = (hipStream_t) stream;
@@ -1065,7 +1172,7 @@ int kbe_render_frame_group_ahead(const void* packed, int N, double cloud_focal, 
             if (e != hipSuccess) return fail(KBE_E_LAUNCH, "kbe_render_frame_group_ahead: hipMemsetAsync", e);
         }
     if (stages & KBE_STAGE_TILES) {
-        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt, fused_build_of_stages(stages));
+        launch_frames_fused(s, n_frames, packed, N, cloud_focal, ft, placed != 0, n_next, nt, fused_build_of_stages(stages), near_depth);
         if ((rc = launched("kbe_render_frame_group_ahead/scatter"))) return rc;
     }
     if (stages & KBE_STAGE_FILL) {
@@ -1109,16 +1216,20 @@ int kbe_render_pointcloud_tiled(const float* points, const float* data, int N, i
 static double trace_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #endif
 constexpr int KBE_VIDEO_STAGES = KBE_STAGE_PROJECT | KBE_STAGE_TILES | KBE_STAGE_FILL;
+#ifndef KBE_HBM_CONSECUTIVE
+#define KBE_HBM_CONSECUTIVE 1
+#endif
 int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H, double baseline,
                      int n_frames, const double* focals, const float* shifts, int crop_w, int crop_h, void* scratch,
                      uint8_t* stage, int batch, uint8_t* host_out, int raster_w, int raster_n, const void* packed,
                      double cloud_focal, int flags, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
-                     const kbe_stream_t* lane_streams)
+                     const kbe_stream_t* lane_streams, double near_depth)
 {
     KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64 && (!packed || cloud_focal > 0.0),
                 "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
     KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
+    KBE_REQUIRE(near_depth >= 0.0 && near_depth < 1.0e30, "kbe_render_video: near_depth is a depth (0: unknown)");
     const hipStream_t cs = (hipStream_t) stream;
     const size_t fb = (size_t) W * H * 3;
     const size_t sb = (scratch_set_bytes(W, H, N) + 255) & ~(size_t) 255;      // == kbe_video_scratch_stride: lane stride
@@ -1320,7 +1431,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                     nt[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), carve(scr, W, H), scratch_place(scr, W, H), k & 1, nullptr, nullptr, nullptr, nullptr, nullptr, k };
                 }
             }
-            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0));
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0), near_depth);
             lane_placed[l] = n_next > 0;
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };
@@ -1340,6 +1451,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         if (ringed && ds[0] != cs && ok) { hipEvent_t e = make(); if (e) { (void) hipEventRecord(e, ds[0]); (void) hipStreamWaitEvent(cs, e, 0); } }
     };
     int rc = KBE_OK;
+    SdmaCall sdma;
     if (!ringed && !per_frame) {
         // host_out is device memory: the last kernel of every frame stores straight into it (the frames stay in HBM)
         if (pairs) {
@@ -1352,7 +1464,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                         int idx[KBE_FRAME_JOBS], count = 0;
                         uint8_t* outs[KBE_FRAME_JOBS];
                         for (int m = 0; m < group; m++) {
-                            const int i = base + m * lanes + l;
+                            // (a launch takes CONSECUTIVE frames -- consecutive cameras share candidate lists, kbe_fused.hip: share_plan;
+                            // until round 5 lane l took frames l, l + lanes, ...: cameras `lanes` steps apart in every launch)
+                            const int i = KBE_HBM_CONSECUTIVE ? base + l * group + m : base + m * lanes + l;
                             if (i < n_frames) { idx[count] = i; outs[count++] = host_out + (size_t) i * fb; }
                         }
                         if (count) rc = render_group(l, count, idx, outs);
@@ -1380,6 +1494,11 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
         } else {
             const int G = -batch;
+            // KBE_VIDEO_SDMA: the groups leave through an SDMA engine (above); whatever keeps HSA from it falls back to the runtime's
+            // transfers, group by group
+            if ((flags & KBE_VIDEO_SDMA) && n_groups > 0) (void) sdma_open(sdma, stage, host_out);
+            volatile int64_t* lane_fin[KBE_MAX_LANES] = {};         // the completion signal of the group the lane's slots hold
+            if (sdma.ok) ctl = nullptr;                             // the engine takes the copies in order: no turns
             // how long a group may wait for its turn: the transfers of every other lane in front of it (a poll is ~1 us; the
             // link moves ~50 bytes per ns), three times over -- a fixed 4 ms was no margin for 16 frames of 2048^2 (3.8 ms each)
             const double group_us = (double) G * (double) fb / 50.0e3;
@@ -1412,6 +1531,11 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 const double t_g = trace_now();
 #endif
                 uint8_t* base = finished + (size_t) l * fin * fb;
+                // (SDMA: the lane's slots hold the group it sent last -- until that has left.  Two sets of slots per lane, so that a
+                // lane renders its next group while its last one leaves, measured SLOWER: 14.2 k instead of 14.6 k frames/s for 20
+                // frames, 15.9 k instead of 16.6 k for 75 -- a lane then renders the group after next while the other lane still
+                // renders the group the engine waits for)
+                if (lane_fin[l]) { hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_POLLS); lane_fin[l] = nullptr; }
                 if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
                     int idx[KBE_FRAME_JOBS], count = 0;
                     uint8_t* outs[KBE_FRAME_JOBS];
@@ -1433,7 +1557,17 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #if defined(KBE_VIDEO_TRACE)
                 const double t_t = trace_now();
 #endif
-                const hipError_t e = hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
+                bool sent = false;
+                if (sdma.ok) {
+                    SdmaPair p;
+                    if (sdma_pair(sdma, p) && hsa_amd_memory_async_copy_on_engine(host_out + (size_t) i0 * fb, sdma.cpu, base, sdma.gpu, (size_t) nb * fb, 1, &p.dep, p.fin,
+                                                                                  sdma.engine, true) == HSA_STATUS_SUCCESS) {
+                        hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], signal_value(p.dep));
+                        lane_fin[l] = signal_value(p.fin);
+                        sent = true;
+                    } else sdma.ok = false;                         // this group and the rest: the runtime's transfers
+                }
+                const hipError_t e = sent ? hipSuccess : hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
 #if defined(KBE_VIDEO_GPU_TRACE)
                 (void) hipEventRecord(ev_copied[g], ls[l]);
@@ -1448,6 +1582,9 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                         (t_g - t_call) * 1e6, (t_r - t_g) * 1e6, (t_t - t_r) * 1e6, (t_c - t_t) * 1e6, (trace_now() - t_c) * 1e6);
 #endif
             }
+            // (SDMA) a lane is done when its last group has left: whoever waits for the lanes (join) waits for the frames
+            for (int l = 0; l < lanes; l++)
+                if (lane_fin[l]) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_POLLS);
 #if defined(KBE_VIDEO_GPU_TRACE)
             for (int l = 0; l < lanes; l++) (void) hipStreamSynchronize(ls[l]);
             for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
@@ -1487,6 +1624,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         }
     }
     join();
+    sdma_close(sdma, cs);
     destroy();
     if (rc == KBE_OK && !ok) rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate");
     return rc;

@@ -86,9 +86,19 @@ struct PlaceArgs {          // the placement of one frame: its camera, and where
 
 // what a tile launch takes: the cloud, up to J frames to render, and up to J frames whose placements it makes AHEAD -- the
 // work of k_place for the frames the NEXT tile launch on this stream renders (they use the other bank of their scratch sets)
+// (KBE_SHARED_LISTS) consecutive frames of a launch share candidate lists in SUB-GROUPS: frame k reads the lists of its sub-group's
+// lead (itself: lists of its own), and a sub-group's tiles zero the shared counter when the last of its frames has
+// read it; of the frames placed ahead, frame k that leads a sub-group k .. last > k makes the lists for those frames
+// (the box of a sub-block's corners under cameras k and nx_last[k], widened by `dev`: how far the cameras in between stray from
+// the straight line between those two -- a Ken Burns path is a parabola in shift space, common.py:88-100), the others of its
+// sub-group store their placements and list nothing.
 template <int J> struct FrameJobsT {
     PackedCloud pc;
     int n_next, pad_;
+    float dev[3];           // the largest distance, per axis, of a placed camera's shift from the chord of its sub-group
+    uint32_t a_share[J];    // lead | size << 8 of the frame's sub-group among the frames this launch renders (dwords: a byte of the kernel
+    uint32_t nx_share[J];   // lead | last << 8 among the frames it places     arguments is fetched by a VECTOR load, and the wait for it is a wait
+                            //                                                 for every load the prologue has in flight: 15.0 -> 16.5 us per frame)
     FrameArgs a[J];
     PlaceArgs nx[J];
 };
@@ -212,6 +222,9 @@ struct ListSlot { int t, pos; };
 #ifndef KBE_SHARED_LISTS
 #define KBE_SHARED_LISTS 1
 #endif
+#ifndef KBE_SHARE_MAX_PX
+#define KBE_SHARE_MAX_PX 16.0       // (launch_frames_fused: share_plan)
+#endif
 // 32-bit byte offsets on the launch's uniform bases (placements, points, colours): with a signed index every such address was a
 // sign extension, a 64-bit multiply-add and a 64-bit add.  The route takes at most 2^28 points (KBE_FUSED_MAX_POINTS): x 16 fits.
 #ifndef KBE_OFFSETS_32
@@ -225,7 +238,7 @@ template <class T> __device__ __forceinline__ const T* at_offset32(const T* base
 {
     return KBE_OFFSETS_32 ? (const T*) ((const char*) base + index * (uint32_t) sizeof(T)) : base + (int) index;
 }
-struct ShareMode { int mode; float dsx, dsy, dsz; };         // dsx, dsy, dsz: the last camera's shift minus this (the first) one's
+struct ShareMode { int mode; float dsx, dsy, dsz, dev_x, dev_y, dev_z; };      // ds: the sub-group's last camera's shift minus this (its first) one's; dev: FrameJobsT::dev
 constexpr float SHARE_MARGIN = 0.25f;
 __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i, int lane, const Camera& cam, int tiles_x, int tiles_y, Placement* place,
                                                       int* tile_count, int* cand_lists, unsigned* bin_flag, const ShareMode& share)
@@ -253,10 +266,16 @@ __device__ __forceinline__ ListSlot place_point_begin(const CloudPoint& p, int i
         // no bound where the point passes the near plane inside the group, comes closer to it than a thousandth of the focal
         // length (a shift's last bit then moves it by more than the margin), or lands nowhere finite: the whole image
         const float z_safe = 1.0e-3f * cam.focal_f;
-        const bool loose = (seen != seen_b) | (seen & !(z >= z_safe)) | (seen_b & !(zb >= z_safe)) | (seen_b & !((fabsf(oxb) < 1.0e9f) & (fabsf(oyb) < 1.0e9f)));
+        // a camera between the two sits within `dev` of a point of the chord, and a shift that is off by (ex, ey, ez) moves the
+        // image position by (F ex - (ox - cx) ez) / (z + ez) exactly: the box grows by that much at the nearest depth it holds
+        const float z_near = fminf(z, zb) - share.dev_z;
+        const bool loose = (seen != seen_b) | (seen & !(z_near >= z_safe)) | (seen_b & !(z_near >= z_safe)) | (seen_b & !((fabsf(oxb) < 1.0e9f) & (fabsf(oyb) < 1.0e9f)));
         const float fw = (float) (cam.W - 1), fh = (float) (cam.H - 1);
-        float lox = fminf(ox, oxb) - SHARE_MARGIN, hix = fmaxf(ox, oxb) + SHARE_MARGIN;
-        float loy = fminf(oy, oyb) - SHARE_MARGIN, hiy = fmaxf(oy, oyb) + SHARE_MARGIN;
+        const float r_near = 1.001f * __builtin_amdgcn_rcpf(z_near);
+        const float mx = __builtin_fmaf(__builtin_fmaf(fmaxf(fabsf(ox - cam.cx_f), fabsf(oxb - cam.cx_f)), share.dev_z, cam.focal_f * share.dev_x), r_near, SHARE_MARGIN);
+        const float my = __builtin_fmaf(__builtin_fmaf(fmaxf(fabsf(oy - cam.cy_f), fabsf(oyb - cam.cy_f)), share.dev_z, cam.focal_f * share.dev_y), r_near, SHARE_MARGIN);
+        float lox = fminf(ox, oxb) - mx, hix = fmaxf(ox, oxb) + mx;
+        float loy = fminf(oy, oyb) - my, hiy = fmaxf(oy, oyb) + my;
         ok = seen & seen_b & (hix >= -1.0f) & (lox < fw + 1.0f) & (hiy >= -1.0f) & (loy < fh + 1.0f);
         lox = fmaxf(lox, -1.0f); hix = fminf(hix, fw); loy = fmaxf(loy, -1.0f); hiy = fminf(hiy, fh);
         if (loose) { ok = seen | seen_b; lox = -1.0f; hix = fw; loy = -1.0f; hiy = fh; }
@@ -323,7 +342,7 @@ __global__ void __launch_bounds__(256) k_place(PlaceJobs jobs)
     const PlaceArgs& a = jobs.a[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;        // Np is a multiple of 64: whole waves only
     if (i >= jobs.pc.Np) return;
-    place_point(jobs.pc.pd[i], i, threadIdx.x & 63, a.cam, jobs.tiles_x, jobs.tiles_y, a.place, a.tile_count, a.cand, a.bin_flag, ShareMode{ 0, 0.0f, 0.0f, 0.0f });
+    place_point(jobs.pc.pd[i], i, threadIdx.x & 63, a.cam, jobs.tiles_x, jobs.tiles_y, a.place, a.tile_count, a.cand, a.bin_flag, ShareMode{ 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f });
 }
 
 // what a pass over candidate blocks does with each point
@@ -390,18 +409,28 @@ __device__ __forceinline__ Camera load_camera(const __attribute__((address_space
 // k_place alone is a streaming launch that waits for memory 70 % of its life (the point, then its list slots); k_frame is bound
 // by instruction issue: one launch lets the one's waits hide under the other's arithmetic whatever else the chip is doing.
 // the mode of frame j of the `n_next` a launch places (shared: the launch's flag)
-__device__ __forceinline__ ShareMode share_mode(PlaceArgsPtr nx, int n_next, int j, bool shared)
+template <class Jobs> __device__ __forceinline__ ShareMode share_mode(const __attribute__((address_space(4))) Jobs* jp, int j, bool shared)
 {
-    ShareMode m = { 0, 0.0f, 0.0f, 0.0f };
+    ShareMode m = { 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     if (KBE_SHARED_LISTS && shared) {
-        m.mode = j == 0 ? 2 : 1;
-        if (j == 0) { m.dsx = nx[n_next - 1].cam.sx - nx[0].cam.sx; m.dsy = nx[n_next - 1].cam.sy - nx[0].cam.sy; m.dsz = nx[n_next - 1].cam.sz - nx[0].cam.sz; }
+        const uint32_t sh = jp->nx_share[j];                            // uniform (a scalar load)
+        const int lead = (int) (sh & 255u), last = (int) (sh >> 8);
+        if (last > lead) {
+            m.mode = j == lead ? 2 : 1;
+            if (j == lead) {
+                PlaceArgsPtr nx = (PlaceArgsPtr) jp->nx;
+                m.dsx = nx[last].cam.sx - nx[lead].cam.sx; m.dsy = nx[last].cam.sy - nx[lead].cam.sy; m.dsz = nx[last].cam.sz - nx[lead].cam.sz;
+                m.dev_x = jp->dev[0]; m.dev_y = jp->dev[1]; m.dev_z = jp->dev[2];
+            }
+        }
     }
     return m;
 }
 
-__device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx, int n_next, int tiles_x, int tiles_y, int wave, int lane, int units_up_front, bool shared)
+template <class Jobs> __device__ __forceinline__ void place_ahead(const __attribute__((address_space(4))) Jobs* jp, int n_next, int tiles_x, int tiles_y, int wave, int lane, int units_up_front, bool shared)
 {
+    PackedCloudPtr pcp = &jp->pc;
+    PlaceArgsPtr nx = (PlaceArgsPtr) jp->nx;
     const CloudPoint* const pd = pcp->pd;
     const int n_units = pcp->Np / kCloudBlock;
     const int first = blockIdx.x * (TILE_THREADS / 64) + wave, step = gridDim.x * (TILE_THREADS / 64);
@@ -412,7 +441,7 @@ __device__ __forceinline__ void place_ahead(PackedCloudPtr pcp, PlaceArgsPtr nx,
         int* const tile_count = a->tile_count;
         int* const cand = a->cand;
         unsigned* const bin_flag = a->bin_flag;
-        const ShareMode share = share_mode(nx, n_next, j, shared);
+        const ShareMode share = share_mode(jp, j, shared);
         const int u0 = first + (j == (int) blockIdx.y ? units_up_front * step : 0);      // (the row's first frame: its first units were placed up front)
         if (u0 >= n_units) continue;
         CloudPoint p = *at_offset32(pd, (uint32_t) (u0 * kCloudBlock + lane));
@@ -553,7 +582,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     if (ahead) {
         PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
         const Camera ncam = load_camera(&na->cam);
-        const ShareMode nshare = share_mode((PlaceArgsPtr) jp->nx, n_next, blockIdx.y, (share_flags & 2) != 0);
+        const ShareMode nshare = share_mode(jp, blockIdx.y, (share_flags & 2) != 0);
         KBE_PROBE(12);
 #pragma unroll
         for (int d = 0; d < NU; d++)
@@ -567,10 +596,11 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     if (KBE_AHEAD_AT == 2) ahead_finish();
     // (only now: every wave of the workgroup has its copy of the count)
     if (tid == 0) {                                     // ready for the next frame's k_place
-        if (KBE_SHARED_LISTS && (share_flags & 1)) {
-            // the list is the group's: the last of its frames' workgroups to get here (each has read the count) zeroes it, and
+        const int sharers = (KBE_SHARED_LISTS && (share_flags & 1)) ? (int) (jp->a_share[job] >> 8) : 1;
+        if (sharers > 1) {
+            // the list is the sub-group's: the last of its frames' workgroups to get here (each has read the count) zeroes it, and
             // the arrivals' own counter next to it
-            if (atomicAdd(&tile_count[tile * CNT_STRIDE + 1], 1) == (int) gridDim.y - 1) { tile_count[tile * CNT_STRIDE + 1] = 0; tile_count[tile * CNT_STRIDE] = 0; }
+            if (atomicAdd(&tile_count[tile * CNT_STRIDE + 1], 1) == sharers - 1) { tile_count[tile * CNT_STRIDE + 1] = 0; tile_count[tile * CNT_STRIDE] = 0; }
         }
         else tile_count[tile * CNT_STRIDE] = 0;
     }
@@ -664,7 +694,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
             if (more) fetch_points();
         }
     }
-    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(pcp, (PlaceArgsPtr) jp->nx, n_next, tiles_x, tiles_y, wave, lane, NU, (share_flags & 2) != 0);
+    if (AHEAD && KBE_AHEAD_AT == 1 && n_next > 0) place_ahead(jp, n_next, tiles_x, tiles_y, wave, lane, NU, (share_flags & 2) != 0);
     KBE_PROBE(3);
     if (KBE_AHEAD_AT == 3) ahead_finish();
     __syncthreads();
@@ -917,7 +947,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
         asm volatile("" : "+s"(jp) :: "memory");
         const int n_left = jp->n_next;
-        if (n_left > 0) place_ahead(&jp->pc, (PlaceArgsPtr) jp->nx, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU, KBE_SHARED_LISTS && (jp->pad_ & 2) != 0);
+        if (n_left > 0) place_ahead(jp, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU, KBE_SHARED_LISTS && (jp->pad_ & 2) != 0);
     }
     KBE_PROBE(9);
 #if defined(KBE_FRAME_PROBE)
@@ -1008,7 +1038,8 @@ bool fused_can_place_ahead(int N, int W, int H, int n, int n_next)
 // `placed`: the previous tile launch made their placements ahead) and one tile launch, each taking all n frames (frame k: its
 // camera, scratch set, and by `parity` / `turn` the set's bank of placements and lists, hole counter and list total); the tile
 // launch also makes the placements of `next` (n_next frames: the ones the next tile launch on this stream renders)
-void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t, bool placed, int n_next, const FusedTarget* next, int build)
+void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* t, bool placed, int n_next, const FusedTarget* next, int build,
+                         double near_depth)
 {
     PlaceJobs pj;
     FrameJobs fj;
@@ -1026,40 +1057,84 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         b.bin_flag = (unsigned*) f.sc.hole_count + flag_of(f);
         return b;
     };
-    // (KBE_SHARED_LISTS) one set of candidate lists for a group of frames placed ahead (ShareMode, above): the group's cameras must
-    // differ in their shifts only, the shifts lying on one line in the order of the frames -- what consecutive steps of a camera
-    // path are.  Decided from the group's cameras alone, so that the launch that places a group and the launch that renders it
-    // agree without being told.
-    auto shareable = [&](const FusedTarget* g, int m) {
-        if (!KBE_SHARED_LISTS || m < 2) return false;
-        // a group's list is a tenth or two longer than a frame's own, and a list beyond LIST_CAP sends its tile down the slow
-        // path: only clouds whose AVERAGE list (1.55 candidates per point of the tile's share, in sub-blocks) leaves a factor of
-        // four to the capacity share (the bench cloud: 54 of 512; 16.8 M points on 2048^2: 198, its densest tiles 480-500 --
-        // shared they reached 515-555 and eighteen tiles of a video scanned the whole cloud)
+    // (KBE_SHARED_LISTS) which consecutive frames of a group placed ahead share ONE set of candidate lists (FrameJobsT, ShareMode).
+    // The group's cameras must differ in their shifts only.  The frames are cut into sub-groups of s consecutive ones -- the
+    // largest s of 12, 8, 6, 4, 3, 2 for which the nearest point the caller knows of (`near_depth`: objectDepthrange's closest
+    // depth, common.py:88) moves by at most KBE_SHARE_MAX_PX pixels between a sub-group's first and last camera: a sub-block is
+    // listed for the box of its corners under those two cameras, and what the box gains in tiles must stay below what ONE list
+    // for s frames saves (measured).  A camera between the two need not lie on the straight line between
+    // them (a Ken Burns path is a parabola in shift space: shiftX = dU closestDepth(step) / F, common.py:88-100): how far the
+    // sub-groups' cameras stray from their chords goes to the kernel as `dev` and widens the boxes.  Decided from the group's
+    // cameras, the cloud and near_depth alone, so that the launch that places a group and the launch that renders it agree
+    // without being told.
+    struct SharePlan { bool any; float dev[3]; uint8_t lead[KBE_FRAME_JOBS], last[KBE_FRAME_JOBS], size[KBE_FRAME_JOBS]; };
+    auto share_plan = [&](const FusedTarget* g, int m) {
+        SharePlan P = {};
+        for (int k = 0; k < KBE_FRAME_JOBS; k++) { P.lead[k] = P.last[k] = (uint8_t) k; P.size[k] = 1; }
+        if (!KBE_SHARED_LISTS || m < 2 || !(near_depth > 0.0)) return P;
+        // a sub-group's list is longer than a frame's own, and a list beyond LIST_CAP sends its tile down the slow path: only
+        // clouds whose AVERAGE list (1.55 candidates per point of the tile's share, in sub-blocks) leaves a factor of four to
+        // the capacity share (the bench cloud: 54 of 512; 16.8 M points on 2048^2: 198, its densest tiles 480-500 -- shared
+        // they reached 515-555 and eighteen tiles of a video scanned the whole cloud)
         const Scratch& sc = g[0].sc;
-        if (1.55 * (double) pc.Np / kCloudSub / ((double) sc.tiles_x * sc.tiles_y) > LIST_CAP / 4.0) return false;
+        if (1.55 * (double) pc.Np / kCloudSub / ((double) sc.tiles_x * sc.tiles_y) > LIST_CAP / 4.0) return P;
         const Camera& c0 = g[0].cam;
-        const Camera& c1 = g[m - 1].cam;
-        const double d[3] = { (double) c1.sx - c0.sx, (double) c1.sy - c0.sy, (double) c1.sz - c0.sz };
-        const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
         double big = 1.0;
-        for (int k = 0; k < m; k++) big = fmax(big, fmax(fabs((double) g[k].cam.sx), fmax(fabs((double) g[k].cam.sy), fabs((double) g[k].cam.sz))));
-        if (big > 100.0) return false;
-        double last = 0.0;
         for (int k = 0; k < m; k++) {
             const Camera& c = g[k].cam;
             if (c.focal_f != c0.focal_f || c.fb != c0.fb || c.half_w != c0.half_w || c.half_h != c0.half_h || c.W != c0.W || c.H != c0.H ||
-                c.fp32_centre != c0.fp32_centre || !c.has_shift || !c0.has_shift || !c0.fp32_centre) return false;
-            const double e[3] = { (double) c.sx - c0.sx, (double) c.sy - c0.sy, (double) c.sz - c0.sz };
-            const double lam = dd > 0.0 ? (e[0] * d[0] + e[1] * d[1] + e[2] * d[2]) / dd : 0.0;
-            if (lam < last - 1.0e-9 || lam > 1.0 + 1.0e-9) return false;                     // in the order of the frames, between the two ends
-            for (int q = 0; q < 3; q++) if (fabs(e[q] - lam * d[q]) > 1.0e-6 * big) return false;  // on the line, to the shifts' own rounding
-            last = lam;
+                c.fp32_centre != c0.fp32_centre || !c.has_shift || !c0.fp32_centre) return P;
+            big = fmax(big, fmax(fabs((double) c.sx), fmax(fabs((double) c.sy), fabs((double) c.sz))));
         }
-        return true;
+        if (big > 100.0) return P;
+        const double F = (double) c0.focal_f, half = 0.5 * (double) (c0.W > c0.H ? c0.W : c0.H);
+        auto spread_px = [&](int a, int b) {            // how far the nearest point moves between cameras a and b, in pixels
+            const Camera& ca = g[a].cam; const Camera& cb = g[b].cam;
+            const double zn = near_depth + fmin((double) ca.sz, (double) cb.sz);
+            if (!(zn > 0.01 * F)) return 1.0e30;
+            return (hypot((double) cb.sx - ca.sx, (double) cb.sy - ca.sy) * F + half * fabs((double) cb.sz - ca.sz)) / zn;
+        };
+        static const int sizes[] = { 12, 8, 6, 4, 3, 2 };
+        int s_sub = 0;
+        for (int q = 0; q < 6 && !s_sub; q++) {
+            const int sz = sizes[q] < m ? sizes[q] : m;
+            bool fits = true;
+            for (int a0 = 0; a0 < m && fits; a0 += sz) { const int b0 = (a0 + sz < m ? a0 + sz : m) - 1; fits = b0 == a0 || spread_px(a0, b0) <= (double) KBE_SHARE_MAX_PX; }
+            if (fits) s_sub = sz;
+        }
+        if (!s_sub) return P;
+        // how far the cameras of a sub-group stray from its chord, per axis (+ the shifts' own fp32 rounding)
+        double dev[3] = { 0.0, 0.0, 0.0 };
+        for (int a0 = 0; a0 < m; a0 += s_sub) {
+            const int b0 = (a0 + s_sub < m ? a0 + s_sub : m) - 1;
+            const Camera& ca = g[a0].cam; const Camera& cb = g[b0].cam;
+            const double d[3] = { (double) cb.sx - ca.sx, (double) cb.sy - ca.sy, (double) cb.sz - ca.sz };
+            const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            for (int k = a0 + 1; k < b0; k++) {
+                const Camera& c = g[k].cam;
+                const double e[3] = { (double) c.sx - ca.sx, (double) c.sy - ca.sy, (double) c.sz - ca.sz };
+                double lam = dd > 0.0 ? (e[0] * d[0] + e[1] * d[1] + e[2] * d[2]) / dd : 0.0;
+                lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
+                for (int q = 0; q < 3; q++) dev[q] = fmax(dev[q], fabs(e[q] - lam * d[q]));
+            }
+        }
+        for (int q = 0; q < 3; q++) dev[q] += 2.0e-6 * big;
+        // (a path that strays from its chords by more than a pixel's worth at the nearest depth is no path to share lists on)
+        const double zn0 = near_depth + fmin((double) c0.sz, (double) g[m - 1].cam.sz);
+        if (!(zn0 > 0.01 * F) || (hypot(dev[0], dev[1]) * F + half * dev[2]) / zn0 > 2.0) return P;
+        for (int a0 = 0; a0 < m; a0 += s_sub) {
+            const int b0 = (a0 + s_sub < m ? a0 + s_sub : m) - 1;
+            for (int k = a0; k <= b0; k++) { P.lead[k] = (uint8_t) a0; P.last[k] = (uint8_t) b0; P.size[k] = (uint8_t) (b0 - a0 + 1); }
+            P.any = P.any || b0 > a0;
+        }
+        for (int q = 0; q < 3; q++) P.dev[q] = (float) (dev[q] * 1.0001);
+        return P;
     };
-    const bool shared_now = placed && shareable(t, n), shared_next = n_next > 0 && shareable(next, n_next);
+    const SharePlan plan_now = placed ? share_plan(t, n) : share_plan(t, 0), plan_next = share_plan(next, n_next > 0 ? n_next : 0);
+    const bool shared_now = plan_now.any, shared_next = plan_next.any;
     pj.pc = pc; fj.pc = pc; fj.n_next = n_next; fj.pad_ = (shared_now ? 1 : 0) | (shared_next ? 2 : 0);
+    for (int q = 0; q < 3; q++) fj.dev[q] = plan_next.dev[q];
+    for (int k = 0; k < KBE_FRAME_JOBS; k++) { fj.a_share[k] = plan_now.lead[k] | ((uint32_t) plan_now.size[k] << 8); fj.nx_share[k] = plan_next.lead[k] | ((uint32_t) plan_next.last[k] << 8); }
     for (int k = 0; k < KBE_FRAME_JOBS; k++) {
         const FusedTarget& f = t[k < n ? k : 0];
         const Scratch& sc = f.sc;
@@ -1074,11 +1149,14 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         a.render = f.render_f32; a.existing = f.existing_f32; a.zee = f.zee_f32; a.zee_pre = f.zee_pre_f32; a.spill = sc.buckets;
         fj.nx[k] = place_args(n_next > 0 ? next[k < n_next ? k : 0] : f);
     }
-    if (shared_now)         // every frame reads the lists the group's first frame's set holds
+    if (shared_now)         // every frame reads the lists its sub-group's first frame's set holds
         // (... and still zeroes the list total its OWN set counts in two turns on: a set that joins an unshared or group-first turn
         // later must not count on top of what an earlier such turn left -- totals only grow, and past the budget every tile of the
         // frame scans the whole cloud: ADVICE r4)
-        for (int k = 1; k < KBE_FRAME_JOBS; k++) { fj.a[k].tile_count = fj.a[0].tile_count; fj.a[k].cand = fj.a[0].cand; fj.a[k].bin_flag = fj.a[0].bin_flag; }
+        for (int k = 1; k < n; k++) {
+            const int l = plan_now.lead[k];
+            if (l != k) { fj.a[k].tile_count = fj.a[l].tile_count; fj.a[k].cand = fj.a[l].cand; fj.a[k].bin_flag = fj.a[l].bin_flag; }
+        }
     if (!placed) hipLaunchKernelGGL(k_place, dim3(blocks_for((size_t) pc.Np), n), dim3(256), 0, s, pj);
     // the lean build (608 records per tile, six workgroups per CU) for clouds of about a point per pixel, the roomy one beyond
     // (`build`: KBE_STAGE_FUSED_LEAN / _ROOMY force one -- a switch for tests and measurements)
@@ -1088,6 +1166,7 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
     if (n == 1 && n_next <= 1) {
         FrameJob1 f1;
         f1.pc = pc; f1.n_next = n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
+        f1.dev[0] = f1.dev[1] = f1.dev[2] = 0.0f; f1.a_share[0] = 1u << 8; f1.nx_share[0] = 0;
         if (n_next) hipLaunchKernelGGL(lean ? k_frame_ahead : k_frame_ahead_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
         else hipLaunchKernelGGL(lean ? k_frame : k_frame_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
     } else if (n_next) {                                                        // (also: one frame that places several)

@@ -52,13 +52,40 @@ def world():
     return 0, 1
 
 
-def shard_steps(steps, rank=None, world_size=None):
-    """Round-robin assignment of frame indices (balances hole-count variation along the
-    trajectory; contiguous blocks would put all the wide-baseline frames on one rank).
-    Returns (indices, steps) for this rank."""
+SHARD_SHAPE = 'round-robin'     # decided by measurement on one GPU, round 5 (profiles/r05_shard_shapes.txt): see shard_indices
+
+
+def shard_indices(n, rank, world_size, shape=None):
+    """Which of a video's n frames rank `rank` renders.
+    'round-robin' (the default): frames rank, rank + world_size, ... -- every rank samples the whole path.  A frame at the ends
+    of a Ken Burns path costs ~7-14 % more than one in its middle, and the video ends with its slowest rank.
+    'block': a contiguous run of n / world_size frames (the first n % world_size ranks one more) -- consecutive cameras, which
+    the renderer's launch groups like (the frames of a launch share candidate lists built for the box between a sub-group's
+    first and last camera: kbe_fused.hip share_plan) -- but the ranks holding the path's ends set the pace.
+    'dealt<k>' (e.g. 'dealt2'): runs of k consecutive frames dealt to the ranks in turn.
+    Measured as an 8-way share of a 128- and a 75-frame 1024^2 video on one GPU (tools/shard_shapes.py; every rank of a node
+    has its own GPU and link, so a share rendered alone is what that rank would do), the video at its slowest rank's pace,
+    delivered / left in HBM, k frames/s over 8 GPUs: 128 frames: round-robin 108 / 267, block 106 / 249, dealt4 110 / 272,
+    dealt2 111 / 275; 75 frames: round-robin 93 / 229, block 92 / 213, dealt4 84 / 197 (12 : 8 frames), dealt2 92 / 220.
+    Round-robin is within 2 % of the best everywhere and never the worst.  KBE_SHARD_SHAPE overrides."""
+    shape = shape or os.environ.get('KBE_SHARD_SHAPE', SHARD_SHAPE)
+    if shape == 'round-robin':
+        return list(range(rank, n, world_size))
+    if shape.startswith('dealt'):           # 'dealt4': runs of 4 consecutive frames dealt to the ranks in turn
+        b = int(shape[5:] or 4)
+        return [i for i in range(n) if (i // b) % world_size == rank]
+    if shape != 'block':
+        raise ValueError('shard shape %r: block, round-robin or dealt<run length>' % (shape,))
+    q, r = divmod(n, world_size)            # as even as blocks get: the first n % world_size ranks take one frame more
+    start = rank * q + min(rank, r)
+    return list(range(start, start + q + (1 if rank < r else 0)))
+
+
+def shard_steps(steps, rank=None, world_size=None, shape=None):
+    """(indices, steps) of this rank's share of a video's steps (shard_indices)."""
     if rank is None:
         rank, world_size = world()
-    idx = list(range(rank, len(steps), world_size))
+    idx = shard_indices(len(steps), rank, world_size, shape)
     return idx, [steps[i] for i in idx]
 
 
@@ -137,9 +164,9 @@ def measure_delivery_lanes(objectSettings, objectCommon):
     return lanes
 
 
-def gather_frames(local_frames, indices, total, device, dst=0):
-    """Collects per-rank uint8 frames [n_local,H,W,3] on rank `dst` in original step order.
-    Returns the full [total,H,W,3] tensor on `dst`, None elsewhere."""
+def gather_frames(local_frames, indices, total, device, dst=0, shape=None):
+    """Collects per-rank uint8 frames [n_local,H,W,3] on rank `dst` in original step order (`shape`: the one the frames were
+    sharded by).  Returns the full [total,H,W,3] tensor on `dst`, None elsewhere."""
     rank, world_size = world()
     if world_size == 1 and not (dist.is_initialized() and single_rank_collectives()):
         return local_frames
@@ -153,14 +180,15 @@ def gather_frames(local_frames, indices, total, device, dst=0):
         return None
     out = torch.empty(total, H, W, 3, dtype=torch.uint8, device=device)
     for r in range(world_size):
-        idx = list(range(r, total, world_size))
-        out[idx] = bucket[r][:len(idx)]
+        idx = shard_indices(total, r, world_size, shape)
+        if idx:
+            out[idx] = bucket[r][:len(idx)]
     return out
 
 
 def process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, device, gather=False):
-    """process_kenburns over all ranks: rank 0 builds the cloud, one broadcast, each rank renders its round-robin share
-    of ``dblSteps``.
+    """process_kenburns over all ranks: rank 0 builds the cloud, one broadcast, each rank renders its share of ``dblSteps``
+    (round-robin: shard_indices).
 
     ``gather=False`` (default): every rank delivers ITS frames to its own pinned host memory over its own PCIe link (what
     a node with one encoder / writer process per GPU wants; nothing funnels through one GPU) and gets

@@ -763,6 +763,42 @@ def test_every_instantiation_of_the_tile_launch_against_the_oracle(K, oracle, mo
             '%s, frame %d: max %d, %.2e of the values differ' % (build, i, d.max(), (d > 0).mean())
 
 
+def test_cloud_of_nine_points_per_pixel_takes_the_atomic_kernels_and_matches_the_oracle(K, oracle, monkeypatch):
+    """Beyond ~8 points per pixel the tile routes' per-tile capacities overflow (a bucket holds 12 records per pixel of its tile)
+    and both fall off a cliff; such clouds take the stage-by-stage kernels with global atomics, which scale linearly
+    (_native.GENERIC_MIN_DENSITY, HipKernels._render_video_generic: VERDICT r4 item 5).  A 3 x 3-upsampled cloud on a 96 x 128
+    raster: the route is chosen by the density alone, the frames -- left in HBM and delivered through the crop -- equal the
+    oracle's within the order of the fp32 sums, and the bucket route forced on the same cloud renders the same frames."""
+    from ken_burns_effect_amd import _native, common, synthetic
+    H, W, up = 96, 128, 3
+    settings, oc = _scene((H, W), 6)
+    image_u, disp_u = synthetic.make_rgbd(H * up, W * up, 6)
+    depth_u = ((512.0 * 120) / (disp_u + 1e-7)).cuda()
+    oc['tensorInpaPoints'] = K.depth_to_points(depth_u, 512.0 * up).view(1, 3, -1)
+    oc['tensorInpaImage'] = image_u.cuda().reshape(1, 3, -1)
+    oc['tensorInpaDepth'] = depth_u.reshape(1, 1, -1)
+    assert oc['tensorInpaPoints'].shape[2] == 9 * H * W > _native.GENERIC_MIN_DENSITY * H * W
+    cams = common.frame_cameras(dict(settings, dblSteps=[0.0, 0.3, 0.7, 1.0]), oc)
+    state = common._prepared_cloud(K, oc)
+    assert state['generic'] and not state['fused']
+    crop = common.crop_size(settings)
+    in_hbm = c(common.render_frames(cams, oc, None, keep_on_device=True))
+    delivered = common.render_frames(cams, oc, crop)
+    ok = oracle.OracleKernels('jacobi')
+    ostate = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), W, H)
+    for i, (focal, shift3) in enumerate(cams):
+        ref = ok.render_frame(ostate, shift3, focal, oc['dblBaseline']).numpy()
+        frames_close(in_hbm[i], ref, 'atomic route, frame %d' % i)
+        frames_close(delivered[i], oracle.crop_resize_u8(ref, crop[0], crop[1]), 'atomic route, delivered frame %d' % i, cropped=True)
+    assert in_hbm.any()
+    monkeypatch.setenv('KBE_FUSED', '0')                # the bucket route on the same cloud (slow at this density, not wrong)
+    oc.pop('_kbePreparedCloud')
+    bucket = c(common.render_frames(cams, oc, None, keep_on_device=True))
+    assert not common._prepared_cloud(K, oc)['generic']
+    for i in range(len(cams)):
+        frames_close(bucket[i], in_hbm[i], 'bucket route against the atomic route, frame %d' % i)
+
+
 @pytest.mark.parametrize('kind', ['rough', 'near_plane'])
 def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, kind):
     """The frames a tile launch places ahead share ONE set of candidate lists when they are consecutive cameras of a straight

@@ -106,7 +106,12 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
     from ken_burns_effect_amd import pipeline as P
     monkeypatch.setenv('KBE_CACHE_DIR', str(tmp_path))
     monkeypatch.delenv('KBE_MIOPEN_FIND', raising=False)
+    monkeypatch.delenv('MIOPEN_DISABLE_CACHE', raising=False)
+    db = tmp_path / 'userdb'
+    db.mkdir()
+    monkeypatch.setenv('MIOPEN_USER_DB_PATH', str(db))
     seen = []
+    keeps = [True]          # does "MIOpen" keep what its find step measured?  (a read-only / disabled find-db keeps nothing)
 
     class Stub(P.Pipeline):
         def __init__(self):
@@ -119,6 +124,9 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
 
         def estimate(self, tensorImage):
             seen.append(torch.backends.cudnn.benchmark)
+            if torch.backends.cudnn.benchmark and keeps[0]:
+                with open(db / 'gfx950.ufdb.txt', 'a') as f:
+                    f.write('a solver measured\n')
             return self.objectCommon
 
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
@@ -135,6 +143,18 @@ def test_miopen_find_runs_once_per_machine_and_image_size(tmp_path, monkeypatch,
     import glob
     assert len(glob.glob(str(tmp_path / 'miopen-tuned' / '96x64-AMD_Instinct_MI355X-*'))) == 1 and len(glob.glob(str(tmp_path / 'miopen-tuned' / '*'))) == 2
     assert 'measures its convolution solvers once' in capsys.readouterr().err
+    # a find-db that keeps nothing (read-only, MIOPEN_DISABLE_CACHE ...): the size is NOT marked tuned -- marking it would leave it
+    # untuned for good -- and the next call measures again
+    keeps[0] = False
+    del seen[:]
+    pipe(torch.zeros(1, 3, 16, 24), zoom)
+    pipe(torch.zeros(1, 3, 16, 24), zoom)
+    assert seen == [True, True] and len(glob.glob(str(tmp_path / 'miopen-tuned' / '*'))) == 2
+    assert 'NOT marked tuned' in capsys.readouterr().err
+    keeps[0] = True
+    pipe(torch.zeros(1, 3, 16, 24), zoom)
+    pipe(torch.zeros(1, 3, 16, 24), zoom)
+    assert seen[2:] == [True, False] and len(glob.glob(str(tmp_path / 'miopen-tuned' / '*'))) == 3
     # explicit settings: never / always
     assert P.Pipeline.__init__.__defaults__ is not None
     monkeypatch.setenv('KBE_MIOPEN_FIND', '0')

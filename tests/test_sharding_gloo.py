@@ -101,7 +101,7 @@ def _worker_many(rank, world_size, port, out_dir, n_frames):
             oc['_kbeDeliveryLanes'] = {False: 3}        # what rank 0 measured travels with the cloud's header
         idx, mine = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'))       # every rank keeps its frames
         assert oc['_kbeDeliveryLanes'] == {False: 3}
-        assert idx == list(range(rank, n_frames, world_size)) and len(mine) == len(idx)
+        assert idx == sharding.shard_indices(n_frames, rank, world_size) == list(range(rank, n_frames, world_size)) and len(mine) == len(idx)
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), idx=np.array(idx), frames=np.stack(mine))
         full = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'), gather=True)
         if rank == 0:
@@ -182,11 +182,18 @@ def test_a_group_of_one_rank_can_be_made_to_run_the_collectives(tmp_path):
 
 def test_shard_steps_partition():
     from ken_burns_effect_amd import sharding
-    steps = list(range(10))
-    seen = []
-    for r in range(4):
-        idx, mine = sharding.shard_steps(steps, r, 4)
-        assert mine == [steps[i] for i in idx]
-        seen += idx
-    assert sorted(seen) == steps
-    assert sharding.shard_steps(steps, 0, 1)[0] == steps
+    for shape in (None, 'block', 'round-robin', 'dealt2'):
+        for n, ws in ((10, 4), (75, 8), (128, 8), (5, 8), (0, 3), (7, 1)):
+            steps = list(range(100, 100 + n))
+            seen, sizes = [], []
+            for r in range(ws):
+                idx, mine = sharding.shard_steps(steps, r, ws, shape)
+                assert mine == [steps[i] for i in idx] and idx == sharding.shard_indices(n, r, ws, shape)
+                seen += idx
+                sizes.append(len(idx))
+                if shape == 'block':
+                    assert idx == list(range(idx[0], idx[0] + len(idx))) if idx else True, 'a block is a contiguous run of frames'
+            assert sorted(seen) == list(range(n)) and (max(sizes) - min(sizes) <= 1 or shape == 'dealt2')
+    assert sharding.shard_steps(list(range(10)), 0, 1)[0] == list(range(10))
+    assert sharding.SHARD_SHAPE == 'round-robin' and sharding.shard_indices(75, 7, 8, 'block') == list(range(66, 75))
+    assert sharding.shard_indices(10, 1, 4) == [1, 5, 9] and sharding.shard_indices(10, 1, 4, 'dealt2') == [2, 3]

@@ -64,7 +64,7 @@ for n in (1, 5, 12):
 torch.cuda.synchronize()
 
 focal, shift3 = cams[len(cams) // 2]
-for n in ((1, 2, 4, 8, 12) if os.environ.get('IDENTICAL', '1') == '1' else ()):
+for n in ((1, 2, 4, 8, 12) if os.environ.get('IDENTICAL', '1') == '1' else ((12,) if os.environ.get('IDENTICAL') == '12' else ())):
     group = [(focal, shift3)] * n
     par = [0]
 
@@ -99,7 +99,7 @@ import ctypes  # noqa: E402
 stats = (ctypes.c_ulonglong * 8)() if hasattr(K.lib, 'kbe_debug_frame_stats') else None
 for steps in [int(v) for v in os.environ.get('PATHS', '1024,75,20').split(',') if v]:
     path = common.frame_cameras(dict(settings, dblSteps=[i / max(steps - 1, 1) for i in range(steps)]), oc)
-    for n in [int(v) for v in os.environ.get('GROUPS', '12,8,4').split(',') if v]:
+    for n in [int(v) for v in os.environ.get('LAUNCH_FRAMES', '12,8,4').split(',') if v]:
         groups = bench.consecutive_groups(path, n)
         launches = [K.prepared_group_ahead(state, g, Bl, out[:n], groups[(k + 1) % len(groups)], stages=2) for k, g in enumerate(groups)]
         turn = [0]

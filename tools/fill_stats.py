@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = '/tmp/libkbe_stats.so'
 src = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
-subprocess.check_call(['make', '-s', '-B', '-C', src, 'EXTRA=-DKBE_FRAME_STATS', 'OUT=' + so])
+subprocess.check_call(['make', '-s', '-B', '-C', src, 'EXTRA=-DKBE_FRAME_STATS ' + os.environ.get('EXTRA', ''), 'OUT=' + so])
 import torch  # noqa: E402
 
 import bench  # noqa: E402

@@ -4,7 +4,7 @@ own PCIe link and the whole cloud, so a rank's share rendered here alone is what
 
 For a 128-frame (BASELINE configs[2]) and a 75-frame (the product's) video of the bench cloud, rank r's share as
   round-robin   cams[r::8]                     (sharding.shard_steps until round 4)
-  block         cams[r * per : (r + 1) * per]  (contiguous; per = ceil(n / 8))
+  block         a contiguous run of n / 8 frames     (sharding.shard_indices, the default since round 5)
 delivered to pinned host memory and left in HBM, against the whole video on one GPU.  A launch group of consecutive cameras shares
 its candidate lists (kbe_fused.hip: ShareMode): cameras 8 steps apart make them as wide as they get.  Prints one line per case:
 frames, us per frame (median of PASSES passes), frames/s."""
@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from ken_burns_effect_amd import common, synthetic  # noqa: E402
+from ken_burns_effect_amd import common, sharding, synthetic  # noqa: E402
 
 size = int(os.environ.get('SIZE', '1024'))
 passes = int(os.environ.get('PASSES', '30'))
@@ -53,12 +53,11 @@ for steps in [int(v) for v in os.environ.get('VIDEOS', '128,75').split(',')]:
     for to_host in (True, False):
         t = rate(path, to_host)
         print('%3d-frame video, whole, %-9s: %3d frames %7.1f us per frame %8.0f frames/s' % (steps, 'delivered' if to_host else 'in HBM', steps, t / steps * 1e6, steps / t), flush=True)
-    per = (steps + world - 1) // world
-    for shape in ('round-robin', 'block'):
+    for shape in os.environ.get('SHAPES', 'round-robin,block,dealt4,dealt2').split(','):
         for to_host in (True, False):
             rs = []
             for r in (0, world // 2, world - 1):
-                cams = path[r::world] if shape == 'round-robin' else path[r * per:(r + 1) * per]
+                cams = [path[i] for i in sharding.shard_indices(steps, r, world, shape)]
                 if not cams:
                     continue
                 t = rate(cams, to_host)

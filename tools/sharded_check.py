@@ -34,7 +34,7 @@ if rank == 0:
     common._reset_inpa(oc)
 frames = sharding.process_kenburns_sharded(settings, oc, None, dev, gather=True)
 idx, mine = sharding.process_kenburns_sharded(settings, oc, None, dev)           # the default: per-rank delivery to host memory
-assert idx == list(range(rank, 11, world)) and len(mine) == len(idx)
+assert idx == sharding.shard_indices(11, rank, world) and len(mine) == len(idx)
 if rank == 0:
     ref = common.process_kenburns(settings, oc, None)
     assert all(np.abs(mine[k].astype(np.int32) - ref[i].astype(np.int32)).max() <= 1 for k, i in enumerate(idx))
