@@ -21,7 +21,8 @@
  *     them back -- host-side objects, no device memory, no blocking wait.
  *   - Return value: KBE_OK, or a negative KBE_E_* for invalid arguments / launch failures
  *     (hipGetLastError after the launch).  Nothing throws across this boundary.
- *   - Re-entrant, no global state: safe with one process per GPU or one stream per thread.
+ *   - Re-entrant: safe with one process per GPU or one stream per thread.  No global state but one item: the pool of HSA
+ *     signals kbe_render_video's KBE_VIDEO_SDMA hand-off draws from (mutex-guarded; see the flag).  No environment variable is read.
  *   - Inputs must be finite.  A point whose projection overflows int range is dropped (the
  *     reference's behaviour there is platform-defined; see DESIGN.md "Deviations").
  *   - Sizes: W*H < 2^31 pixels (2^30 for the frame loop); the frame loop (kbe_render_frame*, kbe_render_video, kbe_render_pointcloud_tiled)
@@ -290,8 +291,8 @@ KBE_API int kbe_render_frame_group_fused(const void* packed, int N, double cloud
  * next turn = turn + 1); only where kbe_render_frame_group_ahead_ok(N, W, H, n_frames, n_next) != 0 (a cloud much denser
  * than the raster keeps its placement launch).  near_depth > 0 (the depth of the nearest point the caller knows of: the
  * reference's objectDepthrange[0], common.py:88; 0 = unknown): consecutive frames of a group placed ahead whose cameras differ
- * in their shifts only share candidate lists in sub-groups of 12, 8, 6, 4, 3 or 2 frames -- as many as keep the nearest point
- * within 16 pixels between a sub-group's first and last camera -- kept in the scratch set of each sub-group's first frame: the
+ * in their shifts only share candidate lists in sub-groups of 12, 8, 6 or 4 frames -- as many as keep the nearest point
+ * within 13 pixels between a sub-group's first and last camera -- kept in the scratch set of each sub-group's first frame: the
  * library decides that from the cameras and near_depth alone in both calls, so the `next` cameras of one call must be the
  * cameras of the next call (they already must) and near_depth the same.  Everything else as kbe_render_frame_group_fused; same
  * results. */

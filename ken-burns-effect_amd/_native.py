@@ -30,9 +30,11 @@ DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over 
 FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
                                  # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
                                  # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
-GENERIC_MIN_DENSITY = 8.0        # clouds denser than this take the stage-by-stage kernels with global atomics (HipKernels._render_video_generic): beyond ~8 points
-                                 # per pixel a tile's bucket (12 records per pixel) and the fused route's lists overflow on the densest tiles and both tile
-                                 # routes fall off a cliff (9 per pixel: 7-8 ms per 1024^2 frame), while the atomic path scales linearly (~0.1 ns per point)
+GENERIC_MIN_DENSITY = 6.5        # clouds denser than this take the stage-by-stage kernels with global atomics (HipKernels._render_video_generic).  Both tile routes
+                                 # fall off a cliff between 5 and 6 points per pixel (tile buckets, candidate lists and spill areas overflow on the densest tiles and
+                                 # those tiles scan the cloud), the atomic path grows linearly -- measured at 1024^2 on a 3 x 3-upsampled cloud thinned at random
+                                 # (profiles/r05_density_sweep.txt), us per frame bucket / fused / atomic: 4 per pixel 158 / 147 / 2276, 5: 195 / 4777 / 2840,
+                                 # 6: 5883 / 3415 / 3975, 7: 8454 / 7476 / 4312, 8: 6237 / 7576 / 5587, 9: 14134 / 14048 / 6611
 FUSED_MAX_POINTS = 1 << 28       # the packed cloud's route addresses points by 32-bit byte offsets (KBE_FUSED_MAX_POINTS, kbe_tiles.h): larger clouds take the bucket route
 FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
@@ -147,7 +149,7 @@ def fused_build_bits(video=False):
     return ((2048 if cap == 'lean' else 4096) if video else (1024 if cap == 'lean' else 2048))
 
 
-HANDOFF_DEFAULT = 'blit'    # until the SDMA hand-off has been measured against it (KBE_HANDOFF=sdma|blit)
+HANDOFF_DEFAULT = 'sdma'    # measured (profiles/r05_handoff_sdma.txt): 20 frames 14.1 k -> 14.5-14.8 k frames/s, 75 frames 16.4-16.5 -> 16.5-16.6 k, long videos equal (KBE_HANDOFF=sdma|blit)
 
 
 def handoff_by_sdma():

@@ -223,7 +223,7 @@ struct ListSlot { int t, pos; };
 #define KBE_SHARED_LISTS 1
 #endif
 #ifndef KBE_SHARE_MAX_PX
-#define KBE_SHARE_MAX_PX 16.0       // (launch_frames_fused: share_plan)
+#define KBE_SHARE_MAX_PX 13.0       // (launch_frames_fused: share_plan)
 #endif
 // 32-bit byte offsets on the launch's uniform bases (placements, points, colours): with a signed index every such address was a
 // sign extension, a 64-bit multiply-add and a 64-bit add.  The route takes at most 2^28 points (KBE_FUSED_MAX_POINTS): x 16 fits.
@@ -1094,10 +1094,11 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
             if (!(zn > 0.01 * F)) return 1.0e30;
             return (hypot((double) cb.sx - ca.sx, (double) cb.sy - ca.sy) * F + half * fabs((double) cb.sz - ca.sz)) / zn;
         };
-        static const int sizes[] = { 12, 8, 6, 4, 3, 2 };
+        static const int sizes[] = { 12, 8, 6, 4 };         // (sub-groups of 2 or 3 measured slower than lists of their own: 17.4-17.7 against 16.8-17.0 us per frame)
         int s_sub = 0;
-        for (int q = 0; q < 6 && !s_sub; q++) {
+        for (int q = 0; q < 4 && !s_sub; q++) {
             const int sz = sizes[q] < m ? sizes[q] : m;
+            if (sz < 4) break;                              // (a group of two or three frames: lists of their own)
             bool fits = true;
             for (int a0 = 0; a0 < m && fits; a0 += sz) { const int b0 = (a0 + sz < m ? a0 + sz : m) - 1; fits = b0 == a0 || spread_px(a0, b0) <= (double) KBE_SHARE_MAX_PX; }
             if (fits) s_sub = sz;

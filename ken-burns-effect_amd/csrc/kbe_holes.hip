@@ -493,9 +493,6 @@ __device__ __forceinline__ void axis_catch_up(Axis& ax, int& r, float u, bool su
 #ifndef KBE_FILL_BURST_LANES
 #define KBE_FILL_BURST_LANES 16         // ... in a wave whose queue has run dry and of which no more lanes than this still walk
 #endif
-#ifndef KBE_FILL_COOP_LANES
-#define KBE_FILL_COOP_LANES 4           // ... and with no more than this many lanes still walking, a creeping ray gets all 64 lanes: its next 64 steps at once
-#endif
 #ifndef KBE_FILL_REFILL_MIN
 #define KBE_FILL_REFILL_MIN 16          // lanes of a wave that must be waiting before new work is fetched
 #endif
@@ -764,52 +761,11 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                 }
                 return true;
             };
-            // ... and once no more than KBE_FILL_COOP_LANES lanes of the wave still walk (round 5), a creeping ray gets the WHOLE WAVE:
-            // lane j looks at the position j + 1 steps on -- all 64 from the ray's integer mantissas, exactly the fp32 sums while
-            // the chain stays inside its binades (struct Axis; a ray next to a binade boundary takes the bursts above until it is
-            // across) -- and the first position that ends the ray counts, as in a burst.  A batch of 256 holes ends with its
-            // slowest ray, and nearly every batch of a late dolly frame holds one that creeps for hundreds of steps (~1 700 of
-            // them per frame, ~1 000 batches): at four steps per iteration its workgroup waited ~100 iterations for it.
-            const auto coop = [&]() -> bool {
-                unsigned long long todo = __ballot(st == END_WALK && rx == ry && rx >= 1 && rx <= 2 && X.e >= 0 && Y.e >= 0);
-                bool any = false;
-                while (todo) {                                          // uniform
-                    const int L = (int) __ffsll((long long) todo) - 1;
-                    todo &= todo - 1;
-                    const int aX = __builtin_amdgcn_readlane(X.A, L), sX = __builtin_amdgcn_readlane(X.step, L), eX = __builtin_amdgcn_readlane(X.e, L);
-                    const int aY = __builtin_amdgcn_readlane(Y.A, L), sY = __builtin_amdgcn_readlane(Y.step, L), eY = __builtin_amdgcn_readlane(Y.e, L);
-                    // every one of the 64 positions, and a step to either side of it, inside the binade (the fast mode's invariant)
-                    if (!(axis_interior(aX + 64 * sX, abs(sX)) & axis_interior(aY + 64 * sY, abs(sY)))) continue;
-                    const float lux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ux), L)), luy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uy), L));
-                    const float lbound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), L));
-                    const bool l_is_b = L & 1;
-                    const int shx = 23 - eX, shy = 23 - eY;
-                    const int cx = (aX + (lane + 1) * sX + (1 << (shx - 1))) >> shx, cy = (aY + (lane + 1) * sY + (1 << (shy - 1))) >> shy;     // axis_pixel
-                    const bool inb = ((unsigned) cx < (unsigned) W) & ((unsigned) cy < (unsigned) H);
-                    const float t = lux * (float) cx + luy * (float) cy;
-                    const bool stop = !inb || (l_is_b ? lbound < t - STRIP_MARGIN : lbound > t + STRIP_MARGIN);
-                    const int dn = dist[inb ? (uint32_t) cy * (uint32_t) W + (uint32_t) cx : 0u];
-                    KBE_FILL_STAT(2, 1);
-                    const unsigned long long m_stop = __ballot(stop), m_end = m_stop | __ballot(!stop && dn == 0);
-                    const int j = m_end ? (int) __ffsll((long long) m_end) - 1 : 63;          // the first position that ends the ray, or the last looked at
-                    const int hx = __builtin_amdgcn_readlane(cx, j), hy = __builtin_amdgcn_readlane(cy, j), hdn = __builtin_amdgcn_readlane(dn, j);
-                    if (lane == L) {
-                        k -= rx;                                        // the pending steps are among these
-                        if (m_end) {
-                            if ((m_stop >> j) & 1ull) st = END_DEAD;
-                            else { st = END_HIT; ix = hx; iy = hy; k += j + 1; }
-                        } else {
-                            X.A = aX + 64 * sX; Y.A = aY + 64 * sY;
-                            ix = hx; iy = hy;
-                            const int m = max(1, (int) ceilf(((float) hdn - 1.03f) * inv_umax));
-                            rx = ry = m;
-                            k += 64 + m;
-                        }
-                    }
-                    any = true;
-                }
-                return any;
-            };
+            // (Round 5 tried more: with four or fewer lanes still walking, a creeping ray got the WHOLE WAVE -- lane j looking at the
+            // position j + 1 steps on, all 64 from the ray's integer mantissas.  Same fills, no gain: 94.2 / 93.7 us per dolly frame
+            // without / with, the fill alone 339 / 343 -- tools/fill_stats.py shows why: since the bursts above only ~100 ray ends of
+            // a late frame still live 128 iterations or more; the launch is the sum of 1.7 M short rays, 62 % of them done in under
+            // four iterations.  Removed again: git show 5750a8a:ken-burns-effect_amd/csrc/kbe_holes.hip.)
             bool stragglers = false;
             for (;;) {
                 look();
@@ -869,7 +825,6 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                     if (st == END_WALK) iters++;
                     { const unsigned long long w = __ballot(st == END_WALK); if (lane == 0) { KBE_FILL_STAT(6, 1ull | (1ull << 32)); KBE_FILL_STAT(7, (unsigned long long) __popcll(w) | ((unsigned long long) __popcll(w) << 32)); } }
 #endif
-                    if (KBE_FILL_COOP_LANES > 0 && __popcll(__ballot(st == END_WALK)) <= KBE_FILL_COOP_LANES && coop()) continue;
                     if (!creep()) step();
                 }
         }

@@ -799,11 +799,12 @@ def test_cloud_of_nine_points_per_pixel_takes_the_atomic_kernels_and_matches_the
         frames_close(bucket[i], in_hbm[i], 'bucket route against the atomic route, frame %d' % i)
 
 
-@pytest.mark.parametrize('kind', ['rough', 'near_plane'])
+@pytest.mark.parametrize('kind', ['rough', 'near_plane', 'curved'])
 def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, kind):
-    """The frames a tile launch places ahead share ONE set of candidate lists when they are consecutive cameras of a straight
-    path (same focal length, shifts on a line: kbe_fused.hip, launch_frames_fused's `shareable`): a sub-block is listed for the box
-    of its corners under the group's first and last camera.  On clouds where that box is large or has no bound -- a depth map of
+    """Consecutive frames a tile launch places ahead share candidate lists in sub-groups (same focal length, shifts only differ:
+    kbe_fused.hip, launch_frames_fused's share_plan): a sub-block is listed for the box of its corners under the sub-group's first
+    and last camera, widened by how far the cameras in between stray from that chord ('curved': a parabola in shift space, what a
+    Ken Burns path is).  On clouds where that box is large or has no bound -- a depth map of
     noise between 3 and 900 under a camera that moves by whole tiles per group ('rough'), and rows of points that pass the near
     plane INSIDE a group ('near_plane': z between 0.5 and 40, the camera advancing by 4 per frame) -- groups of 12, 5, 12, 2
     frames, pipelined, render the frames of the same groups with their per-frame lists (placement launches in front)."""
@@ -817,10 +818,16 @@ def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, k
     pts = torch.stack([(xs - W / 2 + 0.5) * z / 512.0, (ys - H / 2 + 0.5) * z / 512.0, z]).reshape(1, 3, -1)
     N = W * H
     img, dep = torch.rand(1, 3, N, generator=g0), torch.rand(1, 1, N, generator=g0) * 500 + 100
-    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H)
+    # near_depth is a HINT (how many frames share a list: kbe_fused.hip share_plan): one that is far too large makes every group of
+    # four frames or more share ONE list whatever its cameras' spread -- the frames must not change
+    state = K.prepare_cloud(pts.cuda(), img.cuda(), dep.cuda(), W, H, near_depth=1.0e7)
     assert state['fused']
     K._pack(state)
     cams = [(512.0, (0.9 * i - 12.0, 6.0 - 0.5 * i, -4.0 * i)) for i in range(31)]       # one straight path, equal steps
+    if kind == 'curved':
+        # what a Ken Burns path is (common.py:88-100: shiftX = dU closestDepth(step) / F): a parabola in shift space -- the cameras
+        # between a sub-group's first and last stray from the chord (round 4's straight-line test never let such a group share)
+        cams = [(512.0, (0.03 * i * i - 0.9 * i + 3.0, 6.0 - 0.04 * i * i, 2.0 * i - 0.2 * i * i)) for i in range(31)]
     sizes = [12, 5, 12, 2]
     groups, at = [], 0
     for n in sizes:
