@@ -27,14 +27,12 @@ SYMBOLS = (
 ABI_VERSION = 10
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
-FUSED_MAX_DENSITY = 4.5          # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  1.5 until round 4: a denser cloud kept
-                                 # a placement launch of its own and lost to the bucket route; with its placements riding in the tile launch (k_frame_group_ahead_dense)
-                                 # four points per pixel render in 353 against 387 us per 2048^2 frame, 86 against 95 at 1024^2 (profiles/r04_dense_clouds.txt)
-GENERIC_MIN_DENSITY = 6.5        # clouds denser than this take the stage-by-stage kernels with global atomics (HipKernels._render_video_generic).  Both tile routes
-                                 # fall off a cliff between 5 and 6 points per pixel (tile buckets, candidate lists and spill areas overflow on the densest tiles and
-                                 # those tiles scan the cloud), the atomic path grows linearly -- measured at 1024^2 on a 3 x 3-upsampled cloud thinned at random
-                                 # (profiles/r05_density_sweep.txt), us per frame bucket / fused / atomic: 4 per pixel 158 / 147 / 2276, 5: 195 / 4777 / 2840,
-                                 # 6: 5883 / 3415 / 3975, 7: 8454 / 7476 / 4312, 8: 6237 / 7576 / 5587, 9: 14134 / 14048 / 6611
+FUSED_MAX_DENSITY = 20.0         # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  Round 5: a tile's candidate list holds 2048
+                                 # sub-blocks (512 before: the densest tiles' lists overflowed from 5 points per pixel on and those tiles scanned the cloud) and a record
+                                 # that finds no room in LDS waits as its 4-byte point index (16-byte records before; four times the capacity) -- the route now grows
+                                 # linearly to 20 points per pixel: 141 / 284 / 395 / 535 / 657 us per 1024^2 frame at 4 / 9 / 12 / 16 / 20 per pixel, 11.6 ms at 24
+                                 # (profiles/r05_density_sweep.txt; the bucket route: 153 / 14 083 us at 4 / 9, the atomic kernels 2.1 / 5.2 / 20.5 ms at 4 / 9 / 24).
+                                 # (4.5 in round 4, 1.5 before.)
 FUSED_MAX_POINTS = 1 << 28       # the packed cloud's route addresses points by 32-bit byte offsets (KBE_FUSED_MAX_POINTS, kbe_tiles.h): larger clouds take the bucket route
 FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
@@ -324,9 +322,11 @@ class HipKernels:
         # unless the cloud has more than 1.5 points per pixel; render_video also looks at the camera path) | 1 | 0.
         mode = os.environ.get('KBE_FUSED', 'auto')
         state['fused'] = ((N <= FUSED_MAX_DENSITY * W * H) if mode == 'auto' else mode not in ('0', 'generic')) and N <= FUSED_MAX_POINTS
-        # ... and a third for clouds far denser than the raster: the reference's own decomposition (z-splat, degrid, accumulate with
-        # global atomics, normalise, fill), one frame at a time -- see GENERIC_MIN_DENSITY
-        state['generic'] = (N > GENERIC_MIN_DENSITY * W * H) if mode == 'auto' else mode == 'generic'
+        # ... and a third, on request only (KBE_FUSED=generic): the reference's own decomposition (z-splat, degrid, accumulate with global
+        # atomics, normalise, fill), one frame at a time -- the independent cross-check of the two tile routes as a whole video loop.  (For a
+        # day of round 5 clouds beyond 6.5 points per pixel took it, as the lesser evil next to the tile routes' cliff; with the cliff gone it
+        # is 15-35 x slower than the fused route at every density measured.)
+        state['generic'] = mode == 'generic'
         state['cloud_focal'] = float(focal) if focal else 512.0
         # the depth of the nearest point (the reference's objectDepthrange[0], common.py:88, when the caller has it; else found
         # on first need): decides how many consecutive frames of a video share candidate lists (include/kbe.h: near_depth)
@@ -588,8 +588,8 @@ class HipKernels:
     def _render_video_generic(self, state, cameras, baseline, crop, host_out):
         """The frame loop on the stage-by-stage kernels (kbe_shift_points, kbe_render_pointcloud's z-splat / degrid / accumulate /
         normalise with global atomics, kbe_fill_disocclusion, kbe_frame_u8, kbe_crop_resize_u8) -- the reference's own decomposition
-        of common.py:238-257, for clouds so much denser than the raster that the tile routes' per-tile capacities overflow
-        (GENERIC_MIN_DENSITY).  Frame by frame from Python: at ~1 ms of GPU work per frame the loop's own cost does not matter."""
+        of common.py:238-257 (KBE_FUSED=generic: a cross-check of the tile routes, not a product route).  Frame by frame from Python:
+        at >= 1 ms of GPU work per frame the loop's own cost does not matter."""
         n, W, H = len(cameras), state['W'], state['H']
         dev = state['points'].device
         if 'generic_data' not in state:

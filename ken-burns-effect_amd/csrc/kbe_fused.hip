@@ -40,6 +40,7 @@ namespace {
 // correctly.
 // ---------------------------------------------------------------------------------------
 constexpr int MAXC = TILE_THREADS;      // candidate blocks per window of the slow path (one per thread in its prefix scan)
+constexpr int SPILL_CAP = 4 * BUCKET_CAP;   // point indices a tile's spill area holds (the area is BUCKET_STRIDE records of 16 bytes)
 constexpr int LIST_CAP = KBE_CAND_CAP;      // sub-blocks a tile's candidate list holds (kbe_tiles.h: the scratch is sized by it)
 // A sub-block whose points reach more than BIN_WIDE_FAN tiles is "wide": it is still listed for every tile of its box, but
 // the frame keeps a running total of such entries, and once that exceeds BIN_WIDE_BUDGET entries per tile of the frame (an
@@ -614,6 +615,11 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     // (slow path) records each candidate block of a window contributes, then their prefix sums: in the tile's spill area, which
     // only the normal path's further rounds use -- 1 KB less LDS is what lets a fifth workgroup onto the CU
     int* const slow_cnt = (int*) spill;
+    // (normal path) a record that finds no room in LDS waits in the spill area as its POINT INDEX (4 bytes; until round 5: its
+    // 16-byte record {ox, oy, dblError, index}): the round that takes it reads the point's placement again, which the tile has just
+    // pulled through the L2 -- 4 + 4 instead of 16 + 16 bytes of HBM traffic per spilled record, and the same area holds four times
+    // as many (SPILL_CAP: 48 records per pixel of the tile)
+    int* const spill_idx = (int*) spill;
     auto placed_point = [&](int flags, float ox, float oy, float err, bool ok, int idx, int c, const float4& col) {
         Proj p;
         p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
@@ -663,7 +669,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
                     if (lane == 0) sbase = atomicAdd(&F.n_ovf, __popcll(ms));
                     sbase = __builtin_amdgcn_readfirstlane(sbase);
                     const int o = sbase + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
-                    if (sp && o < BUCKET_CAP) spill[o] = make_float4(ox, oy, err, __int_as_float(idx));
+                    if (sp && o < SPILL_CAP) spill_idx[o] = idx;
                 }
             }
         }
@@ -756,7 +762,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
     const int total = L.nrec;
     bool fast;
     const int n_spill = F.n_ovf;
-    if (listed && n_spill <= BUCKET_CAP) {
+    if (listed && n_spill <= SPILL_CAP) {
         // ---- the first REC_CAP records are in LDS with their colours
         // ... or (LAZY: the launch for dense clouds, which is as close to the memory's limit as to the issue rate's) with their
         // points: the colours of the RECORDS only -- the near misses of the candidate list, a third of it, never fetch
@@ -798,12 +804,10 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const int i = tid + u * TILE_THREADS;
-                rr[u] = i < n ? spill[r0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int i = tid + u * TILE_THREADS;
-                cc[u] = fetch_rgbd(i < n ? __float_as_int(rr[u].w) : 0);
+                const int id = i < n ? spill_idx[r0 + i] : 0;
+                const Placement q = *at_offset32(place, (uint32_t) id);
+                rr[u] = make_float4(q.ox, q.oy, q.err, 0.0f);
+                cc[u] = fetch_rgbd(id);
             }
             __syncthreads();
 #pragma unroll
@@ -930,7 +934,7 @@ __device__ __forceinline__ void frame_body(const __attribute__((address_space(4)
         atomicAdd(&g_frame_stats[0], 1ull);
         atomicAdd(&g_frame_stats[2], (unsigned long long) n_cand);
         atomicAdd(&g_frame_stats[4], (unsigned long long) total);
-        atomicAdd(&g_frame_stats[5], (unsigned long long) !(listed && n_spill <= BUCKET_CAP));
+        atomicAdd(&g_frame_stats[5], (unsigned long long) !(listed && n_spill <= SPILL_CAP));
         atomicAdd(&g_frame_stats[6], (unsigned long long) (n_spill > 0));
     }
 #else

@@ -49,7 +49,9 @@ constexpr int BUCKET_CAP = KBE_BUCKET_FACTOR * TW * TH;     // records a tile's 
 constexpr int BUCKET_STRIDE = BUCKET_CAP + KBE_BUCKET_PAD;  // records between two buckets: NOT a power-of-two multiple, or the
                                                     // live head of every bucket lands on the same few HBM channels
 #ifndef KBE_CAND_CAP
-#define KBE_CAND_CAP (512 * 16 / KBE_CLOUD_SUB)
+#define KBE_CAND_CAP (2048 * 16 / KBE_CLOUD_SUB)     // (512 until round 5: from 5 points per pixel on the densest tiles' lists overflowed and those tiles scanned the
+                                                    // cloud -- 2.5 ms per 1024^2 frame at 5 per pixel, 13 ms at 9; with 1024 entries 175 and 283 us, and the headline
+                                                    // launch costs the same with 512, 768 or 1024: profiles/r05_density_sweep.txt)
 #endif
 constexpr int CNT_STRIDE = 32;                      // ints between two bucket counters: one 128-byte line each, so that
                                                     // the counter atomics of neighbouring tiles do not serialise in L2

@@ -763,12 +763,13 @@ def test_every_instantiation_of_the_tile_launch_against_the_oracle(K, oracle, mo
             '%s, frame %d: max %d, %.2e of the values differ' % (build, i, d.max(), (d > 0).mean())
 
 
-def test_cloud_of_nine_points_per_pixel_takes_the_atomic_kernels_and_matches_the_oracle(K, oracle, monkeypatch):
-    """Beyond ~8 points per pixel the tile routes' per-tile capacities overflow (a bucket holds 12 records per pixel of its tile)
-    and both fall off a cliff; such clouds take the stage-by-stage kernels with global atomics, which scale linearly
-    (_native.GENERIC_MIN_DENSITY, HipKernels._render_video_generic: VERDICT r4 item 5).  A 3 x 3-upsampled cloud on a 96 x 128
-    raster: the route is chosen by the density alone, the frames -- left in HBM and delivered through the crop -- equal the
-    oracle's within the order of the fp32 sums, and the bucket route forced on the same cloud renders the same frames."""
+def test_cloud_of_nine_points_per_pixel_on_all_three_routes_against_the_oracle(K, oracle, monkeypatch):
+    """Until round 5 both tile routes fell off a cliff from 5-6 points per pixel on (candidate lists of 512 sub-blocks and spill
+    areas of 16-byte records overflowed on the densest tiles, which then scanned the cloud: 13 ms per 1024^2 frame at 9 per pixel).
+    Lists of 2048 entries and records spilled as 4-byte point indices let the fused route grow linearly to 20 per pixel (VERDICT r4
+    items 5 and 7).  A 3 x 3-upsampled cloud on a 96 x 128 raster: the default route is the fused one, its frames -- left in HBM and
+    delivered through the crop -- equal the oracle's within the order of the fp32 sums; so do the bucket route's and those of the
+    stage-by-stage atomic kernels run as a video loop (KBE_FUSED=generic)."""
     from ken_burns_effect_amd import _native, common, synthetic
     H, W, up = 96, 128, 3
     settings, oc = _scene((H, W), 6)
@@ -777,26 +778,29 @@ def test_cloud_of_nine_points_per_pixel_takes_the_atomic_kernels_and_matches_the
     oc['tensorInpaPoints'] = K.depth_to_points(depth_u, 512.0 * up).view(1, 3, -1)
     oc['tensorInpaImage'] = image_u.cuda().reshape(1, 3, -1)
     oc['tensorInpaDepth'] = depth_u.reshape(1, 1, -1)
-    assert oc['tensorInpaPoints'].shape[2] == 9 * H * W > _native.GENERIC_MIN_DENSITY * H * W
+    oc['_kbeCloudRaster'] = (W * up, W * up * H * up)
+    assert oc['tensorInpaPoints'].shape[2] == 9 * H * W <= _native.FUSED_MAX_DENSITY * H * W
     cams = common.frame_cameras(dict(settings, dblSteps=[0.0, 0.3, 0.7, 1.0]), oc)
     state = common._prepared_cloud(K, oc)
-    assert state['generic'] and not state['fused']
+    assert state['fused'] and not state['generic']
     crop = common.crop_size(settings)
     in_hbm = c(common.render_frames(cams, oc, None, keep_on_device=True))
     delivered = common.render_frames(cams, oc, crop)
     ok = oracle.OracleKernels('jacobi')
     ostate = ok.prepare_cloud(oc['tensorInpaPoints'].cpu(), oc['tensorInpaImage'].cpu(), oc['tensorInpaDepth'].cpu(), W, H)
-    for i, (focal, shift3) in enumerate(cams):
-        ref = ok.render_frame(ostate, shift3, focal, oc['dblBaseline']).numpy()
-        frames_close(in_hbm[i], ref, 'atomic route, frame %d' % i)
-        frames_close(delivered[i], oracle.crop_resize_u8(ref, crop[0], crop[1]), 'atomic route, delivered frame %d' % i, cropped=True)
+    refs = [ok.render_frame(ostate, shift3, focal, oc['dblBaseline']).numpy() for focal, shift3 in cams]
+    for i, ref in enumerate(refs):
+        frames_close(in_hbm[i], ref, 'fused route, frame %d' % i)
+        frames_close(delivered[i], oracle.crop_resize_u8(ref, crop[0], crop[1]), 'fused route, delivered frame %d' % i, cropped=True)
     assert in_hbm.any()
-    monkeypatch.setenv('KBE_FUSED', '0')                # the bucket route on the same cloud (slow at this density, not wrong)
-    oc.pop('_kbePreparedCloud')
-    bucket = c(common.render_frames(cams, oc, None, keep_on_device=True))
-    assert not common._prepared_cloud(K, oc)['generic']
-    for i in range(len(cams)):
-        frames_close(bucket[i], in_hbm[i], 'bucket route against the atomic route, frame %d' % i)
+    for route in ('0', 'generic'):                      # the bucket route (slow at this density, not wrong) and the atomic kernels
+        monkeypatch.setenv('KBE_FUSED', route)
+        oc.pop('_kbePreparedCloud')
+        other = c(common.render_frames(cams, oc, None, keep_on_device=True))
+        st = common._prepared_cloud(K, oc)
+        assert not st['fused'] and st['generic'] == (route == 'generic')
+        for i, ref in enumerate(refs):
+            frames_close(other[i], ref, 'KBE_FUSED=%s, frame %d' % (route, i))
 
 
 @pytest.mark.parametrize('kind', ['rough', 'near_plane', 'curved'])

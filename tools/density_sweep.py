@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
 
-size, up = int(os.environ.get('SIZE', '1024')), 3
+size, up = int(os.environ.get('SIZE', '1024')), int(os.environ.get('UP', '3'))
 dev = torch.device('cuda:0')
 K = _native.kernels()
 image_u, disp_u = synthetic.make_rgbd(size * up, size * up, 0)
