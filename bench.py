@@ -135,7 +135,7 @@ BUCKET_GROUP_MAX = 4    # kbe_render_frame_group takes up to four frames, kbe_re
 VALU_ISSUE_PER_US = 570.0e3
 
 
-def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES, fill_flags=0, paths=None):
+def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FRAMES, fill_flags=0, paths=None, fill_group=1):
     """Average GPU time of the frame launches from HIP events on the launch stream (torch's
     current stream is the one the C ABI launches on).  Each figure is `reps` back-to-back
     launches between two events; the tile kernel is timed alone (back to back on a prepared scratch) --
@@ -293,6 +293,25 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
         fills.append(max(t_all - t_scatter, 0.0))
     out['fill_along_path'] = sum(fills) / len(fills)
     out['fill_along_path_max'] = max(fills)
+    # ... and with the frames per launch the video loop gives the fill where it groups them (KBE_VIDEO_FILL_GROUP: the table-driven fill of a
+    # dolly zoom takes four frames per launch on the bucket route -- its launches are bound by their own chains of dependent look-ups, and
+    # four frames in one launch take much less than four times one): four consecutive cameras at the same eight places of the path
+    if route == 'bucket' and fill_group > 1:
+        gout = torch.empty(fill_group, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
+        gfills = []
+        for i in range(8):
+            at = min((2 * i + 1) * len(cams) // 16, max(0, len(cams) - fill_group))
+            group = cams[at:at + fill_group]
+            if len(group) < fill_group:
+                break
+            t_all = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7 | fill_flags, fill_rect=fill_rect))
+            t_scatter = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7, fill_rect=empty))      # the fill launch with nothing to fill: its reset
+            gfills.append(max(t_all - t_scatter, 0.0))
+        if gfills:
+            out['fill_group_along_path'] = sum(gfills) / len(gfills)
+            out['fill_group_along_path_max'] = max(gfills)
+            out['fill_group_frames'] = fill_group
+        del gout
     frame = K.render_frame(state, shift3, focal, Bl)
     cw, ch = int(0.9 * W), int(0.9 * H)
     out['crop_resize'] = timed(lambda: K.crop_resize_u8(frame, cw, ch))
@@ -709,7 +728,7 @@ def main():
             for n_steps in dict.fromkeys((total_steps, PRODUCT_STEPS, DRIVER_STEPS)):
                 paths[str(n_steps)] = common.frame_cameras(dict(settings, dblSteps=np.linspace(0.0, 1.0, max(n_steps, 2)).tolist()[:n_steps]), oc)
         kt = time_kernels(oc, cams, route, fill_rect=None if crop is None else common.crop_window(size, size, crop[0], crop[1]), group_frames=group_frames,
-                          fill_flags=fill_flags, paths=paths)
+                          fill_flags=fill_flags, paths=paths, fill_group=group_used if (video_flags & 1) else 1)
         HW = size * size
         # roofline = the scatter (render_pointcloud, common.py:428-686: z-buffer clear + z-splat + degrid + accumulate +
         # normalise), SURVEY.md 8d: algorithmic bytes 28 N + 20 HW (every input once, every output once, no scratch) per frame
@@ -824,6 +843,16 @@ def main():
                     'us_worst_of_eight_cameras': round(kt['fill_along_path_max'] * 1e6, 2),
                     'note': 'a frame on its own on one stream (HIP events, 40 repetitions), with and without its fill, eight cameras along the path; '
                             'the walk is bound by instruction issue and the number of holes, not by these bytes'}
+        if 'fill_group_along_path' in kt:
+            # the fill's launches as the video loop makes them: `frames_per_launch` frames each (the single-frame figure stays beside it)
+            g_t, g_n = kt['fill_group_along_path'], kt['fill_group_frames']
+            fill_obj['one_frame_per_launch'] = {k: fill_obj[k] for k in ('achieved', 'frac', 'us_per_frame', 'us_worst_of_eight_cameras')}
+            fill_obj.update({'frames_per_launch': g_n, 'us': round(g_t * 1e6, 2), 'us_per_frame': round(g_t * 1e6 / g_n, 2), 'algorithmic_bytes': g_n * 36 * HW,
+                             'achieved': g_n * 36 * HW / max(g_t, 1e-9) / 1e9, 'frac': g_n * 36 * HW / max(g_t, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                             'us_worst_of_eight_cameras': round(kt['fill_group_along_path_max'] * 1e6 / g_n, 2),
+                             'note': 'the fill launches of %d consecutive frames (what the video loop launches: KBE_VIDEO_FILL_GROUP) alone on one stream (HIP events, 40 repetitions), with and '
+                                     'without their fill, at eight places along the path; `one_frame_per_launch`: a frame on its own; the walk is bound by instruction issue, '
+                                     'dependent look-ups and the number of holes, not by these bytes' % g_n})
         if fill_t * 1e6 > single['us_per_frame']:          # (like with like: both a frame on its own)
             fill_obj['scatter'] = line['roofline']
             line['roofline'] = fill_obj

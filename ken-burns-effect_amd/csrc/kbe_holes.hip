@@ -194,8 +194,7 @@ static_assert(DT_W == 64, "the halo is one 32-pixel word on each side");
 // rounded per axis; the fp32 sums drift by < 0.03 over 1000 steps), so the only valid pixels it can ever meet lie in the
 // strip of lines c in [b - 1, b + 2), b = floor(c(p)), c(q) = n . q the coordinate across the direction.  Per direction
 // and b, (lo, hi) bound the coordinate t(q) = u . q along the direction over every valid pixel of that strip -- or rather
-// over a superset of them: the x-extent of each tile row (the y-extent of each tile column for the flat directions), from
-// the tiles' boxes.  The end walking towards -u meets nothing once lo > t + 1, the end towards +u once hi < t - 1: the
+// over a superset of them: the boxes of the tiles the strip crosses (build_strips).  The end walking towards -u meets nothing once lo > t + 1, the end towards +u once hi < t - 1: the
 // direction is skipped (common.py:880-885, 891-896) without walking to the image border.  A zoomed-out frame is mostly
 // border around a convex patch of valid pixels; outside a convex patch NO direction has valid pixels on both sides.
 // Measured on the last frame of the dolly bench (266 k holes inside the box of valid pixels): 1.7 of a hole's 16 directions
@@ -212,40 +211,45 @@ __device__ __forceinline__ int strip_offset(float ux, float uy, int W, int H)
 __device__ void build_strips(const int4* __restrict__ bbox, int tiles_x, int tiles_y, int W, int H, float ux, float uy, int first_bin,
                              float2* __restrict__ out)
 {
-    __shared__ int s_ext[4][STRIP_TILES];           // per tile row: min x, max x; per tile column: min y, max y
-    const int tid = threadIdx.x;
-    for (int i = tid; i < STRIP_TILES; i += blockDim.x) { s_ext[0][i] = 1 << 30; s_ext[1][i] = -1; s_ext[2][i] = 1 << 30; s_ext[3][i] = -1; }
-    __syncthreads();
-    for (int t = tid; t < tiles_x * tiles_y; t += blockDim.x) {
-        const int4 bb = bbox[t];
-        if (bb.z < bb.x) continue;                              // a tile without a valid pixel
-        const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        atomicMin(&s_ext[0][ty], bb.x); atomicMax(&s_ext[1][ty], bb.z);
-        atomicMin(&s_ext[2][tx], bb.y); atomicMax(&s_ext[3][tx], bb.w);
-    }
-    __syncthreads();
-    const int b = first_bin + tid;
+    const int b = first_bin + (int) threadIdx.x;
     if (b >= strip_bins(W, H)) return;
     const float c0 = (float) (b - strip_offset(ux, uy, W, H)) - STRIP_MARGIN, c1 = c0 + 1.0f + 2.0f * STRIP_MARGIN;
+    // The superset the bounds are taken over (round 5): the BOXES OF THE TILES the strip crosses -- per tile row (tile column for
+    // a flat direction) the one to three tiles under the strip, each with the box of its own valid pixels (the tile launch's
+    // bbox table), the strip clipped to the box's rows and columns.  Until round 5: the x-extent of each whole tile ROW (the
+    // y-extent of each tile column) -- 4.46 of a late dolly frame's 16 directions per hole passed the test where 1.73 complete;
+    // with the tiles' own boxes 2.47 pass (tools/strip_proto.c on the oracle's masks; row and column extents intersected: 3.19;
+    // exact per-line extents: 1.90) -- and the directions that pass without completing are the expensive ones: they walk to the
+    // end of their strip.
     float lo = INFINITY, hi = -INFINITY;
     const bool steep = fabsf(uy) >= fabsf(ux);                  // the line crosses every row once: walk the tile rows
-    const int n = steep ? tiles_y : tiles_x;
+    const int n = steep ? tiles_y : tiles_x, m = steep ? tiles_x : tiles_y;
     const float ua = steep ? ux : uy, ub = steep ? uy : ux;     // a = the coordinate along a row (column), b = across
     const float inv = 1.0f / ub;
-    for (int i = 0; i < n; i++) {
-        const int e0 = s_ext[steep ? 0 : 2][i], e1 = s_ext[steep ? 1 : 3][i];
-        if (e1 < 0) continue;
-        const float b0 = (float) (i * (steep ? TH : TW)), b1 = b0 + (float) ((steep ? TH : TW) - 1);
-        // steep: c = -uy x + ux y  =>  x = (ux y - c) / uy;   flat: y = (c + uy x) / ux
+    const int sa = steep ? TW : TH, sb = steep ? TH : TW;
+    // the strip's extent along a over the rows (columns) b0 .. b1 -- steep: c = -uy x + ux y => x = (ux y - c) / uy; flat: y = (c + uy x) / ux
+    const auto along = [&](float b0, float b1, float& a0, float& a1) {
         const float v0 = steep ? (ua * b0 - c0) * inv : (c0 + ua * b0) * inv, v1 = steep ? (ua * b0 - c1) * inv : (c1 + ua * b0) * inv;
         const float v2 = steep ? (ua * b1 - c0) * inv : (c0 + ua * b1) * inv, v3 = steep ? (ua * b1 - c1) * inv : (c1 + ua * b1) * inv;
-        float a0 = fminf(fminf(v0, v1), fminf(v2, v3)) - 0.01f, a1 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) + 0.01f;
-        a0 = fmaxf(a0, (float) e0); a1 = fminf(a1, (float) e1);
-        if (a0 > a1) continue;
-        // t = ux x + uy y = ua a + ub b over [a0, a1] x [b0, b1]
-        const float t0 = ua * a0 + ub * b0, t1 = ua * a0 + ub * b1, t2 = ua * a1 + ub * b0, t3 = ua * a1 + ub * b1;
-        lo = fminf(lo, fminf(fminf(t0, t1), fminf(t2, t3)));
-        hi = fmaxf(hi, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+        a0 = fminf(fminf(v0, v1), fminf(v2, v3)) - 0.01f; a1 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) + 0.01f;
+    };
+    for (int i = 0; i < n; i++) {
+        float a0, a1;
+        along((float) (i * sb), (float) (i * sb + sb - 1), a0, a1);
+        const int j0 = max((int) floorf(a0 / (float) sa), 0), j1 = min((int) floorf(a1 / (float) sa), m - 1);
+        for (int j = j0; j <= j1; j++) {
+            const int4 bb = bbox[steep ? i * tiles_x + j : j * tiles_x + i];
+            if (bb.z < bb.x) continue;                          // a tile without a valid pixel
+            const float q0 = (float) (steep ? bb.y : bb.x), q1 = (float) (steep ? bb.w : bb.z);        // the box across ...
+            float p0, p1;
+            along(q0, q1, p0, p1);
+            p0 = fmaxf(p0, (float) (steep ? bb.x : bb.y)); p1 = fminf(p1, (float) (steep ? bb.z : bb.w));     // ... and along
+            if (p0 > p1) continue;
+            // t = ux x + uy y = ua a + ub b over [p0, p1] x [q0, q1]
+            const float t0 = ua * p0 + ub * q0, t1 = ua * p0 + ub * q1, t2 = ua * p1 + ub * q0, t3 = ua * p1 + ub * q1;
+            lo = fminf(lo, fminf(fminf(t0, t1), fminf(t2, t3)));
+            hi = fmaxf(hi, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+        }
     }
     out[b] = make_float2(lo, hi);
 }
@@ -761,11 +765,12 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                 }
                 return true;
             };
-            // (Round 5 tried more: with four or fewer lanes still walking, a creeping ray got the WHOLE WAVE -- lane j looking at the
-            // position j + 1 steps on, all 64 from the ray's integer mantissas.  Same fills, no gain: 94.2 / 93.7 us per dolly frame
-            // without / with, the fill alone 339 / 343 -- tools/fill_stats.py shows why: since the bursts above only ~100 ray ends of
-            // a late frame still live 128 iterations or more; the launch is the sum of 1.7 M short rays, 62 % of them done in under
-            // four iterations.  Removed again: git show 5750a8a:ken-burns-effect_amd/csrc/kbe_holes.hip.)
+            // (Round 5 tried more, twice: with few lanes of a wave still walking -- 4, 8, 16 -- a ray got the WHOLE WAVE, lane j looking at the
+            // position j + 1 steps on, all 64 from the ray's integer mantissas; first for creeping rays only, then for any walking ray.
+            // Same fills, no gain either time: 89.5 us per dolly frame with and without.  tools/fill_stats.py and a PMC pass say why: the
+            // video loop is bound by its INSTRUCTION COUNT -- 38 M wave-level VALU per frame, 23 M of them this kernel's, = 67 us of issue
+            // in an 89 us frame -- not by its longest rays (the longest ray of a late frame lives ~95 iterations, and sixteen frames are
+            // in flight).  Removed again: git show 5750a8a:ken-burns-effect_amd/csrc/kbe_holes.hip.)
             bool stragglers = false;
             for (;;) {
                 look();

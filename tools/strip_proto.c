@@ -15,30 +15,31 @@ static uint8_t m[H][W];
 int main(int argc,char**argv){
     FILE*f=fopen(argv[1],"rb"); fread(m,1,W*H,f); fclose(f);
     const float dx[16]={-1,0,1,1,-1,1,2,2,-2,-1,1,2,3,3,3,3}, dy[16]={1,1,1,0,2,2,1,-1,3,3,3,3,2,1,-1,-2};
-    // tile-row / tile-col extents
-    int rmin[H/TH], rmax[H/TH], cmin[W/TW], cmax[W/TW];
-    for(int i=0;i<H/TH;i++){rmin[i]=1<<20;rmax[i]=-1;} for(int i=0;i<W/TW;i++){cmin[i]=1<<20;cmax[i]=-1;}
+    // the box of every tile's valid pixels (what the tile launch leaves in its bbox table)
+    static int bb[H/TH][W/TW][4];
+    for(int ty=0;ty<H/TH;ty++)for(int tx=0;tx<W/TW;tx++){bb[ty][tx][0]=1<<20;bb[ty][tx][1]=1<<20;bb[ty][tx][2]=-1;bb[ty][tx][3]=-1;}
     int bx0=W,bx1=-1,by0=H,by1=-1;
-    for(int y=0;y<H;y++)for(int x=0;x<W;x++) if(m[y][x]){ int ty=y/TH,tx=x/TW; if(x<rmin[ty])rmin[ty]=x; if(x>rmax[ty])rmax[ty]=x; if(y<cmin[tx])cmin[tx]=y; if(y>cmax[tx])cmax[tx]=y;
+    for(int y=0;y<H;y++)for(int x=0;x<W;x++) if(m[y][x]){ int*q=bb[y/TH][x/TW]; if(x<q[0])q[0]=x; if(y<q[1])q[1]=y; if(x>q[2])q[2]=x; if(y>q[3])q[3]=y;
         if(x<bx0)bx0=x; if(x>bx1)bx1=x; if(y<by0)by0=y; if(y>by1)by1=y; }
     const int NB=2*(W+H)+8, OFF=W+H+4; const float M=1.0f;
     static float lo[16][2*(W+H)+8], hi[16][2*(W+H)+8];
+    // as build_strips (round 5): per tile row (tile column for a flat direction) the tiles under the strip, the strip clipped to each tile's own box
     for(int d=0;d<16;d++){ float n=sqrtf(dx[d]*dx[d]+dy[d]*dy[d]); float ux=dx[d]/n, uy=dy[d]/n;
         for(int b=0;b<NB;b++){ float c0=(float)(b-OFF)-M, c1=(float)(b-OFF)+1.0f+M; float l=1e9f,h=-1e9f;
-            // c = -uy*x + ux*y
-            if(fabsf(uy)>=fabsf(ux)){ // steep: walk tile rows
-                for(int ty=0;ty<H/TH;ty++){ if(rmax[ty]<0) continue; float ya=ty*TH, yb=ty*TH+TH-1;
-                    // x = (ux*y - c)/uy ; over y in [ya,yb], c in [c0,c1]
+            if(fabsf(uy)>=fabsf(ux)){ for(int ty=0;ty<H/TH;ty++){ float ya=ty*TH, yb=ty*TH+TH-1;
                     float xs[4]={(ux*ya-c0)/uy,(ux*ya-c1)/uy,(ux*yb-c0)/uy,(ux*yb-c1)/uy}; float xa=xs[0],xb=xs[0]; for(int k=1;k<4;k++){ if(xs[k]<xa)xa=xs[k]; if(xs[k]>xb)xb=xs[k]; }
-                    float ia=fmaxf(xa,(float)rmin[ty]), ib=fminf(xb,(float)rmax[ty]); if(ia>ib) continue;
-                    // t = ux*x + uy*y over x in [ia,ib], y in [ya,yb]
-                    float ts[4]={ux*ia+uy*ya,ux*ia+uy*yb,ux*ib+uy*ya,ux*ib+uy*yb}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } }
-            } else { // shallow: walk tile columns;  y = (c + uy*x)/ux
-                for(int tx=0;tx<W/TW;tx++){ if(cmax[tx]<0) continue; float xa=tx*TW, xb=tx*TW+TW-1;
+                    int t0=(int)floorf((xa-0.01f)/TW), t1=(int)floorf((xb+0.01f)/TW); if(t0<0)t0=0; if(t1>=W/TW)t1=W/TW-1;
+                    for(int tx=t0;tx<=t1;tx++){ int*q=bb[ty][tx]; if(q[2]<0) continue; float y0=q[1], y1=q[3];
+                        float zs[4]={(ux*y0-c0)/uy,(ux*y0-c1)/uy,(ux*y1-c0)/uy,(ux*y1-c1)/uy}; float za=zs[0],zb=zs[0]; for(int k=1;k<4;k++){ if(zs[k]<za)za=zs[k]; if(zs[k]>zb)zb=zs[k]; }
+                        float ia=fmaxf(za-0.01f,(float)q[0]), ib=fminf(zb+0.01f,(float)q[2]); if(ia>ib) continue;
+                        float ts[4]={ux*ia+uy*y0,ux*ia+uy*y1,ux*ib+uy*y0,ux*ib+uy*y1}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } } }
+            } else { for(int tx=0;tx<W/TW;tx++){ float xa=tx*TW, xb=tx*TW+TW-1;
                     float ys[4]={(c0+uy*xa)/ux,(c1+uy*xa)/ux,(c0+uy*xb)/ux,(c1+uy*xb)/ux}; float ya=ys[0],yb=ys[0]; for(int k=1;k<4;k++){ if(ys[k]<ya)ya=ys[k]; if(ys[k]>yb)yb=ys[k]; }
-                    float ia=fmaxf(ya,(float)cmin[tx]), ib=fminf(yb,(float)cmax[tx]); if(ia>ib) continue;
-                    float ts[4]={ux*xa+uy*ia,ux*xa+uy*ib,ux*xb+uy*ia,ux*xb+uy*ib}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } }
-            }
+                    int t0=(int)floorf((ya-0.01f)/TH), t1=(int)floorf((yb+0.01f)/TH); if(t0<0)t0=0; if(t1>=H/TH)t1=H/TH-1;
+                    for(int ty=t0;ty<=t1;ty++){ int*q=bb[ty][tx]; if(q[2]<0) continue; float x0=q[0], x1=q[2];
+                        float zs[4]={(c0+uy*x0)/ux,(c1+uy*x0)/ux,(c0+uy*x1)/ux,(c1+uy*x1)/ux}; float za=zs[0],zb=zs[0]; for(int k=1;k<4;k++){ if(zs[k]<za)za=zs[k]; if(zs[k]>zb)zb=zs[k]; }
+                        float ia=fmaxf(za-0.01f,(float)q[1]), ib=fminf(zb+0.01f,(float)q[3]); if(ia>ib) continue;
+                        float ts[4]={ux*x0+uy*ia,ux*x0+uy*ib,ux*x1+uy*ia,ux*x1+uy*ib}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } } } }
             lo[d][b]=l; hi[d][b]=h; } }
     long steps_loop=0; long holes=0, pairs=0, complete=0, survive=0, falsekill=0, steps_all=0, steps_surv=0, holes_any=0;
     for(int y=by0;y<=by1;y++)for(int x=bx0;x<=bx1;x++){ if(m[y][x]) continue; holes++; int any=0;
