@@ -296,7 +296,8 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
     # ... and with the frames per launch the video loop gives the fill where it groups them (KBE_VIDEO_FILL_GROUP: the table-driven fill of a
     # dolly zoom takes four frames per launch on the bucket route -- its launches are bound by their own chains of dependent look-ups, and
     # four frames in one launch take much less than four times one): four consecutive cameras at the same eight places of the path
-    if route == 'bucket' and fill_group > 1:
+    fill_group = min(fill_group, BUCKET_GROUP_MAX)           # (the fill's launches take up to four frames whatever the scatter's take)
+    if fill_group > 1:
         gout = torch.empty(fill_group, H, W, 3, dtype=torch.uint8, device=oc['tensorInpaPoints'].device)
         gfills = []
         for i in range(8):
@@ -304,8 +305,12 @@ def time_kernels(oc, cams, route, reps=40, fill_rect=None, group_frames=GROUP_FR
             group = cams[at:at + fill_group]
             if len(group) < fill_group:
                 break
-            t_all = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7 | fill_flags, fill_rect=fill_rect))
-            t_scatter = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7, fill_rect=empty))      # the fill launch with nothing to fill: its reset
+            if route == 'fused':
+                t_all = timed(lambda: K.render_frame_group_fused(state, group, Bl, gout, stages=6 | fill_flags, fill_rect=fill_rect))
+                t_scatter = timed(lambda: K.render_frame_group_fused(state, group, Bl, gout, stages=2))
+            else:
+                t_all = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7 | fill_flags, fill_rect=fill_rect))
+                t_scatter = timed(lambda: K.render_frame_group(state, group, Bl, gout, stages=7, fill_rect=empty))  # the fill launch with nothing to fill: its reset
             gfills.append(max(t_all - t_scatter, 0.0))
         if gfills:
             out['fill_group_along_path'] = sum(gfills) / len(gfills)

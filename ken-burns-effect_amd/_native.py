@@ -508,17 +508,21 @@ class HipKernels:
         four lanes (the lanes fill the same gaps), and where the PCIe link binds (frames delivered to host memory: 59 us
         per frame whatever n) n = 4 leaves the most of the chip idle.  Small frames are bound by their launches: 4 up to
         576^2.  KBE_FILL_GROUP overrides.
-        The route: the state's (prepare_cloud), except that a camera that zooms out takes the bucket route (the density of
-        the points on the shrinking image grows along the video: 97 against 151 us per frame)."""
+        The route: the state's (prepare_cloud)."""
         W, H = state['W'], state['H']
         mode = os.environ.get('KBE_FILL_DIST', 'auto')
         zooms_out = len(cameras) > 0 and min(float(c[0]) for c in cameras) < 0.9 * state['cloud_focal']
         flags = int(state['N'] <= W * H and zooms_out) if mode == 'auto' else int(mode != '0')
-        fused = bool(state.get('fused')) and (os.environ.get('KBE_FUSED') == '1' or not zooms_out)
+        # (until round 5 a zoom-out took the bucket route: the density of the points on the shrinking image grows along the video, the fused
+        # route's candidate lists of 512 sub-blocks overflowed and it lost 147 : 97 us per frame.  With lists of 2048 it wins: 82 against
+        # 90 us per 1024^2 dolly frame left in HBM, 21.8 against 23.5 at 512^2 -- profiles/r05_dolly_routes.txt.  KBE_FUSED=0 still forces the other.)
+        fused = bool(state.get('fused'))
         if os.environ.get('KBE_FILL_GROUP'):
             group = max(1, min(12 if fused else 4, int(os.environ['KBE_FILL_GROUP'])))
         elif flags:
-            group = DEFAULT_FILL_GROUP
+            # the table-driven fill: launches bound by their own chains of look-ups -- four frames per fill launch; the fused scatter in
+            # front of them takes eight (measured, us per dolly frame left in HBM / k frames/s delivered with 4 / 8 / 12: 82.1 / 80.4 / 79.7, 9.6 / 9.9 / 9.8)
+            group = 8 if fused else DEFAULT_FILL_GROUP
         elif fused:
             # eight where the link binds (the rendering then only has to stay out of the transfers' way: the fewer, larger
             # launches the better), four for frames left in HBM on four lanes -- since a group's tile launch also makes the next

@@ -911,7 +911,7 @@ def test_scratch_budget_falls_back_to_fewer_frames_per_launch_and_hint_replaces_
     state = common._prepared_cloud(K, oc)
     want = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
     full_sets = state['video_sets']
-    assert full_sets == 16                                  # four frames per launch on four lanes
+    assert full_sets == 32                                  # eight frames per scatter launch on four lanes (a zoom-out that fills with the tables)
     stride = int(K.lib.kbe_video_scratch_stride(size[1], size[0], state['N']))
     monkeypatch.setenv('KBE_SCRATCH_BUDGET_MB', str(9 * stride / 1e6))            # room for nine sets: two frames per launch
     got = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()

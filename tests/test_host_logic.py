@@ -275,7 +275,7 @@ def test_lanes_for_delivery_follow_the_measured_render_time():
 
 def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     """_native.video_launch_shape: the table-driven fill for clouds without appended points seen by a camera that zooms out;
-    frames per launch by what binds the video; the scatter route (a zoom-out piles the points up: the bucket route)."""
+    frames per launch by what binds the video; the scatter route is the cloud's (until round 5 a zoom-out took the bucket route)."""
     from ken_burns_effect_amd import _native
     for k in ('KBE_FILL_DIST', 'KBE_FILL_GROUP', 'KBE_FUSED'):
         monkeypatch.delenv(k, raising=False)
@@ -285,13 +285,13 @@ def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     zoom = [(512.0 - 40.0 * i, (0.0, 0.0, -20.0 * i)) for i in range(8)]
     inpainted = {'W': 1024, 'H': 1024, 'N': 1137109, 'cloud_focal': 512.0, 'fused': True}
     raw = {'W': 1024, 'H': 1024, 'N': 1048576, 'cloud_focal': 512.0, 'fused': True}
-    # the fused route: four frames per launch left in HBM, twelve where the link binds (KBE_VIDEO_GROUP: bits 5-8); a zoom-out takes
-    # the bucket route
+    # the fused route: four frames per launch left in HBM, twelve where the link binds (KBE_VIDEO_GROUP: bits 5-8); a zoom-out of a
+    # cloud without appended points fills with the tables, eight frames per scatter launch
     assert shape(inpainted, still) == (3 << 1, 4, True) and shape(inpainted, still, to_host=True) == (11 << 5, 12, True)
-    assert shape(inpainted, zoom) == (0, 1, False)
+    assert shape(inpainted, zoom) == (3 << 1, 4, True)
     assert shape(raw, still) == (3 << 1, 4, True)
-    assert shape(raw, zoom) == (1 | (3 << 1), 4, False)
-    assert shape(raw, zoom, batch=8) == (1, 1, False), 'the staged ring renders one frame per launch'
+    assert shape(raw, zoom) == (1 | (7 << 5), 8, True)
+    assert shape(raw, zoom, batch=8) == (1, 1, True), 'the staged ring renders one frame per launch'
     assert shape({'W': 512, 'H': 512, 'N': 300000, 'cloud_focal': 512.0, 'fused': True}, still) == (3 << 1, 4, True)
     # the bucket route (a cloud denser than the raster: prepare_cloud leaves `fused` off)
     dense = lambda size, n: {'W': size, 'H': size, 'N': n, 'cloud_focal': 512.0, 'fused': False}    # noqa: E731
@@ -301,6 +301,5 @@ def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     monkeypatch.setenv('KBE_FILL_GROUP', '3')
     assert shape(inpainted, still) == (2 << 1, 3, True)
     monkeypatch.setenv('KBE_FILL_DIST', '0')
-    assert shape(raw, zoom) == (2 << 1, 3, False)
-    monkeypatch.setenv('KBE_FUSED', '1')
-    assert shape(raw, zoom) == (2 << 1, 3, True), 'KBE_FUSED=1 forces the route'
+    assert shape(raw, zoom) == (2 << 1, 3, True)
+    assert shape(dict(raw, fused=False), zoom) == (2 << 1, 3, False), 'the route is the state\'s (prepare_cloud: KBE_FUSED=0 / 1 force it there)'
