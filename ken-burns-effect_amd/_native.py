@@ -330,7 +330,7 @@ class HipKernels:
         state['cloud_focal'] = float(focal) if focal else 512.0
         # the depth of the nearest point (the reference's objectDepthrange[0], common.py:88, when the caller has it; else found
         # on first need): decides how many consecutive frames of a video share candidate lists (include/kbe.h: near_depth)
-        state['near_depth'] = None if near_depth is None else max(0.0, float(near_depth))
+        state['near_depth'] = None if near_depth is None else (float(near_depth) if 0.0 < float(near_depth) < 1.0e30 else 0.0)     # (nan, inf, <= 0: unknown)
         if state['fused']:
             self._pack(state)
         return state
@@ -345,7 +345,8 @@ class HipKernels:
         if state.get('near_depth') is None:
             z = state['points'][2]
             z = z[z > 0]
-            state['near_depth'] = float(z.min()) if z.numel() else 0.0
+            near = float(z.min()) if z.numel() else 0.0
+            state['near_depth'] = near if 0.0 < near < 1.0e30 else 0.0
         return state['near_depth']
 
     def _pack(self, state):
