@@ -754,6 +754,9 @@ __global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, int
     }
 }
 constexpr int SDMA_MAX_POLLS = 2000000;
+#ifndef KBE_SDMA_TWO_ENGINES
+#define KBE_SDMA_TWO_ENGINES 0      // (1: consecutive groups alternate between two engines -- measured slower end to end, see sdma_open)
+#endif
 
 struct SdmaPair { hsa_signal_t dep, fin; };
 struct SdmaGeneration { hipEvent_t done; std::vector<SdmaPair> pairs; };
@@ -768,7 +771,8 @@ static volatile int64_t* signal_value(hsa_signal_t sg) { return &((amd_signal_t*
 struct SdmaCall {                               // one kbe_render_video call's use of the engine
     bool ok = false;
     hsa_agent_t gpu = {}, cpu = {};
-    hsa_amd_sdma_engine_id_t engine = HSA_AMD_SDMA_ENGINE_0;
+    hsa_amd_sdma_engine_id_t engine[2] = { HSA_AMD_SDMA_ENGINE_0, HSA_AMD_SDMA_ENGINE_0 };      // consecutive groups alternate between two engines
+    int sent = 0;
     std::vector<SdmaPair> used;
 };
 // which agents own the two buffers, and an engine that copies from the one to the other; false: no SDMA hand-off (the caller
@@ -790,7 +794,14 @@ static bool sdma_open(SdmaCall& c, const void* device_buffer, const void* host_b
     if (hsa_amd_memory_copy_engine_status(hinfo.agentOwner, dinfo.agentOwner, &avail) != HSA_STATUS_SUCCESS || !avail) return false;
     if (hsa_amd_memory_get_preferred_copy_engine(hinfo.agentOwner, dinfo.agentOwner, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
     const uint32_t pick = (preferred & avail) ? (preferred & avail) : avail;
-    c.engine = (hsa_amd_sdma_engine_id_t) (pick & (~pick + 1u));            // its lowest engine
+    // its lowest engine.  (An engine takes ~9.4 us from the end of one copy to the start of the next even when that one has long been
+    // released -- the device-side timeline of a 20-frame video, tools/sdma_timeline.py: five such gaps in 1.35 ms.  With the groups
+    // alternating between TWO engines, KBE_SDMA_TWO_ENGINES, the copies overlap and the last one ends 60 us earlier on the device --
+    // and the video is delivered SLOWER: 13.9 instead of 14.6 k frames/s for 20 frames, 16.15 instead of 16.6 k for 75: the host sees
+    // the end ~170 us after the device instead of ~30.  One engine it is.)
+    const uint32_t first = pick & (~pick + 1u), rest = pick & ~first, second = rest ? (rest & (~rest + 1u)) : first;
+    c.engine[0] = (hsa_amd_sdma_engine_id_t) first;
+    c.engine[1] = (hsa_amd_sdma_engine_id_t) (KBE_SDMA_TWO_ENGINES ? second : first);
     c.gpu = dinfo.agentOwner; c.cpu = hinfo.agentOwner;
     // the signals of calls that have run to their end are idle again
     for (size_t g = 0; g < pool.running.size(); ) {
@@ -1561,7 +1572,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 if (sdma.ok) {
                     SdmaPair p;
                     if (sdma_pair(sdma, p) && hsa_amd_memory_async_copy_on_engine(host_out + (size_t) i0 * fb, sdma.cpu, base, sdma.gpu, (size_t) nb * fb, 1, &p.dep, p.fin,
-                                                                                  sdma.engine, true) == HSA_STATUS_SUCCESS) {
+                                                                                  sdma.engine[sdma.sent++ & 1], true) == HSA_STATUS_SUCCESS) {
                         hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], signal_value(p.dep));
                         lane_fin[l] = signal_value(p.fin);
                         sent = true;
