@@ -1507,9 +1507,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             const int G = -batch;
             // KBE_VIDEO_SDMA: the groups leave through an SDMA engine (above); whatever keeps HSA from it falls back to the runtime's
             // transfers, group by group
-            if ((flags & KBE_VIDEO_SDMA) && n_groups > 0) (void) sdma_open(sdma, stage, host_out);
+            // (opened behind the first group's launches, below: the queries cost the host 10-25 us, which would otherwise sit in front of
+            // the video's first kernel)
+            bool sdma_asked = !(flags & KBE_VIDEO_SDMA);
             volatile int64_t* lane_fin[KBE_MAX_LANES] = {};         // the completion signal of the group the lane's slots hold
-            if (sdma.ok) ctl = nullptr;                             // the engine takes the copies in order: no turns
             // how long a group may wait for its turn: the transfers of every other lane in front of it (a poll is ~1 us; the
             // link moves ~50 bytes per ns), three times over -- a fixed 4 ms was no margin for 16 frames of 2048^2 (3.8 ms each)
             const double group_us = (double) G * (double) fb / 50.0e3;
@@ -1561,6 +1562,10 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #if defined(KBE_VIDEO_GPU_TRACE)
                 (void) hipEventRecord(ev_ready[g], ls[l]);
 #endif
+                if (!sdma_asked) {
+                    sdma_asked = true;
+                    if (sdma_open(sdma, stage, host_out)) ctl = nullptr;        // the engine takes the copies in order: no turns
+                }
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls);
 #if defined(KBE_VIDEO_GPU_TRACE)
                 (void) hipEventRecord(ev_gate[g], ls[l]);
