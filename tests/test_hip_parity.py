@@ -803,6 +803,31 @@ def test_cloud_of_nine_points_per_pixel_on_all_three_routes_against_the_oracle(K
             frames_close(other[i], ref, 'KBE_FUSED=%s, frame %d' % (route, i))
 
 
+@pytest.mark.parametrize('steps', [20, 75, 400])
+def test_video_on_a_ken_burns_path_with_shared_lists_equals_the_video_with_lists_per_frame(K, monkeypatch, steps):
+    """The candidate lists of consecutive frames are shared in sub-groups whose size follows the nearest point's motion between a
+    sub-group's first and last camera (kbe_fused.hip share_plan; near_depth = objectDepthrange[0]): on the product's own camera path --
+    a parabola in shift space -- with 20 steps (7 px per step at 512^2 scaled: lists per frame), 75 (sub-groups) and 400 (whole
+    launches share), one lane so that launches of twelve follow one another: the same frames as with KBE_SHARE_LISTS=0 (near_depth 0:
+    every frame its own lists), and as the oracle's for a sample of them."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_LANES', '1')
+    monkeypatch.setenv('KBE_FILL_GROUP', '12')
+    size = 384
+    settings, oc = _scene((size, size), 8)
+    n = 38
+    start = 0.3
+    cams = common.frame_cameras(dict(settings, dblSteps=[start + i / (steps - 1.0) for i in range(n) if start + i / (steps - 1.0) <= 1.0]), oc)
+    assert len(cams) >= 13
+    shared = c(common.render_frames(cams, oc, None, keep_on_device=True))
+    assert common._prepared_cloud(K, oc)['near_depth'] == oc['objectDepthrange'][0] > 0
+    monkeypatch.setenv('KBE_SHARE_LISTS', '0')
+    own = c(common.render_frames(cams, oc, None, keep_on_device=True))
+    for i in range(len(cams)):
+        frames_close(shared[i], own[i], '%d-step path, frame %d' % (steps, i))
+    assert shared.any()
+
+
 @pytest.mark.parametrize('kind', ['rough', 'near_plane', 'curved'])
 def test_groups_sharing_their_candidate_lists_on_clouds_with_large_parallax(K, kind):
     """Consecutive frames a tile launch places ahead share candidate lists in sub-groups (same focal length, shifts only differ:
