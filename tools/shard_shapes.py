@@ -3,8 +3,9 @@
 own PCIe link and the whole cloud, so a rank's share rendered here alone is what that rank would do on a node.)
 
 For a 128-frame (BASELINE configs[2]) and a 75-frame (the product's) video of the bench cloud, rank r's share as
-  round-robin   cams[r::8]                     (sharding.shard_steps until round 4)
-  block         a contiguous run of n / 8 frames     (sharding.shard_indices, the default since round 5)
+  round-robin   cams[r::8]                           (the default, before and after this measurement)
+  block         a contiguous run of n / 8 frames
+  dealt<k>      runs of k consecutive frames dealt to the ranks in turn     (sharding.shard_indices)
 delivered to pinned host memory and left in HBM, against the whole video on one GPU.  A launch group of consecutive cameras shares
 its candidate lists (kbe_fused.hip: ShareMode): cameras 8 steps apart make them as wide as they get.  Prints one line per case:
 frames, us per frame (median of PASSES passes), frames/s."""
