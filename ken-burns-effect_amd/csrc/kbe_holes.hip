@@ -656,7 +656,8 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
 #if defined(KBE_FRAME_STATS)
             int iters = 0;
 #endif
-            float ux = 0.0f, uy = 0.0f, bound = 0.0f, inv_umax = 1.0f;
+            float ux = 0.0f, uy = 0.0f, inv_umax = 1.0f;
+            int k_dead = FILL_MAX_STEPS + 1;           // the step count from which the end is past every valid pixel of its strip (below)
             Axis X = { 0, 0, -1 }, Y = { 0, 0, -1 };
             // the two ends of a direction look at each other
             const auto look = [&]() {
@@ -698,10 +699,9 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                         }
                         if ((rx | ry) == 0) {
                             ix = axis_pixel(X); iy = axis_pixel(Y);
-                            const float t = ux * (float) ix + uy * (float) iy;
                             int m = 0;
                             if (!(((unsigned) ix < (unsigned) W) & ((unsigned) iy < (unsigned) H))) st = END_DEAD;       // :880-885 / :891-896
-                            else if (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN) st = END_DEAD;         // past every valid pixel of its strip
+                            else if (k >= k_dead) st = END_DEAD;                                                        // past every valid pixel of its strip
                             else {
                                 const int ci = (iy >> 3) * cw + (ix >> 3);
                                 const int c = block_distance(ci);
@@ -742,8 +742,7 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                     fy = is_b ? fy + uy : fy - uy;
                     bpx[j] = (int) roundf(fx); bpy[j] = (int) roundf(fy);
                     const bool inb = ((unsigned) bpx[j] < (unsigned) W) & ((unsigned) bpy[j] < (unsigned) H);
-                    const float t = ux * (float) bpx[j] + uy * (float) bpy[j];
-                    bstop[j] = !inb || (is_b ? bound < t - STRIP_MARGIN : bound > t + STRIP_MARGIN);
+                    bstop[j] = !inb || (k - rx + j + 1 >= k_dead);
                     bdn[j] = dist[inb ? (uint32_t) bpy[j] * (uint32_t) W + (uint32_t) bpx[j] : 0u];
                 }
                 KBE_FILL_STAT(2, B);
@@ -799,10 +798,18 @@ __device__ __forceinline__ void fill_tables_body(const int* __restrict__ holes, 
                             iy = qpx / W; ix = qpx - iy * W;
                             ux = s_dir[0][d]; uy = s_dir[1][d];
                             inv_umax = 0.999999f / fmaxf(fabsf(ux), fabsf(uy));
-                            bound = is_b ? INFINITY : -INFINITY;
+                            // The end is past every valid pixel of its strip once its pixel's coordinate along the direction, t = u . q, is
+                            // more than STRIP_MARGIN beyond the strip's bound.  The pixel k steps on lies within 0.75 of the hole's t -/+ k
+                            // (a unit direction; rounding per axis, < 0.03 of drift), so from k_dead = ceil(|bound - t| + 2.8) steps on that
+                            // holds for sure -- one integer comparison per landing instead of the coordinate's two conversions, a
+                            // multiply-add and a comparison (the ray may die two or three steps later than with the coordinate itself: it
+                            // meets nothing there, that is what the bound says)
+                            k_dead = FILL_MAX_STEPS + 1;
                             if (strips) {
                                 const float2 lh = strips[(size_t) d * bins + ((int) floorf(ux * (float) iy - uy * (float) ix) + s_off[d])];
-                                bound = is_b ? lh.y : lh.x;
+                                const float t_hole = ux * (float) ix + uy * (float) iy;
+                                const float room = is_b ? lh.y - t_hole : t_hole - lh.x;            // -inf: nothing on that side at all
+                                k_dead = room > (float) FILL_MAX_STEPS ? FILL_MAX_STEPS + 1 : (int) ceilf(fmaxf(room, -2.0f) + STRIP_MARGIN + 1.8f);
                             }
                             X = axis_enter((float) ix, ux, !is_b);
                             Y = axis_enter((float) iy, uy, !is_b);
