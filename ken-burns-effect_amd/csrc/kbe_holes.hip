@@ -194,7 +194,7 @@ static_assert(DT_W == 64, "the halo is one 32-pixel word on each side");
 // rounded per axis; the fp32 sums drift by < 0.03 over 1000 steps), so the only valid pixels it can ever meet lie in the
 // strip of lines c in [b - 1, b + 2), b = floor(c(p)), c(q) = n . q the coordinate across the direction.  Per direction
 // and b, (lo, hi) bound the coordinate t(q) = u . q along the direction over every valid pixel of that strip -- or rather
-// over a superset of them: the boxes of the tiles the strip crosses (build_strips).  The end walking towards -u meets nothing once lo > t + 1, the end towards +u once hi < t - 1: the
+// over exactly those (build_strips: the tiles' boxes first, then the bitmask's rows at either end).  The end walking towards -u meets nothing once lo > t + 1, the end towards +u once hi < t - 1: the
 // direction is skipped (common.py:880-885, 891-896) without walking to the image border.  A zoomed-out frame is mostly
 // border around a convex patch of valid pixels; outside a convex patch NO direction has valid pixels on both sides.
 // Measured on the last frame of the dolly bench (266 k holes inside the box of valid pixels): 1.7 of a hole's 16 directions
@@ -208,37 +208,45 @@ __device__ __forceinline__ int strip_offset(float ux, float uy, int W, int H)
     return (int) ceilf(fmaxf(0.0f, uy * (float) W) + fmaxf(0.0f, -ux * (float) H)) + 2;
 }
 
-__device__ void build_strips(const int4* __restrict__ bbox, int tiles_x, int tiles_y, int W, int H, float ux, float uy, int first_bin,
-                             float2* __restrict__ out)
+__device__ void build_strips(const int4* __restrict__ bbox, const uint32_t* __restrict__ mask, int tiles_x, int tiles_y, int W, int H, float ux, float uy,
+                             int first_bin, float2* __restrict__ out)
 {
     const int b = first_bin + (int) threadIdx.x;
     if (b >= strip_bins(W, H)) return;
     const float c0 = (float) (b - strip_offset(ux, uy, W, H)) - STRIP_MARGIN, c1 = c0 + 1.0f + 2.0f * STRIP_MARGIN;
-    // The superset the bounds are taken over (round 5): the BOXES OF THE TILES the strip crosses -- per tile row (tile column for
-    // a flat direction) the one to three tiles under the strip, each with the box of its own valid pixels (the tile launch's
-    // bbox table), the strip clipped to the box's rows and columns.  Until round 5: the x-extent of each whole tile ROW (the
-    // y-extent of each tile column) -- 4.46 of a late dolly frame's 16 directions per hole passed the test where 1.73 complete;
-    // with the tiles' own boxes 2.47 pass (tools/strip_proto.c on the oracle's masks; row and column extents intersected: 3.19;
-    // exact per-line extents: 1.90) -- and the directions that pass without completing are the expensive ones: they walk to the
-    // end of their strip.
-    float lo = INFINITY, hi = -INFINITY;
+    // Per tile row (tile column for a flat direction) the one to three tiles under the strip, each with the box of its own valid pixels
+    // (the tile launch's bbox table), the strip clipped to the box; then the tile whose box reaches farthest towards either end of the
+    // strip is looked at ROW BY ROW in the validity bitmask: its valid pixels of the strip give that end's bound, unless another tile's
+    // box reaches farther than they do (then that box's reach does: still a superset).  Until round 5: the x-extent of each whole tile
+    // ROW (the y-extent of each tile column) -- 4.46 of a late dolly frame's 16 directions per hole passed the test where 1.73
+    // complete; the tiles' own boxes alone: 2.47; with the one tile looked at: 2.01; every tile looked at until nothing can improve
+    // (exact): 1.91 -- but that walk's chain of dependent loads made k_hole_dist slower than the fill gained (tools/strip_proto.c on
+    // the oracle's masks, the restatement of this function).  The directions that pass without completing are the expensive ones: they
+    // walk to the end of their strip.
     const bool steep = fabsf(uy) >= fabsf(ux);                  // the line crosses every row once: walk the tile rows
     const int n = steep ? tiles_y : tiles_x, m = steep ? tiles_x : tiles_y;
     const float ua = steep ? ux : uy, ub = steep ? uy : ux;     // a = the coordinate along a row (column), b = across
     const float inv = 1.0f / ub;
     const int sa = steep ? TW : TH, sb = steep ? TH : TW;
+    const int wpr = (W + 31) >> 5;
+    const bool rows_cross = fabsf(uy) >= 1.0e-6f;               // else: a horizontal direction, a strip is whole rows
+    const float inv_uy = rows_cross ? 1.0f / uy : 0.0f;
+    static_assert(TW == 32 && TH == 16, "a tile row is one word of the validity bitmask, a tile sixteen of them");
     // the strip's extent along a over the rows (columns) b0 .. b1 -- steep: c = -uy x + ux y => x = (ux y - c) / uy; flat: y = (c + uy x) / ux
     const auto along = [&](float b0, float b1, float& a0, float& a1) {
         const float v0 = steep ? (ua * b0 - c0) * inv : (c0 + ua * b0) * inv, v1 = steep ? (ua * b0 - c1) * inv : (c1 + ua * b0) * inv;
         const float v2 = steep ? (ua * b1 - c0) * inv : (c0 + ua * b1) * inv, v3 = steep ? (ua * b1 - c1) * inv : (c1 + ua * b1) * inv;
         a0 = fminf(fminf(v0, v1), fminf(v2, v3)) - 0.01f; a1 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) + 0.01f;
     };
+    float lo1 = INFINITY, lo2 = INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;        // the farthest and the second farthest reach of a box, either end
+    int lo_tile = -1, hi_tile = -1;
     for (int i = 0; i < n; i++) {
         float a0, a1;
         along((float) (i * sb), (float) (i * sb + sb - 1), a0, a1);
         const int j0 = max((int) floorf(a0 / (float) sa), 0), j1 = min((int) floorf(a1 / (float) sa), m - 1);
         for (int j = j0; j <= j1; j++) {
-            const int4 bb = bbox[steep ? i * tiles_x + j : j * tiles_x + i];
+            const int tile = steep ? i * tiles_x + j : j * tiles_x + i;
+            const int4 bb = bbox[tile];
             if (bb.z < bb.x) continue;                          // a tile without a valid pixel
             const float q0 = (float) (steep ? bb.y : bb.x), q1 = (float) (steep ? bb.w : bb.z);        // the box across ...
             float p0, p1;
@@ -247,10 +255,43 @@ __device__ void build_strips(const int4* __restrict__ bbox, int tiles_x, int til
             if (p0 > p1) continue;
             // t = ux x + uy y = ua a + ub b over [p0, p1] x [q0, q1]
             const float t0 = ua * p0 + ub * q0, t1 = ua * p0 + ub * q1, t2 = ua * p1 + ub * q0, t3 = ua * p1 + ub * q1;
-            lo = fminf(lo, fminf(fminf(t0, t1), fminf(t2, t3)));
-            hi = fmaxf(hi, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+            const float tmin = fminf(fminf(t0, t1), fminf(t2, t3)), tmax = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+            if (tmin < lo1) { lo2 = lo1; lo1 = tmin; lo_tile = tile; } else lo2 = fminf(lo2, tmin);
+            if (tmax > hi1) { hi2 = hi1; hi1 = tmax; hi_tile = tile; } else hi2 = fmaxf(hi2, tmax);
         }
     }
+    // the valid pixels of the strip in one tile, row by row in the bitmask (the sixteen words requested together): the smallest
+    // (`low`) or the largest t among them; none: +inf / -inf
+    const auto in_tile = [&](int tile, bool low) -> float {
+        float best = low ? INFINITY : -INFINITY;
+        if (tile < 0) return best;
+        const int4 bb = bbox[tile];
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x, x0 = tx * TW;
+        uint32_t words[TH];
+#pragma unroll
+        for (int r = 0; r < TH; r++) words[r] = mask[(size_t) min(bb.y + r, bb.w) * wpr + tx];
+#pragma unroll
+        for (int r = 0; r < TH; r++) {
+            const int y = bb.y + r;
+            if (y > bb.w) continue;
+            float xa = -1.0e9f, xb = 1.0e9f;
+            if (rows_cross) {
+                const float e0 = (ux * (float) y - c0) * inv_uy, e1 = (ux * (float) y - c1) * inv_uy;
+                xa = fminf(e0, e1) - 0.01f; xb = fmaxf(e0, e1) + 0.01f;
+            } else {
+                const float c = ux * (float) y;
+                if (c < c0 - 0.01f || c > c1 + 0.01f) continue;
+            }
+            const int xl = (int) ceilf(fmaxf(xa, (float) bb.x)), xr = (int) floorf(fminf(xb, (float) bb.z));
+            if (xl > xr) continue;
+            const uint32_t w = words[r] & (0xFFFFFFFFu << (xl - x0)) & (0xFFFFFFFFu >> (31 - (xr - x0)));
+            if (!w) continue;
+            const float ta = ux * (float) (x0 + __builtin_ctz(w)) + uy * (float) y, tb = ux * (float) (x0 + 31 - __builtin_clz(w)) + uy * (float) y;
+            best = low ? fminf(best, fminf(ta, tb)) : fmaxf(best, fmaxf(ta, tb));
+        }
+        return best;
+    };
+    const float lo = fminf(in_tile(lo_tile, true), lo2), hi = fmaxf(in_tile(hi_tile, false), hi2);
     out[b] = make_float2(lo, hi);
 }
 
@@ -337,7 +378,7 @@ __device__ __forceinline__ void hole_dist_body(const uint32_t* __restrict__ mask
         const int bins = strip_bins(W, H), per_dir = (bins + 255) / 256;
         if (si < 16 * per_dir) {
             const int d = si / per_dir;
-            if (strips) build_strips(bbox, tiles_x, tiles_y, W, H, dirs.x[d], dirs.y[d], (si - d * per_dir) * 256, strips + (size_t) d * bins);
+            if (strips) build_strips(bbox, mask, tiles_x, tiles_y, W, H, dirs.x[d], dirs.y[d], (si - d * per_dir) * 256, strips + (size_t) d * bins);
             return;
         }
         si -= 16 * per_dir;

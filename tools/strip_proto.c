@@ -23,24 +23,44 @@ int main(int argc,char**argv){
         if(x<bx0)bx0=x; if(x>bx1)bx1=x; if(y<by0)by0=y; if(y>by1)by1=y; }
     const int NB=2*(W+H)+8, OFF=W+H+4; const float M=1.0f;
     static float lo[16][2*(W+H)+8], hi[16][2*(W+H)+8];
-    // as build_strips (round 5): per tile row (tile column for a flat direction) the tiles under the strip, the strip clipped to each tile's own box
+    // as build_strips (round 5): per tile row (tile column for a flat direction) the tiles under the strip, the strip clipped to each tile's own
+    // box; the tile whose box reaches farthest towards either end of the strip is then looked at row by row in the validity bitmask itself: its
+    // valid pixels of the strip give that end's bound, unless another tile's box reaches farther than they do (then that box's reach does)
+    static uint32_t bits[H][W/32];
+    for(int y=0;y<H;y++)for(int x=0;x<W;x++) if(m[y][x]) bits[y][x>>5]|=1u<<(x&31);
+    long row_tests=0, box_tests=0;
     for(int d=0;d<16;d++){ float n=sqrtf(dx[d]*dx[d]+dy[d]*dy[d]); float ux=dx[d]/n, uy=dy[d]/n;
+        const int steep=fabsf(uy)>=fabsf(ux); const int nn=steep?H/TH:W/TW, mm=steep?W/TW:H/TH;
+        const float ua=steep?ux:uy, ub=steep?uy:ux, inv=1.0f/ub; const int sa=steep?TW:TH, sb=steep?TH:TW;
         for(int b=0;b<NB;b++){ float c0=(float)(b-OFF)-M, c1=(float)(b-OFF)+1.0f+M; float l=1e9f,h=-1e9f;
-            if(fabsf(uy)>=fabsf(ux)){ for(int ty=0;ty<H/TH;ty++){ float ya=ty*TH, yb=ty*TH+TH-1;
-                    float xs[4]={(ux*ya-c0)/uy,(ux*ya-c1)/uy,(ux*yb-c0)/uy,(ux*yb-c1)/uy}; float xa=xs[0],xb=xs[0]; for(int k=1;k<4;k++){ if(xs[k]<xa)xa=xs[k]; if(xs[k]>xb)xb=xs[k]; }
-                    int t0=(int)floorf((xa-0.01f)/TW), t1=(int)floorf((xb+0.01f)/TW); if(t0<0)t0=0; if(t1>=W/TW)t1=W/TW-1;
-                    for(int tx=t0;tx<=t1;tx++){ int*q=bb[ty][tx]; if(q[2]<0) continue; float y0=q[1], y1=q[3];
-                        float zs[4]={(ux*y0-c0)/uy,(ux*y0-c1)/uy,(ux*y1-c0)/uy,(ux*y1-c1)/uy}; float za=zs[0],zb=zs[0]; for(int k=1;k<4;k++){ if(zs[k]<za)za=zs[k]; if(zs[k]>zb)zb=zs[k]; }
-                        float ia=fmaxf(za-0.01f,(float)q[0]), ib=fminf(zb+0.01f,(float)q[2]); if(ia>ib) continue;
-                        float ts[4]={ux*ia+uy*y0,ux*ia+uy*y1,ux*ib+uy*y0,ux*ib+uy*y1}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } } }
-            } else { for(int tx=0;tx<W/TW;tx++){ float xa=tx*TW, xb=tx*TW+TW-1;
-                    float ys[4]={(c0+uy*xa)/ux,(c1+uy*xa)/ux,(c0+uy*xb)/ux,(c1+uy*xb)/ux}; float ya=ys[0],yb=ys[0]; for(int k=1;k<4;k++){ if(ys[k]<ya)ya=ys[k]; if(ys[k]>yb)yb=ys[k]; }
-                    int t0=(int)floorf((ya-0.01f)/TH), t1=(int)floorf((yb+0.01f)/TH); if(t0<0)t0=0; if(t1>=H/TH)t1=H/TH-1;
-                    for(int ty=t0;ty<=t1;ty++){ int*q=bb[ty][tx]; if(q[2]<0) continue; float x0=q[0], x1=q[2];
-                        float zs[4]={(c0+uy*x0)/ux,(c1+uy*x0)/ux,(c0+uy*x1)/ux,(c1+uy*x1)/ux}; float za=zs[0],zb=zs[0]; for(int k=1;k<4;k++){ if(zs[k]<za)za=zs[k]; if(zs[k]>zb)zb=zs[k]; }
-                        float ia=fmaxf(za-0.01f,(float)q[1]), ib=fminf(zb+0.01f,(float)q[3]); if(ia>ib) continue;
-                        float ts[4]={ux*x0+uy*ia,ux*x0+uy*ib,ux*x1+uy*ia,ux*x1+uy*ib}; for(int k=0;k<4;k++){ if(ts[k]<l)l=ts[k]; if(ts[k]>h)h=ts[k]; } } } }
+            for(int pass=0;pass<2;pass++){
+                float best=pass==0?1e9f:-1e9f, second=best; int bty=-1,btx=-1;
+                for(int i=0;i<nn;i++){ const float b0=i*sb, b1=i*sb+sb-1;
+                    float v[4]={steep?(ua*b0-c0)*inv:(c0+ua*b0)*inv, steep?(ua*b0-c1)*inv:(c1+ua*b0)*inv, steep?(ua*b1-c0)*inv:(c0+ua*b1)*inv, steep?(ua*b1-c1)*inv:(c1+ua*b1)*inv};
+                    float a0=v[0],a1=v[0]; for(int k=1;k<4;k++){ if(v[k]<a0)a0=v[k]; if(v[k]>a1)a1=v[k]; } a0-=0.01f; a1+=0.01f;
+                    int j0=(int)floorf(a0/sa), j1=(int)floorf(a1/sa); if(j0<0)j0=0; if(j1>=mm)j1=mm-1;
+                    for(int j=j0;j<=j1;j++){ const int ty=steep?i:j, tx=steep?j:i; int*q=bb[ty][tx]; box_tests++; if(q[2]<0) continue;
+                        const float q0=steep?q[1]:q[0], q1=steep?q[3]:q[2];
+                        float z[4]={steep?(ua*q0-c0)*inv:(c0+ua*q0)*inv, steep?(ua*q0-c1)*inv:(c1+ua*q0)*inv, steep?(ua*q1-c0)*inv:(c0+ua*q1)*inv, steep?(ua*q1-c1)*inv:(c1+ua*q1)*inv};
+                        float p0=z[0],p1=z[0]; for(int k=1;k<4;k++){ if(z[k]<p0)p0=z[k]; if(z[k]>p1)p1=z[k]; } p0-=0.01f; p1+=0.01f;
+                        p0=fmaxf(p0,(float)(steep?q[0]:q[1])); p1=fminf(p1,(float)(steep?q[2]:q[3])); if(p0>p1) continue;
+                        const float t4[4]={ua*p0+ub*q0,ua*p0+ub*q1,ua*p1+ub*q0,ua*p1+ub*q1}; float tmin=t4[0],tmax=t4[0]; for(int k=1;k<4;k++){ if(t4[k]<tmin)tmin=t4[k]; if(t4[k]>tmax)tmax=t4[k]; }
+                        const float key=pass==0?tmin:tmax;
+                        if(pass==0 ? key<best : key>best){ second=best; best=key; bty=ty; btx=tx; } else if(pass==0 ? key<second : key>second) second=key; } }
+                float exact=pass==0?1e9f:-1e9f;
+                if(bty>=0){ int*q=bb[bty][btx]; const int tx=btx;
+                    for(int y=q[1];y<=q[3];y++){ row_tests++;
+                        float xa,xb;
+                        if(fabsf(uy)>=1e-6f){ const float e0=(ux*y-c0)/uy, e1=(ux*y-c1)/uy; xa=fminf(e0,e1)-0.01f; xb=fmaxf(e0,e1)+0.01f; }
+                        else { const float c=ux*y; if(c<c0-0.01f||c>c1+0.01f) continue; xa=-1e9f; xb=1e9f; }
+                        int xl=(int)ceilf(fmaxf(xa,(float)q[0])), xr=(int)floorf(fminf(xb,(float)q[2])); if(xl>xr) continue;
+                        const int x0=tx*TW; uint32_t wbits=bits[y][tx]&(0xFFFFFFFFu<<(xl-x0))&(0xFFFFFFFFu>>(31-(xr-x0))); if(!wbits) continue;
+                        const int xf=x0+__builtin_ctz(wbits), xt=x0+31-__builtin_clz(wbits);
+                        const float ta=ux*xf+uy*y, tb=ux*xt+uy*y;
+                        if(pass==0){ if(ta<exact)exact=ta; if(tb<exact)exact=tb; } else { if(ta>exact)exact=ta; if(tb>exact)exact=tb; } } }
+                if(pass==0) l=fminf(exact,second); else h=fmaxf(exact,second); }
             lo[d][b]=l; hi[d][b]=h; } }
+    fprintf(stderr,"box tests per bin %.1f, row tests per bin %.1f\n",(double)box_tests/(16.0*NB),(double)row_tests/(16.0*NB));
     long steps_loop=0; long holes=0, pairs=0, complete=0, survive=0, falsekill=0, steps_all=0, steps_surv=0, holes_any=0;
     for(int y=by0;y<=by1;y++)for(int x=bx0;x<=bx1;x++){ if(m[y][x]) continue; holes++; int any=0;
         for(int d=0;d<16;d++){ float n=sqrtf(dx[d]*dx[d]+dy[d]*dy[d]); volatile float ux=dx[d]/n, uy=dy[d]/n; pairs++;
