@@ -376,7 +376,8 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * (hsa_amd_memory_async_copy_on_engine; the copy's dependency signal is released and its completion signal awaited by one-lane
  * kernels in the lanes' streams, so the call stays asynchronous and `stream` still sees every frame delivered) instead of the
  * runtime's hipMemcpyAsync, which is a blit kernel on the compute units.  The engine takes the groups in order: no turns.
- * Falls back to hipMemcpyAsync when HSA does not report an engine for the two buffers.  The one piece of process-wide state the
+ * Falls back to hipMemcpyAsync when HSA does not report an engine for the two buffers.  A completion signal that has not fired
+ * after seconds of polling is a dead engine: the polling kernel traps and `stream`'s next synchronisation fails.  The one piece of process-wide state the
  * library keeps belongs to this flag: a pool of HSA signals, reused once the call that used them has run to its end. */
 #define KBE_VIDEO_SDMA 8192
 /* fused route: force the lean / the roomy build of the tile launches (KBE_STAGE_FUSED_LEAN / _ROOMY for every frame) */

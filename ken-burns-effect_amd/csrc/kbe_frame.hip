@@ -744,14 +744,17 @@ __global__ void __launch_bounds__(64) k_signal_release(volatile int64_t* value)
     __threadfence_system();
     __hip_atomic_store((int64_t*) value, (int64_t) 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// bounded (~2 s): an engine that never reports is a dead device, and a kernel that polls for ever would hide that
+// bounded (seconds): an engine that never reports is a dead device, and a kernel that polls for ever would hide that.  Giving up
+// is an ERROR the caller must see -- the frames of that group are not in its memory: the kernel traps, and the stream's next
+// synchronisation reports the failed launch instead of a video with stale frames in it
 __global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, int max_polls)
 {
     if (threadIdx.x != 0) return;
     for (int polls = 0; polls < max_polls; polls++) {
-        if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) break;
+        if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) return;
         __builtin_amdgcn_s_sleep(16);
     }
+    __builtin_trap();
 }
 constexpr int SDMA_MAX_POLLS = 2000000;
 #ifndef KBE_SDMA_TWO_ENGINES
