@@ -306,20 +306,32 @@ __device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, boo
     c1 = cv_round(f * 2048.f);
 }
 
-// One workgroup = a 64 x 8 tile of the output, in the two steps OpenCV takes but without the intermediate
+// One workgroup = a 64 x CR_TH tile of the output, in the two steps OpenCV takes but without the intermediate
 // image: (0) the raw-frame rows the tile needs are staged in LDS with coalesced dword loads, (1) the
 // getRectSubPix patch pixels under the tile (each the rounded 16-bit fixed-point blend of 2 x 2 raw pixels) are
 // computed ONCE into LDS, (2) every output pixel blends 2 x 2 of those.  (One thread per output pixel doing
 // all 16 raw taps itself was instruction-bound: 400 VALU instructions per wave, 14.5 us per 1024^2 frame;
 // before the LDS staging it issued 48 byte gathers per pixel and took 25 us.)  The resize coefficients of the
-// tile's 64 columns and 8 rows are computed once, by 72 threads, not per pixel.
-constexpr int CR_TW = 64, CR_TH = 8, CR_THREADS = 256;
+// tile's columns and rows are computed once, by 64 + CR_TH threads, not per pixel.
+// Round 5: next to the other launches of the frame loop what counts is its instruction count (a 64 x 8 tile: ~450 vector
+// instructions per wave, 7.1 us per 1024^2 frame = 0.11 of the HBM roofline by its 6 HW bytes).  The tile is 64 x 16 now -- the
+// coefficients, the staging and the patch's two extra rows are paid once per 16 rows instead of once per 8 -- and a wave walks DOWN
+// its four output rows: two consecutive
+// output rows share a patch row (the scale is <= 1), so the horizontal pass of a patch row is taken once and kept in registers
+// (every test about rows is wave-uniform).  A patch that starts on a whole pixel (an odd crop of an even frame) IS the raw
+// rectangle: step (1) is skipped and step (2) reads the staged raw rows.
+#ifndef KBE_CROP_TH
+#define KBE_CROP_TH 16      // (64 x 8 / 16 / 32 / 64: 43.1 / 44.7 / 44.2 k frames/s left in HBM; a launch on its own is a chain of waits and takes longer with taller tiles)
+#endif
+constexpr int CR_TW = 64, CR_TH = KBE_CROP_TH, CR_THREADS = 256, CR_WAVES = CR_THREADS / 64;
+constexpr int CR_ROWS_PER_WAVE = CR_TH / CR_WAVES;
 constexpr int CR_PROWS = CR_TH + 2, CR_PCOLS = CR_TW + 2;              // patch pixels under a tile (scale <= 1)
 constexpr int CR_PBYTES = CR_PCOLS * 3, CR_PSTRIDE = (CR_PBYTES + 3) / 4 + 1;      // dwords per patch row in LDS
 constexpr int CR_RROWS = CR_PROWS + 1, CR_RDW = ((CR_PCOLS + 1) * 3 + 3 + 3) / 4 + 1;  // raw rows / dwords per raw row
-static_assert(CR_RROWS * CR_RDW <= 3 * CR_THREADS && CR_THREADS == 4 * CR_TW && CR_TH == 8, "crop tile geometry");
+constexpr int CR_STAGE = (CR_RROWS + CR_WAVES - 1) / CR_WAVES;        // raw rows a wave stages
+static_assert(CR_TH % CR_WAVES == 0 && CR_RDW <= 64 && CR_PBYTES <= CR_THREADS && CR_TW + CR_TH <= CR_THREADS && CR_PROWS + 1 <= CR_THREADS, "crop tile geometry");
 
-__device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_, uint8_t* __restrict__ out)
+__device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_, double scale_x, double scale_y, uint8_t* __restrict__ out)
 {
     __shared__ uint32_t s_raw[CR_RROWS][CR_RDW];
     __shared__ uint32_t s_patch[CR_PROWS][CR_PSTRIDE];
@@ -334,12 +346,15 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     const float fa = cx - (float) ipx, fb = cy - (float) ipy;
     const int a11 = cv_round((1.f - fa) * (1.f - fb) * 65536.f), a12 = cv_round(fa * (1.f - fb) * 65536.f);
     const int a21 = cv_round((1.f - fa) * fb * 65536.f), a22 = cv_round(fa * fb * 65536.f);
+    // an odd crop of an even frame (or the reverse) starts on a whole pixel: a11 = 65536 and the patch IS the raw rectangle
+    // ((t * 65536 + 32768) >> 16 == t); uniform over the launch
+    const bool whole = (a12 | a21 | a22) == 0;
     if (tid < CR_TW + CR_TH) {
         const bool col = tid < CR_TW;
         const int k = col ? tid : tid - CR_TW;
         int s0, s1, c0, c1;
-        if (col) resize_coeff(min(bx + k, W - 1), (double) cw / W, cw, true, s0, s1, c0, c1);
-        else resize_coeff(min(by + k, H - 1), (double) ch_ / H, ch_, false, s0, s1, c0, c1);
+        if (col) resize_coeff(min(bx + k, W - 1), scale_x, cw, true, s0, s1, c0, c1);         // scale = (double) cw / W, divided on the host
+        else resize_coeff(min(by + k, H - 1), scale_y, ch_, false, s0, s1, c0, c1);
         int* t = col ? &s_cx[0][k] : &s_cy[0][k];
         const int stride = col ? CR_TW : CR_TH;
         t[0] = s0; t[stride] = s1; t[2 * stride] = c0; t[3 * stride] = c1;
@@ -352,15 +367,14 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     const int ry0 = min(max(ipy + py_lo, 0), H - 1), ry1 = min(max(ipy + py_hi + 1, 0), H - 1);
     const int n_rows = ry1 - ry0 + 1;                                                       // <= CR_RROWS
     const size_t frame_bytes = (size_t) W * H * 3;
-    // (0) stage the raw rows: wave w takes rows w, w + 4, w + 8, lane = dword of the row, so everything about a row
+    // (0) stage the raw rows: wave w takes rows w, w + 4, w + 8, ..., lane = dword of the row, so everything about a row
     // is wave-uniform (scalar unit) and a lane only adds its offset; every load is issued before the first LDS
     // store (a load-store-load-store loop serialises the memory latencies)
-    static_assert(CR_RROWS <= 12 && CR_RDW <= 64 && CR_THREADS == 256, "one lane per dword of a staged row");
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-    uint32_t stage[3];
+    uint32_t stage[CR_STAGE];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int r = wv + 4 * k;                                       // wave-uniform
+    for (int k = 0; k < CR_STAGE; k++) {
+        const int r = wv + CR_WAVES * k;                                // wave-uniform
         stage[k] = 0;
         if (r < n_rows) {
             const size_t b0 = ((size_t) (ry0 + r) * W + rx0) * 3, b1 = ((size_t) (ry0 + r) * W + rx1) * 3 + 3;
@@ -375,8 +389,8 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int r = wv + 4 * k;
+    for (int k = 0; k < CR_STAGE; k++) {
+        const int r = wv + CR_WAVES * k;
         if (r < CR_RROWS && ln < CR_RDW) s_raw[r][ln] = stage[k];
     }
     if (tid <= CR_PROWS) {
@@ -391,14 +405,10 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     // rounding of cast_8u.  (One (row, byte) item per step with its own index arithmetic: 400 instructions.)
     const uint8_t* raw = (const uint8_t*) s_raw;
     uint8_t* patch = (uint8_t*) s_patch;
-    if (tid < n_pc3) {
-        const int pc = tid / 3, c = tid - pc * 3;
-        const int x0 = (min(max(ipx + px_lo + pc, 0), W - 1) - rx0) * 3 + c, x1 = (min(max(ipx + px_lo + pc + 1, 0), W - 1) - rx0) * 3 + c;
-        if ((a12 | a21 | a22) == 0) {
-            // an odd crop of an even frame (or the reverse) starts on a whole pixel: a11 = 65536 and the patch IS the
-            // raw rectangle ((t * 65536 + 32768) >> 16 == t): a copy (wave-uniform branch)
-            for (int pr = 0; pr < n_pr; pr++) patch[pr * (int) sizeof(s_patch[0]) + tid] = raw[s_ro[pr] + x0];
-        } else {
+    if (!whole) {                                                       // uniform
+        if (tid < n_pc3) {
+            const int pc = tid / 3, c = tid - pc * 3;
+            const int x0 = (min(max(ipx + px_lo + pc, 0), W - 1) - rx0) * 3 + c, x1 = (min(max(ipx + px_lo + pc + 1, 0), W - 1) - rx0) * 3 + c;
             int o = s_ro[0];
             int t0 = raw[o + x0], t1 = raw[o + x1];
             for (int pr = 0; pr < n_pr; pr++) {
@@ -409,22 +419,54 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
                 t0 = u0; t1 = u1;
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    // (2) resize INTER_LINEAR: 2 x 2 patch pixels per output pixel; two output rows per thread
+    // (2) resize INTER_LINEAR: 2 x 2 patch pixels per output pixel.  A thread owns a column of the tile and walks down its wave's
+    // CR_ROWS_PER_WAVE output rows; the horizontal pass of a patch row (x 2048, then >> 4 as OpenCV's vertical pass takes it) is
+    // kept for the two rows last used -- consecutive output rows mostly need one new patch row, not two.  What a row of the source
+    // is called: its byte offset in `src` (the patch, or the staged raw rows when the patch is the raw rectangle).
     const int col = tid & (CR_TW - 1);
-    const int sx = (s_cx[0][col] - px_lo) * 3, sx1 = (s_cx[1][col] - px_lo) * 3, ax0 = s_cx[2][col], ax1 = s_cx[3][col];
-    uint8_t px[2][3];
+    const uint8_t* const src = whole ? raw : (const uint8_t*) patch;
+    int sx, sx1;
+    if (whole) {
+        sx = (min(max(ipx + s_cx[0][col], 0), W - 1) - rx0) * 3;
+        sx1 = (min(max(ipx + s_cx[1][col], 0), W - 1) - rx0) * 3;
+    } else {
+        sx = (s_cx[0][col] - px_lo) * 3;
+        sx1 = (s_cx[1][col] - px_lo) * 3;
+    }
+    const int ax0 = s_cx[2][col], ax1 = s_cx[3][col];
+    auto row_offset = [&](int pr) -> int {                              // wave-uniform
+        return whole ? s_ro[pr] : pr * (int) sizeof(s_patch[0]);
+    };
+    auto horizontal = [&](int pr, int (&h)[3]) {
+        const int o = row_offset(pr);
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int row = (tid >> 6) + 4 * m;
-        const int sy = (s_cy[0][row] - py_lo) * (int) sizeof(s_patch[0]), sy1 = (s_cy[1][row] - py_lo) * (int) sizeof(s_patch[0]);
-        const int by0 = s_cy[2][row], by1 = s_cy[3][row];
+        for (int c = 0; c < 3; c++) h[c] = (int) (((uint32_t) src[o + sx + c] * (uint32_t) ax0 + (uint32_t) src[o + sx1 + c] * (uint32_t) ax1) >> 4);
+    };
+    int ka = -1, kb = -1;                                               // the patch rows whose horizontal pass `ha`, `hb` hold (scalars)
+    int ha[3] = { 0, 0, 0 }, hb[3] = { 0, 0, 0 };
+    uint8_t px[CR_ROWS_PER_WAVE][3];
+#pragma unroll
+    for (int m = 0; m < CR_ROWS_PER_WAVE; m++) {
+        const int row = wv * CR_ROWS_PER_WAVE + m;
+        const int y0 = __builtin_amdgcn_readfirstlane(s_cy[0][row] - py_lo), y1 = __builtin_amdgcn_readfirstlane(s_cy[1][row] - py_lo);
+        const int by0 = __builtin_amdgcn_readfirstlane(s_cy[2][row]), by1 = __builtin_amdgcn_readfirstlane(s_cy[3][row]);
+        if (ka != y0) {                                                 // uniform
+            if (kb == y0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) ha[c] = hb[c];
+            } else horizontal(y0, ha);
+            ka = y0;
+        }
+        if (y1 == y0) {                                                 // a row tap clipped at the image edge: both taps read the same row
+#pragma unroll
+            for (int c = 0; c < 3; c++) hb[c] = ha[c];
+            kb = y0;
+        } else if (kb != y1) { horizontal(y1, hb); kb = y1; }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int r0 = patch[sy + sx + c] * ax0 + patch[sy + sx1 + c] * ax1;            // horizontal pass, x2048
-            const int r1 = patch[sy1 + sx + c] * ax0 + patch[sy1 + sx1 + c] * ax1;
-            const int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;  // vertical pass
+            const int v = (((by0 * ha[c]) >> 16) + ((by1 * hb[c]) >> 16) + 2) >> 2;        // vertical pass
             px[m][c] = (uint8_t) min(max(v, 0), 255);
         }
         uint8_t* so = (uint8_t*) s_out[row] + col * 3;
@@ -432,12 +474,11 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     }
     __syncthreads();
     if ((W & 15) == 0 && bx + CR_TW <= W && ((uintptr_t) out & 15) == 0) {
-        // a tile row is 192 bytes: twelve 16-byte stores where the frame allows it -- 96 stores by 96 threads instead of two
-        // trips of dword stores with their index arithmetic for all 256 (as tile_epilogue, kbe_tiles.h)
+        // a tile row is 192 bytes: twelve 16-byte stores where the frame allows it (as tile_epilogue, kbe_tiles.h)
         constexpr int Q = CR_TW * 3 / 16;
-        static_assert((CR_TW * 3) % 16 == 0 && CR_TH * Q <= CR_THREADS && sizeof(s_out[0]) % 16 == 0, "16-byte row stores");
-        if (tid < CR_TH * Q) {
-            const int r = tid / Q, k = tid - r * Q;
+        static_assert((CR_TW * 3) % 16 == 0 && sizeof(s_out[0]) % 16 == 0, "16-byte row stores");
+        for (int i = tid; i < CR_TH * Q; i += CR_THREADS) {
+            const int r = i / Q, k = i - r * Q;
             if (by + r < H) ((uint4*) (out + ((size_t) (by + r) * W + bx) * 3))[k] = ((const uint4*) s_out[r])[k];
         }
     } else if ((W & 3) == 0 && bx + CR_TW <= W) {
@@ -448,8 +489,8 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int dx = bx + col, dy = by + (tid >> 6) + 4 * m;
+        for (int m = 0; m < CR_ROWS_PER_WAVE; m++) {
+            const int dx = bx + col, dy = by + wv * CR_ROWS_PER_WAVE + m;
             if (dx < W && dy < H) {
                 const size_t o = ((size_t) dy * W + dx) * 3;
                 out[o] = px[m][0]; out[o + 1] = px[m][1]; out[o + 2] = px[m][2];
@@ -458,17 +499,17 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     }
 }
 
-__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_,
+__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8(const uint8_t* __restrict__ img, int W, int H, int cw, int ch_, double scale_x, double scale_y,
                                                                uint8_t* __restrict__ out)
 {
-    crop_resize_body(img, W, H, cw, ch_, out);
+    crop_resize_body(img, W, H, cw, ch_, scale_x, scale_y, out);
 }
 
 // the same for up to four frames of the same size in one launch (blockIdx.z = the frame): the video loop's groups
 struct CropJobs { const uint8_t* img[4]; uint8_t* out[4]; };
-__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8_group(CropJobs jobs, int W, int H, int cw, int ch_)
+__global__ void __launch_bounds__(CR_THREADS) k_crop_resize_u8_group(CropJobs jobs, int W, int H, int cw, int ch_, double scale_x, double scale_y)
 {
-    crop_resize_body(jobs.img[blockIdx.z], W, H, cw, ch_, jobs.out[blockIdx.z]);
+    crop_resize_body(jobs.img[blockIdx.z], W, H, cw, ch_, scale_x, scale_y, jobs.out[blockIdx.z]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -885,7 +926,7 @@ int kbe_crop_resize_u8(const uint8_t* frame_hwc, int W, int H, int crop_w, int c
     KBE_REQUIRE(frame_hwc && out_hwc && W > 0 && H > 0 && crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H,
                 "kbe_crop_resize_u8: bad arguments");
     hipLaunchKernelGGL(k_crop_resize_u8, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH), dim3(CR_THREADS), 0,
-                       (hipStream_t) stream, frame_hwc, W, H, crop_w, crop_h, out_hwc);
+                       (hipStream_t) stream, frame_hwc, W, H, crop_w, crop_h, (double) crop_w / W, (double) crop_h / H, out_hwc);
     return launched("kbe_crop_resize_u8");
 }
 
@@ -898,7 +939,7 @@ int crop_resize_group(int n, const uint8_t* const* frames, int W, int H, int cro
     if (n == 1) return kbe_crop_resize_u8(frames[0], W, H, crop_w, crop_h, outs[0], (kbe_stream_t) stream);
     CropJobs jobs;
     for (int k = 0; k < 4; k++) { jobs.img[k] = frames[k < n ? k : 0]; jobs.out[k] = outs[k < n ? k : 0]; }
-    hipLaunchKernelGGL(k_crop_resize_u8_group, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH, n), dim3(CR_THREADS), 0, stream, jobs, W, H, crop_w, crop_h);
+    hipLaunchKernelGGL(k_crop_resize_u8_group, dim3((W + CR_TW - 1) / CR_TW, (H + CR_TH - 1) / CR_TH, n), dim3(CR_THREADS), 0, stream, jobs, W, H, crop_w, crop_h, (double) crop_w / W, (double) crop_h / H);
     return launched("kbe_crop_resize_u8 (group)");
 }
 }  // namespace kbe
