@@ -648,6 +648,13 @@ class HipKernels:
                 # 13.93 k frames/s, 75 frames 16.05 against 16.21 k: the larger groups render next to the other lane's transfer, whose
                 # blit kernel's PCIe-bound stores slow them.  Not the default.)
                 fast_ramp = os.environ.get('KBE_RAMP', 'classic') == 'fast'
+                if not batch and lanes > DEFAULT_HOST_LANES:
+                    # all lanes: the rendering binds, not the link (delivery_lanes).  A lane then waits for nothing but its own last
+                    # transfer, and what a video loses is its END -- the lanes' last transfer groups leave one after the other when
+                    # nothing is left to render, and groups of 32 deal the frames unevenly to four lanes: a transfer group is what ONE
+                    # scatter launch renders.  Measured (tools/gpu_r05_dolly_batch.sh, bench --dolly, 256 frames, k frames/s delivered with
+                    # groups of up to 32 / 16 / 12 / 8 frames: 10.2 / 10.7 / 10.7 / 11.4; left in HBM: 13.0)
+                    batch = -self.video_launch_shape(state, cameras, -1, to_host=True)[1]
                 batch = batch or -max(1, min(32, max(n // (2 * lanes), (n + 1) // 2 if fast_ramp else 0)))
         # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
         batch = int(batch)

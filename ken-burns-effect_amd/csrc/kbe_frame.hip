@@ -744,19 +744,21 @@ __global__ void __launch_bounds__(64) k_signal_release(volatile int64_t* value)
     __threadfence_system();
     __hip_atomic_store((int64_t*) value, (int64_t) 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// bounded (seconds): an engine that never reports is a dead device, and a kernel that polls for ever would hide that.  Giving up
-// is an ERROR the caller must see -- the frames of that group are not in its memory: the kernel traps, and the stream's next
-// synchronisation reports the failed launch instead of a video with stale frames in it
-__global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, int max_polls)
+// bounded (SDMA_MAX_WAIT of the 100 MHz wall clock: 4 s -- a video's groups take milliseconds): an engine that never reports is a dead
+// device, and a kernel that polls for ever would hide that.  Giving up is an ERROR the caller must see -- the frames of that group
+// are not in its memory: the kernel traps, and the stream's next synchronisation reports the failed launch instead of a video with
+// stale frames in it
+__global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, unsigned long long max_ticks)
 {
     if (threadIdx.x != 0) return;
-    for (int polls = 0; polls < max_polls; polls++) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    do {
         if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) return;
         __builtin_amdgcn_s_sleep(16);
-    }
+    } while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks);
     __builtin_trap();
 }
-constexpr int SDMA_MAX_POLLS = 2000000;
+constexpr unsigned long long SDMA_MAX_WAIT = 400000000ull;
 #ifndef KBE_SDMA_TWO_ENGINES
 #define KBE_SDMA_TWO_ENGINES 0      // (1: consecutive groups alternate between two engines -- measured slower end to end, see sdma_open)
 #endif
@@ -1550,7 +1552,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 // lane renders its next group while its last one leaves, measured SLOWER: 14.2 k instead of 14.6 k frames/s for 20
                 // frames, 15.9 k instead of 16.6 k for 75 -- a lane then renders the group after next while the other lane still
                 // renders the group the engine waits for)
-                if (lane_fin[l]) { hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_POLLS); lane_fin[l] = nullptr; }
+                if (lane_fin[l]) { hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_WAIT); lane_fin[l] = nullptr; }
                 if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
                     int idx[KBE_FRAME_JOBS], count = 0;
                     uint8_t* outs[KBE_FRAME_JOBS];
@@ -1603,7 +1605,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
             // (SDMA) a lane is done when its last group has left: whoever waits for the lanes (join) waits for the frames
             for (int l = 0; l < lanes; l++)
-                if (lane_fin[l]) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_POLLS);
+                if (lane_fin[l]) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_WAIT);
 #if defined(KBE_VIDEO_GPU_TRACE)
             for (int l = 0; l < lanes; l++) (void) hipStreamSynchronize(ls[l]);
             for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
