@@ -53,6 +53,20 @@ def lanes_for_delivery(lanes, render_us, frame_bytes):
     return min(lanes, DEFAULT_HOST_LANES) if link_us > 1.5 * render_us else lanes
 
 
+def transfer_group(n_frames, lanes, launch_group, fast_ramp=False):
+    """-(frames per transfer group) of a delivered video of n_frames on `lanes` lanes (kbe_render_video's batch < 0; the first groups
+    ramp 1, 2, 4, ...: include/kbe.h).  Two lanes -- the link binds: groups of up to 32 frames (16 -> 32: 17.3 -> 17.5 k frames/s), a short
+    video's small enough for each lane to have two of full size.  More lanes -- the rendering binds, not the link (delivery_lanes): a
+    lane then waits for nothing but its own last transfer, and what a video loses is its END -- the lanes' last groups leave one after
+    the other when nothing is left to render, and groups of 32 deal the frames unevenly to four lanes: a transfer group is what ONE
+    scatter launch renders (`launch_group`).  Measured (tools/gpu_r05_dolly_batch.sh, profiles/r05_transfer_groups.txt): bench --dolly,
+    256 frames, k frames/s delivered with groups of up to 32 / 16 / 12 / 8 frames 10.2 / 10.7 / 10.7 / 11.4 (left in HBM: 13.0);
+    configs[4], 64 frames, groups of 32 / 2: 2.2 / 3.0 k."""
+    if lanes > DEFAULT_HOST_LANES:
+        return -max(1, int(launch_group))
+    return -max(1, min(32, max(n_frames // (2 * lanes), (n_frames + 1) // 2 if fast_ramp else 0)))
+
+
 def host_lanes(lanes, n_points, W, H, frame_bytes):
     """The a-priori estimate (HipKernels.delivery_lanes measures instead, once per cloud, when the video is long enough).
     Lanes of the frame loop when the frames go to pinned host memory (env KBE_HOST_LANES overrides).  Where the PCIe
@@ -648,14 +662,7 @@ class HipKernels:
                 # 13.93 k frames/s, 75 frames 16.05 against 16.21 k: the larger groups render next to the other lane's transfer, whose
                 # blit kernel's PCIe-bound stores slow them.  Not the default.)
                 fast_ramp = os.environ.get('KBE_RAMP', 'classic') == 'fast'
-                if not batch and lanes > DEFAULT_HOST_LANES:
-                    # all lanes: the rendering binds, not the link (delivery_lanes).  A lane then waits for nothing but its own last
-                    # transfer, and what a video loses is its END -- the lanes' last transfer groups leave one after the other when
-                    # nothing is left to render, and groups of 32 deal the frames unevenly to four lanes: a transfer group is what ONE
-                    # scatter launch renders.  Measured (tools/gpu_r05_dolly_batch.sh, bench --dolly, 256 frames, k frames/s delivered with
-                    # groups of up to 32 / 16 / 12 / 8 frames: 10.2 / 10.7 / 10.7 / 11.4; left in HBM: 13.0)
-                    batch = -self.video_launch_shape(state, cameras, -1, to_host=True)[1]
-                batch = batch or -max(1, min(32, max(n // (2 * lanes), (n + 1) // 2 if fast_ramp else 0)))
+                batch = batch or transfer_group(n, lanes, self.video_launch_shape(state, cameras, -1, to_host=True)[1] if lanes > DEFAULT_HOST_LANES else 0, fast_ramp)
         # the staging buffers grow with |batch| (lanes * (4 + G) frames): never more frames per transfer than the video has, or than 64
         batch = int(batch)
         batch = -min(-batch, max(n, 1), 64) if batch < 0 else min(batch, max(n, 1), 64)

@@ -273,6 +273,17 @@ def test_lanes_for_delivery_follow_the_measured_render_time():
     assert _native.lanes_for_delivery(1, 25.0, fb) == 1 and _native.lanes_for_delivery(8, 5.0, fb) == 2
 
 
+def test_transfer_groups_follow_the_lanes():
+    """_native.transfer_group: up to 32 frames per transfer where the link binds (two lanes), one scatter launch's frames where the
+    rendering does (all lanes)."""
+    from ken_burns_effect_amd import _native
+    assert _native.transfer_group(1024, 2, 12) == -32 and _native.transfer_group(75, 2, 12) == -18 and _native.transfer_group(20, 2, 12) == -5
+    assert _native.transfer_group(3, 2, 12) == -1 and _native.transfer_group(0, 2, 12) == -1
+    assert _native.transfer_group(256, 4, 8) == -8 and _native.transfer_group(64, 4, 2) == -2 and _native.transfer_group(5, 3, 12) == -12
+    assert _native.transfer_group(20, 2, 12, fast_ramp=True) == -10
+    assert _native.transfer_group(100, 1, 12) == -32
+
+
 def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     """_native.video_launch_shape: the table-driven fill for clouds without appended points seen by a camera that zooms out;
     frames per launch by what binds the video; the scatter route is the cloud's (until round 5 a zoom-out took the bucket route)."""
