@@ -37,7 +37,6 @@
 #include <vector>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
-#include <hsa/amd_hsa_signal.h>
 
 #include "kbe_cloud.h"
 #include "kbe_tiles.h"
@@ -763,7 +762,7 @@ constexpr unsigned long long SDMA_MAX_WAIT = 400000000ull;
 #define KBE_SDMA_TWO_ENGINES 0      // (1: consecutive groups alternate between two engines -- measured slower end to end, see sdma_open)
 #endif
 
-struct SdmaPair { hsa_signal_t dep, fin; };
+struct SdmaPair { hsa_signal_t dep, fin; volatile int64_t* dep_value; volatile int64_t* fin_value; };     // the signals and where their values live
 struct SdmaGeneration { hipEvent_t done; std::vector<SdmaPair> pairs; };
 struct SdmaPool {
     std::mutex mu;
@@ -772,7 +771,17 @@ struct SdmaPool {
     std::vector<SdmaGeneration> running;
 };
 static SdmaPool& sdma_pool() { static SdmaPool* p = new SdmaPool; return *p; }         // (never destroyed: the signals must not die before the runtime)
-static volatile int64_t* signal_value(hsa_signal_t sg) { return &((amd_signal_t*) sg.handle)->value; }
+// A signal whose value device code may store to and poll: HSA asks for one that only GPUs consume (no host interrupt behind it -- nothing
+// on the host ever waits for these) and hands out the value's address (hsa_amd_signal_value_pointer)
+static bool sdma_signal(hsa_signal_t& sg, volatile int64_t*& value)
+{
+    if (hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &sg) != HSA_STATUS_SUCCESS) return false;
+    volatile hsa_signal_value_t* p = nullptr;
+    if (hsa_amd_signal_value_pointer(sg, &p) != HSA_STATUS_SUCCESS || !p) { (void) hsa_signal_destroy(sg); return false; }
+    static_assert(sizeof(hsa_signal_value_t) == sizeof(int64_t), "a signal's value is 64 bits");
+    value = (volatile int64_t*) p;
+    return true;
+}
 struct SdmaCall {                               // one kbe_render_video call's use of the engine
     bool ok = false;
     hsa_agent_t gpu = {}, cpu = {};
@@ -827,7 +836,10 @@ static bool sdma_pair(SdmaCall& c, SdmaPair& p)
     SdmaPool& pool = sdma_pool();
     std::lock_guard<std::mutex> lock(pool.mu);
     if (!pool.idle.empty()) { p = pool.idle.back(); pool.idle.pop_back(); }
-    else if (hsa_signal_create(1, 0, nullptr, &p.dep) != HSA_STATUS_SUCCESS || hsa_signal_create(1, 0, nullptr, &p.fin) != HSA_STATUS_SUCCESS) return false;
+    else {
+        if (!sdma_signal(p.dep, p.dep_value)) return false;
+        if (!sdma_signal(p.fin, p.fin_value)) { (void) hsa_signal_destroy(p.dep); return false; }
+    }
     hsa_signal_store_relaxed(p.dep, 1);
     hsa_signal_store_relaxed(p.fin, 1);
     c.used.push_back(p);
@@ -1583,8 +1595,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                     SdmaPair p;
                     if (sdma_pair(sdma, p) && hsa_amd_memory_async_copy_on_engine(host_out + (size_t) i0 * fb, sdma.cpu, base, sdma.gpu, (size_t) nb * fb, 1, &p.dep, p.fin,
                                                                                   sdma.engine[sdma.sent++ & 1], true) == HSA_STATUS_SUCCESS) {
-                        hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], signal_value(p.dep));
-                        lane_fin[l] = signal_value(p.fin);
+                        hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], p.dep_value);
+                        lane_fin[l] = p.fin_value;
                         sent = true;
                     } else sdma.ok = false;                         // this group and the rest: the runtime's transfers
                 }
