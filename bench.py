@@ -113,12 +113,18 @@ def measured_instructions():
 
 
 def consecutive_groups(path, n):
-    """The launch groups of a video whose cameras are `path`: group k = cameras [n k, n k + n), the path taken cyclically so that
-    every group has n frames (a 20-step path in groups of twelve: [0..11], [12..19, 0..3]).  What the scatter's launch is priced on
-    since round 5: the frames of a group share candidate lists built for the box between the group's first and last
-    camera, so a launch of n copies of ONE camera is that scheme's best case."""
-    count = max(1, (len(path) + n - 1) // n)
-    return [[path[(k * n + j) % len(path)] for j in range(n)] for k in range(count)]
+    """The launch groups of a video whose cameras are `path`: group k = cameras [n k, n k + n); where the path does not divide, the
+    last group is the path's LAST n cameras (a 20-step path in groups of twelve: [0..11], [8..19]) -- every launch holds n consecutive
+    cameras of the path, as every launch of a real video does (until late in round 5 the last group wrapped round to the path's start:
+    a jump from the last camera to the first inside one launch, which no video makes and which took that launch's shared lists away).
+    What the scatter's launch is priced on since round 5: the frames of a group share candidate lists built for the box
+    between a sub-group's first and last camera, so a launch of n copies of ONE camera is that scheme's best case."""
+    if len(path) <= n:
+        return [list(path)]
+    groups = [list(path[k:k + n]) for k in range(0, len(path) - n + 1, n)]
+    if len(path) % n:
+        groups.append(list(path[-n:]))
+    return groups
 
 
 PRODUCT_STEPS = 75      # /root/reference/kbe.py:104: a video of the product is np.linspace(0, 1, 75)
@@ -793,9 +799,10 @@ def main():
         for label in paths:
             t = kt.get('fused:scatter_group_ahead:consecutive:' + label)
             if t:
-                by_path[label] = {'steps': int(label), 'groups': len(consecutive_groups(paths[label], group_frames)), 'frames_per_launch': group_frames,
-                                  'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / group_frames, 2),
-                                  'achieved': group_frames * scatter_bytes / t / 1e9, 'frac': group_frames * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
+                fpl = min(group_frames, len(paths[label]))      # (a path shorter than a launch: one group of all its frames)
+                by_path[label] = {'steps': int(label), 'groups': len(consecutive_groups(paths[label], group_frames)), 'frames_per_launch': fpl,
+                                  'us': round(t * 1e6, 2), 'us_per_frame': round(t * 1e6 / fpl, 2),
+                                  'achieved': fpl * scatter_bytes / t / 1e9, 'frac': fpl * scatter_bytes / t / 1e9 / HBM_PEAK_GBS,
                                   'rounds_us': [round(x * 1e6, 2) for x in kt['fused:scatter_group_ahead:consecutive:' + label + ':rounds']]}
         cameras_note, identical = 'identical (one camera, %d copies per launch)' % frames_per_launch, None
         if route == 'fused' and ahead and frames_per_launch == group_frames and str(PRODUCT_STEPS) in by_path:
@@ -804,7 +811,7 @@ def main():
             main = dict(main, us=c['us'], us_per_frame=c['us_per_frame'], achieved=c['achieved'], frac=c['frac'])
             if 'valu_issue' in main:
                 main['valu_issue'] = dict(main['valu_issue'], frac=main['valu_issue']['us_at_peak'] / c['us_per_frame'])
-            cameras_note = 'consecutive: groups of %d consecutive cameras of a %d-step path, group k placing group k + 1 ahead' % (group_frames, PRODUCT_STEPS)
+            cameras_note = 'consecutive: groups of %d consecutive cameras of a %d-step path (the last group: the path\'s last %d), group k placing group k + 1 ahead' % (group_frames, PRODUCT_STEPS, group_frames)
         cloud = ('raw' if args.dolly else args.cloud) if args.upsample == 1 else '%dx-upsampled' % args.upsample ** 2
         line = {
             'metric': 'novel_view_frames_per_sec_%dx%d' % (size, size), 'value': total_steps / elapsed,

@@ -92,7 +92,7 @@ for n in ((1, 2, 4, 8, 12) if os.environ.get('IDENTICAL', '1') == '1' else ((12,
     print('%2d frame(s) per launch: k_place + k_frame %.2f us per frame, pipelined (one launch) %.2f us per frame (arguments prepared: %.2f)' % (n, t_classic, t_ahead, t_prepared))
 
 
-# ---- the launch on a video's OWN groups: group k = cameras [n k, n k + n) of a path of PATHS steps (cyclic), the
+# ---- the launch on a video's OWN groups: group k = cameras [n k, n k + n) of a path of PATHS steps (the last group: the path's last n), the
 # launch of group k placing group k + 1 ahead -- the frames of a group share their candidate lists, built for the box between the
 # group's first and last camera, so twelve copies of one camera (above) are that scheme's best case
 import ctypes  # noqa: E402
