@@ -401,7 +401,7 @@ class HipKernels:
     def group_scratch(self, state, sets):
         """`sets` initialised scratch sets for launches that take several frames (kbe_render_frame_group, KBE_VIDEO_FILL_GROUP),
         allocated on first use: (tensor, stride in bytes)."""
-        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
+        stride = self.scratch_stride(state)
         if 'scratch_groups' not in state or state['scratch_groups'].numel() < sets * stride:
             state['scratch_groups'] = torch.empty(sets * stride, dtype=torch.uint8, device=state['points'].device)
             self._check(self.lib.kbe_frame_scratch_init_sets(ctypes.c_void_p(state['scratch_groups'].data_ptr()), _z(stride), _i(sets), _i(state['W']), _i(state['H']),
@@ -497,10 +497,16 @@ class HipKernels:
         launch.keep = keep
         return launch
 
+    def scratch_stride(self, state):
+        """Bytes between two scratch sets of the cloud's frame size (kbe_video_scratch_stride), asked once per cloud."""
+        if 'scratch_stride' not in state:
+            state['scratch_stride'] = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
+        return state['scratch_stride']
+
     def scratch_set_budget(self, state):
         """How many scratch sets (kbe_video_scratch_stride bytes each) a video loop may hold: KBE_SCRATCH_BUDGET_MB, or half of the
         device memory that is free now plus what the cloud's sets already hold; at least one per lane."""
-        stride = int(self.lib.kbe_video_scratch_stride(_i(state['W']), _i(state['H']), _i(state['N'])))
+        stride = self.scratch_stride(state)
         env = os.environ.get('KBE_SCRATCH_BUDGET_MB')
         if env:
             budget = float(env) * 1e6
@@ -702,9 +708,12 @@ class HipKernels:
             # n scratch sets per lane in use, allocated on first use -- 224 MB each at 1024^2, 0.9 GB at 2048^2 (most of it the
             # bucket / spill area): a launch shape that would take more than the budget (KBE_SCRATCH_BUDGET_MB, default half of
             # what is free, never less than one set per lane) falls back to fewer frames per launch
-            max_sets, fits = self.scratch_set_budget(state), group
-            while fits > 1 and fits * lanes > max_sets:
-                fits = max(1, fits // 2)
+            # (asked only when the sets the cloud already holds do not do: the budget reads the device's free memory, ~10 us of every call)
+            fits = group
+            if 'scratch_groups' not in state or state['scratch_groups'].numel() < group * lanes * self.scratch_stride(state) or os.environ.get('KBE_SCRATCH_BUDGET_MB'):
+                max_sets = self.scratch_set_budget(state)
+                while fits > 1 and fits * lanes > max_sets:
+                    fits = max(1, fits // 2)
             if fits != group:
                 flags, group, fused = self.video_launch_shape(state, cameras, batch, to_host=not host_out.is_cuda, max_group=fits)
                 flags |= keep_flags
