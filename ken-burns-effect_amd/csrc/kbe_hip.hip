@@ -306,6 +306,13 @@ __device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, boo
     c1 = cv_round(f * 2048.f);
 }
 
+// 24-bit multiplies as the instructions (a 32-bit integer multiply is a quarter-rate instruction, and the compiler cannot see that a
+// byte times an 11- or 17-bit weight fits 24 bits); _s: the first factor is wave-uniform (a scalar register)
+__device__ __forceinline__ uint32_t mul_u24_v(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t mad_u24_v(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t mul_u24_s(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t mad_u24_s(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c)); return r; }
+
 // One workgroup = a 64 x CR_TH tile of the output, in the two steps OpenCV takes but without the intermediate
 // image: (0) the raw-frame rows the tile needs are staged in LDS with coalesced dword loads, (1) the
 // getRectSubPix patch pixels under the tile (each the rounded 16-bit fixed-point blend of 2 x 2 raw pixels) are
@@ -414,8 +421,9 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
             for (int pr = 0; pr < n_pr; pr++) {
                 o = s_ro[pr + 1];
                 const int u0 = raw[o + x0], u1 = raw[o + x1];
-                const int t = t0 * a11 + t1 * a12 + u0 * a21 + u1 * a22;
-                patch[pr * (int) sizeof(s_patch[0]) + tid] = (uint8_t) ((t + (1 << 15)) >> 16);
+                // (bytes times 17-bit weights that sum to 65536: 24-bit multiply-adds, the sum below 2^24 + 2^15)
+                const uint32_t t = mad_u24_s((uint32_t) a22, (uint32_t) u1, mad_u24_s((uint32_t) a21, (uint32_t) u0, mad_u24_s((uint32_t) a12, (uint32_t) t1, mad_u24_s((uint32_t) a11, (uint32_t) t0, 1u << 15))));
+                patch[pr * (int) sizeof(s_patch[0]) + tid] = (uint8_t) (t >> 16);
                 t0 = u0; t1 = u1;
             }
         }
@@ -442,7 +450,7 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     auto horizontal = [&](int pr, int (&h)[3]) {
         const int o = row_offset(pr);
 #pragma unroll
-        for (int c = 0; c < 3; c++) h[c] = (int) (((uint32_t) src[o + sx + c] * (uint32_t) ax0 + (uint32_t) src[o + sx1 + c] * (uint32_t) ax1) >> 4);
+        for (int c = 0; c < 3; c++) h[c] = (int) (mad_u24_v(src[o + sx1 + c], (uint32_t) ax1, mul_u24_v(src[o + sx + c], (uint32_t) ax0)) >> 4);
     };
     int ka = -1, kb = -1;                                               // the patch rows whose horizontal pass `ha`, `hb` hold (scalars)
     int ha[3] = { 0, 0, 0 }, hb[3] = { 0, 0, 0 };
@@ -466,8 +474,9 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
         } else if (kb != y1) { horizontal(y1, hb); kb = y1; }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int v = (((by0 * ha[c]) >> 16) + ((by1 * hb[c]) >> 16) + 2) >> 2;        // vertical pass
-            px[m][c] = (uint8_t) min(max(v, 0), 255);
+            // vertical pass (by <= 2048, h < 2^15: 24-bit multiplies; the sum is at most 2048 * 32640 / 65536 = 1020, never negative)
+            const uint32_t v = ((mul_u24_s((uint32_t) by0, (uint32_t) ha[c]) >> 16) + (mul_u24_s((uint32_t) by1, (uint32_t) hb[c]) >> 16) + 2u) >> 2;
+            px[m][c] = (uint8_t) min(v, 255u);
         }
         uint8_t* so = (uint8_t*) s_out[row] + col * 3;
         so[0] = px[m][0]; so[1] = px[m][1]; so[2] = px[m][2];
