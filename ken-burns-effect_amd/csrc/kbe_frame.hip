@@ -1253,8 +1253,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                      double cloud_focal, int flags, kbe_stream_t stream, kbe_stream_t copy_stream, int lanes,
                      const kbe_stream_t* lane_streams, double near_depth)
 {
-    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64 && (!packed || cloud_focal > 0.0),
-                "kbe_render_video: bad arguments");
+    KBE_REQUIRE(n_frames >= 0 && focals && shifts && stage && host_out && W > 0 && H > 0 && batch >= -64 && (!packed || cloud_focal > 0.0) &&
+                (size_t) W * H <= (1u << 30) && W < (1 << 24) && H < (1 << 24), "kbe_render_video: bad arguments");
     KBE_REQUIRE((crop_w == 0 && crop_h == 0) || (crop_w > 0 && crop_h > 0 && crop_w <= W && crop_h <= H), "kbe_render_video: bad crop");
     KBE_REQUIRE(lanes >= 1 && lanes <= KBE_MAX_LANES && (lanes == 1 || lane_streams), "kbe_render_video: bad lanes");
     KBE_REQUIRE(near_depth >= 0.0 && near_depth < 1.0e30, "kbe_render_video: near_depth is a depth (0: unknown)");
