@@ -311,6 +311,7 @@ __device__ __forceinline__ void resize_coeff(int d, double scale, int src_n, boo
 __device__ __forceinline__ uint32_t mul_u24_v(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint32_t mad_u24_v(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ uint32_t mul_u24_s(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t mul_hi_u24_s(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }      // bits 47..32 of the product
 __device__ __forceinline__ uint32_t mad_u24_s(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c)); return r; }
 
 // One workgroup = a 64 x CR_TH tile of the output, in the two steps OpenCV takes but without the intermediate
@@ -430,7 +431,7 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
         __syncthreads();
     }
     // (2) resize INTER_LINEAR: 2 x 2 patch pixels per output pixel.  A thread owns a column of the tile and walks down its wave's
-    // CR_ROWS_PER_WAVE output rows; the horizontal pass of a patch row (x 2048, then >> 4 as OpenCV's vertical pass takes it) is
+    // CR_ROWS_PER_WAVE output rows; the horizontal pass of a patch row (x 2048, its low four bits dropped as OpenCV's vertical pass drops them) is
     // kept for the two rows last used -- consecutive output rows mostly need one new patch row, not two.  What a row of the source
     // is called: its byte offset in `src` (the patch, or the staged raw rows when the patch is the raw rectangle).
     const int col = tid & (CR_TW - 1);
@@ -450,7 +451,7 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
     auto horizontal = [&](int pr, int (&h)[3]) {
         const int o = row_offset(pr);
 #pragma unroll
-        for (int c = 0; c < 3; c++) h[c] = (int) (mad_u24_v(src[o + sx1 + c], (uint32_t) ax1, mul_u24_v(src[o + sx + c], (uint32_t) ax0)) >> 4);
+        for (int c = 0; c < 3; c++) h[c] = (int) (mad_u24_v(src[o + sx1 + c], (uint32_t) ax1, mul_u24_v(src[o + sx + c], (uint32_t) ax0)) & ~15u);       // (r >> 4) << 4: see the vertical pass
     };
     int ka = -1, kb = -1;                                               // the patch rows whose horizontal pass `ha`, `hb` hold (scalars)
     int ha[3] = { 0, 0, 0 }, hb[3] = { 0, 0, 0 };
@@ -474,9 +475,12 @@ __device__ __forceinline__ void crop_resize_body(const uint8_t* __restrict__ img
         } else if (kb != y1) { horizontal(y1, hb); kb = y1; }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            // vertical pass (by <= 2048, h < 2^15: 24-bit multiplies; the sum is at most 2048 * 32640 / 65536 = 1020, never negative)
-            const uint32_t v = ((mul_u24_s((uint32_t) by0, (uint32_t) ha[c]) >> 16) + (mul_u24_s((uint32_t) by1, (uint32_t) hb[c]) >> 16) + 2u) >> 2;
-            px[m][c] = (uint8_t) min(v, 255u);
+            // vertical pass: OpenCV's ((by * (r >> 4)) >> 16) is the high word of the 48-bit product (by << 12) * ((r >> 4) << 4) -- one
+            // v_mul_hi_u32_u24 (by <= 2048 and r < 2^20: both factors fit 24 bits) instead of a multiply and a shift.  The two weights sum
+            // to 2048 (2049 at most, where both roundings go up) and r >> 4 <= 32640, so the sum is at most 1020 and the pixel at most
+            // 255: OpenCV's saturation never acts
+            const uint32_t v = (mul_hi_u24_s((uint32_t) by0 << 12, (uint32_t) ha[c]) + mul_hi_u24_s((uint32_t) by1 << 12, (uint32_t) hb[c]) + 2u) >> 2;
+            px[m][c] = (uint8_t) v;
         }
         uint8_t* so = (uint8_t*) s_out[row] + col * 3;
         so[0] = px[m][0]; so[1] = px[m][1]; so[2] = px[m][2];
