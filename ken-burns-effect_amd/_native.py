@@ -55,8 +55,8 @@ def lanes_for_delivery(lanes, render_us, frame_bytes):
 
 def transfer_group(n_frames, lanes, launch_group, fast_ramp=False):
     """-(frames per transfer group) of a delivered video of n_frames on `lanes` lanes (kbe_render_video's batch < 0; the first groups
-    ramp 1, 2, 4, ...: include/kbe.h).  Two lanes -- the link binds: groups of up to 32 frames (16 -> 32: 17.3 -> 17.5 k frames/s), a short
-    video's small enough for each lane to have two of full size.  More lanes -- the rendering binds, not the link (delivery_lanes): a
+    ramp 1, 2, 4, ...: include/kbe.h).  Two lanes -- the link binds: groups of up to 32 frames (16 -> 32: 17.3 -> 17.5 k frames/s), a quarter of
+    the video between 64 and 128 frames, 16 below.  More lanes -- the rendering binds, not the link (delivery_lanes): a
     lane then waits for nothing but its own last transfer, and what a video loses is its END -- the lanes' last groups leave one after
     the other when nothing is left to render, and groups of 32 deal the frames unevenly to four lanes: a transfer group is what ONE
     scatter launch renders (`launch_group`).  Measured (tools/gpu_r05_dolly_batch.sh, profiles/r05_transfer_groups.txt): bench --dolly,
@@ -64,7 +64,10 @@ def transfer_group(n_frames, lanes, launch_group, fast_ramp=False):
     configs[4], 64 frames, groups of 32 / 2: 2.2 / 3.0 k."""
     if lanes > DEFAULT_HOST_LANES:
         return -max(1, int(launch_group))
-    return -max(1, min(32, max(n_frames // (2 * lanes), (n_frames + 1) // 2 if fast_ramp else 0)))
+    # (the ramp is never cut below 16: until late in round 5 a short video's cap was n / 4 alone -- "small enough for each lane to have two
+    # groups of full size", a rule from the blit hand-off's days; with the SDMA engine a transfer fewer is worth more: tools/gpu_r05_short_batch.sh,
+    # k frames/s delivered with the old cap / 8 / 16: 16 frames 13.8-13.9 / 14.3 / 14.3, 20 frames 14.8 / 14.9 / 14.9, 30 frames 15.5 / 15.4 / 15.65; 40, 75: equal)
+    return -max(1, min(32, max(n_frames // (2 * lanes), 16, (n_frames + 1) // 2 if fast_ramp else 0)))
 
 
 def host_lanes(lanes, n_points, W, H, frame_bytes):
@@ -661,8 +664,7 @@ class HipKernels:
                     batch = int(env)
                 except ValueError:
                     raise KbeError('KBE_DELIVERY_BATCH=%r is not an integer (frames per transfer: < 0 groups per lane, > 0 staged ring)' % env)
-                # groups of up to 32 frames per transfer (the first ones ramp 1, 2, 4, 8, 16: include/kbe.h; 16 -> 32: 17.3 -> 17.5 k frames/s); a short video's groups stay
-                # small enough for each lane to have two of full size
+                # how many frames a transfer group may hold: transfer_group (the first groups ramp 1, 2, 4, 8, 16: include/kbe.h)
                 # (KBE_RAMP=fast: groups of 1, 3, 7, 15, 31, ... frames, capped at half the video -- two transfers fewer than 1, 2, 4, 8, ...
                 # for a 20- or a 75-frame video.  Measured, round 4 (profiles/r04_short_videos.txt): no gain -- 20 frames 14.05 against
                 # 13.93 k frames/s, 75 frames 16.05 against 16.21 k: the larger groups render next to the other lane's transfer, whose

@@ -277,10 +277,10 @@ def test_transfer_groups_follow_the_lanes():
     """_native.transfer_group: up to 32 frames per transfer where the link binds (two lanes), one scatter launch's frames where the
     rendering does (all lanes)."""
     from ken_burns_effect_amd import _native
-    assert _native.transfer_group(1024, 2, 12) == -32 and _native.transfer_group(75, 2, 12) == -18 and _native.transfer_group(20, 2, 12) == -5
-    assert _native.transfer_group(3, 2, 12) == -1 and _native.transfer_group(0, 2, 12) == -1
+    assert _native.transfer_group(1024, 2, 12) == -32 and _native.transfer_group(75, 2, 12) == -18 and _native.transfer_group(100, 2, 12) == -25
+    assert _native.transfer_group(20, 2, 12) == -16 and _native.transfer_group(3, 2, 12) == -16 and _native.transfer_group(0, 2, 12) == -16      # (render_video caps at the video's length)
     assert _native.transfer_group(256, 4, 8) == -8 and _native.transfer_group(64, 4, 2) == -2 and _native.transfer_group(5, 3, 12) == -12
-    assert _native.transfer_group(20, 2, 12, fast_ramp=True) == -10
+    assert _native.transfer_group(20, 2, 12, fast_ramp=True) == -16 and _native.transfer_group(50, 2, 12, fast_ramp=True) == -25
     assert _native.transfer_group(100, 1, 12) == -32
 
 
