@@ -764,11 +764,13 @@ constexpr unsigned long long SDMA_MAX_WAIT = 400000000ull;
 
 struct SdmaPair { hsa_signal_t dep, fin; volatile int64_t* dep_value; volatile int64_t* fin_value; };     // the signals and where their values live
 struct SdmaGeneration { hipEvent_t done; std::vector<SdmaPair> pairs; };
+struct SdmaRoute { hsa_agent_t gpu, cpu; uint32_t engines; };          // the engines that copy from `gpu` to `cpu`'s memory (the preferred ones, or all)
 struct SdmaPool {
     std::mutex mu;
     int state = 0;                              // 0 = not tried, 1 = HSA is up, -1 = it is not
     std::vector<SdmaPair> idle;
     std::vector<SdmaGeneration> running;
+    std::vector<SdmaRoute> routes;
 };
 static SdmaPool& sdma_pool() { static SdmaPool* p = new SdmaPool; return *p; }         // (never destroyed: the signals must not die before the runtime)
 // A signal whose value device code may store to and poll: HSA asks for one that only GPUs consume (no host interrupt behind it -- nothing
@@ -804,10 +806,18 @@ static bool sdma_open(SdmaCall& c, const void* device_buffer, const void* host_b
     hsa_device_type_t dt, ht;
     if (hsa_agent_get_info(dinfo.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS || dt != HSA_DEVICE_TYPE_GPU) return false;
     if (hsa_agent_get_info(hinfo.agentOwner, HSA_AGENT_INFO_DEVICE, &ht) != HSA_STATUS_SUCCESS || ht != HSA_DEVICE_TYPE_CPU) return false;
-    uint32_t avail = 0, preferred = 0;
-    if (hsa_amd_memory_copy_engine_status(hinfo.agentOwner, dinfo.agentOwner, &avail) != HSA_STATUS_SUCCESS || !avail) return false;
-    if (hsa_amd_memory_get_preferred_copy_engine(hinfo.agentOwner, dinfo.agentOwner, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
-    const uint32_t pick = (preferred & avail) ? (preferred & avail) : avail;
+    // which engines copy from this GPU to this CPU agent is a property of the machine: asked once per pair of agents (the two queries cost
+    // the host ~10 us of every call, between the launches of a video's first and second group)
+    uint32_t pick = 0;
+    for (const SdmaRoute& r : pool.routes)
+        if (r.gpu.handle == dinfo.agentOwner.handle && r.cpu.handle == hinfo.agentOwner.handle) pick = r.engines;
+    if (!pick) {
+        uint32_t avail = 0, preferred = 0;
+        if (hsa_amd_memory_copy_engine_status(hinfo.agentOwner, dinfo.agentOwner, &avail) != HSA_STATUS_SUCCESS || !avail) return false;
+        if (hsa_amd_memory_get_preferred_copy_engine(hinfo.agentOwner, dinfo.agentOwner, &preferred) != HSA_STATUS_SUCCESS) preferred = 0;
+        pick = (preferred & avail) ? (preferred & avail) : avail;
+        pool.routes.push_back(SdmaRoute{ dinfo.agentOwner, hinfo.agentOwner, pick });
+    }
     // its lowest engine.  (An engine takes ~9.4 us from the end of one copy to the start of the next even when that one has long been
     // released -- the device-side timeline of a 20-frame video, tools/sdma_timeline.py: five such gaps in 1.35 ms.  With the groups
     // alternating between TWO engines, KBE_SDMA_TWO_ENGINES, the copies overlap and the last one ends 60 us earlier on the device --
