@@ -15,6 +15,8 @@ from ken_burns_effect_amd import _native, common, synthetic  # noqa: E402
 
 if os.environ.get('KBE_LIB_PATH'):
     _native._lib, _native._kernels, _native.LIB_PATH = None, None, os.environ['KBE_LIB_PATH']
+# (dev) PAD_MB: device memory taken before anything else -- shifts every later allocation (is the launch's time a matter of addresses?)
+_pad = torch.empty(int(float(os.environ.get('PAD_MB', '0')) * 1e6), dtype=torch.uint8, device='cuda') if os.environ.get('PAD_MB') else None
 size = int(os.environ.get('SIZE', '1024'))
 reps = int(os.environ.get('REPS', '40'))
 ofrom, oto = synthetic.default_windows(size, size, False)
