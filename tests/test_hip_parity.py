@@ -921,6 +921,35 @@ def test_video_whose_tile_launches_place_ahead_equals_the_video_with_placement_l
     same(K.render_frame(state, cams[0][1], cams[0][0], oc['dblBaseline']).cpu().numpy(), alone[0], 'a frame on its own after the videos')
 
 
+def test_delivered_videos_enqueued_back_to_back_without_a_host_synchronisation(K, monkeypatch):
+    """kbe_render_video is enqueue-only: a caller may enqueue video after video on one stream and synchronise once.  With the SDMA
+    hand-off every call draws signals from the process-wide pool and returns before its copies run; the next call renders into the same
+    staging slots.  Thirty videos of different lengths into host buffers of their own, no host synchronisation in between: every frame
+    must be the frame of the same video left in HBM (and the pool must hand signals out again afterwards: thirty more)."""
+    from ken_burns_effect_amd import common
+    monkeypatch.setenv('KBE_FUSED', '1')
+    size = (160, 224)
+    settings, oc = _scene(size, 23, 'smooth', True)
+    state = common._prepared_cloud(K, oc)
+    lengths = [1, 2, 3, 5, 8, 13, 20, 33, 7, 4]
+    videos = []
+    for n in lengths:
+        cams = common.frame_cameras(dict(settings, dblSteps=[i / max(n - 1, 1) for i in range(n)]), oc)
+        want = common.render_frames(cams, oc, None, keep_on_device=True).cpu().numpy()
+        videos.append((cams, want))
+    for _ in range(2):
+        hosts = []
+        for rep in range(3):
+            for cams, want in videos:
+                host = torch.zeros(len(cams), size[0], size[1], 3, dtype=torch.uint8, pin_memory=True)
+                K.render_video(state, cams, oc['dblBaseline'], None, host_out=host)         # enqueued; no synchronisation
+                hosts.append((host, want))
+        torch.cuda.current_stream().synchronize()
+        for k, (host, want) in enumerate(hosts):
+            d = np.abs(host.numpy().astype(np.int32) - want.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, 'video %d of the batch: max %d, %.2e of the values differ' % (k, d.max(), (d > 0).mean())
+
+
 def test_scratch_budget_falls_back_to_fewer_frames_per_launch_and_hint_replaces_the_probe(K, monkeypatch):
     """ADVICE r3 / VERDICT r3 item 6.  (1) The video loop's scratch sets (frames per launch x lanes of them) are capped by a memory
     budget: with KBE_SCRATCH_BUDGET_MB too small for the default shape the loop takes fewer frames per launch -- same frames.
