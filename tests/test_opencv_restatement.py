@@ -2,7 +2,8 @@
 numpy restatement (what the HIP kernel k_crop_resize_u8 is tested against, tests/test_hip_parity.py) versus a second,
 independently written restatement that follows the structure of OpenCV's own implementation
 (tests/opencv_8u_restatement.c).  OpenCV is not installed here: agreement of two restatements catches transcription
-errors, it does not pin parity with cv2 -- DESIGN.md keeps that row "parity unpinned".  The last two tests pin it the day an
+errors, it does not pin parity with cv2 -- DESIGN.md keeps that row "parity unpinned".  A third party checks the GEOMETRY (Pillow's
+bilinear resize: within one count on noise where both interpolate once).  The last two tests pin the arithmetic the day an
 image with OpenCV runs them: they call cv2 itself, exactly as common.py:256-257 and pipeline.py:96 do, and are SKIPPED without it."""
 import ctypes
 import os
@@ -63,6 +64,47 @@ def test_window_sticking_out_of_the_image_replicates_the_border(cvr):
     pad = np.pad(src, ((10, 10), (10, 10), (0, 0)), mode='edge')
     want = pad[10 + 1 - 4:10 + 1 + 5, 10 + 2 - 5:10 + 2 + 6]
     assert np.array_equal(dst, want)
+
+
+def test_geometry_against_pillows_bilinear_resize(oracle):
+    """A third party's view of the GEOMETRY (not of OpenCV's fixed-point arithmetic): Pillow's bilinear resize of the box getRectSubPix
+    samples -- patch pixel i is the source position W/2 - (cw - 1)/2 + i in pixel-centre coordinates (common.py:256), i.e. the box
+    [x0, x0 + cw] in Pillow's pixel-edge coordinates -- back to W x H.  Where the window starts on a whole pixel the patch is a copy
+    and both are ONE bilinear interpolation on the half-pixel grid: within one count everywhere inside the border, on NOISE (a
+    convention that is off by half a pixel reads 40 counts off on average).  Where it starts on a half pixel OpenCV interpolates
+    twice (getRectSubPix rounds a 2 x 2 blend to bytes, resize blends those): close on a smooth image only.  The outermost pixels are
+    left out: Pillow reads the source beyond the box there, OpenCV replicates the patch's edge."""
+    Image = pytest.importorskip('PIL.Image')
+    rng = np.random.default_rng(1)
+
+    def smooth(H, W):
+        y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+        out = np.zeros((H, W, 3))
+        for c in range(3):
+            for _ in range(4):
+                fx, fy, ph = rng.uniform(0.002, 0.03), rng.uniform(0.002, 0.03), rng.uniform(0, 6.28)
+                out[..., c] += np.sin(6.28 * (x * fx + y * fy) + ph)
+        return ((out - out.min()) / (out.max() - out.min()) * 255).round().astype(np.uint8)
+
+    def pillow(frame, cw, ch, off=0.0):
+        H, W, _ = frame.shape
+        x0, y0 = W / 2.0 - (cw - 1) * 0.5 + off, H / 2.0 - (ch - 1) * 0.5 + off
+        return np.asarray(Image.fromarray(frame).resize((W, H), Image.BILINEAR, box=(x0, y0, x0 + cw, y0 + ch)))
+
+    for (H, W, cw, ch) in [(256, 256, 231, 231), (300, 400, 361, 271), (512, 512, 461, 461), (1024, 1024, 921, 921), (96, 128, 39, 29)]:
+        frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)                 # whole-pixel windows, noise
+        ours = oracle.crop_resize_u8(frame, cw, ch).astype(np.int32)
+        d = np.abs(ours - pillow(frame, cw, ch))[3:-3, 3:-3]
+        assert d.max() <= 1 and d.mean() < 0.3, ((H, W, cw, ch), int(d.max()), float(d.mean()))
+        off = np.abs(ours - pillow(frame, cw, ch, 0.5))[3:-3, 3:-3]                 # ... and the test can tell: half a pixel off
+        assert off.mean() > 20, ((H, W, cw, ch), float(off.mean()))
+    for (H, W, cw, ch) in [(256, 256, 230, 230), (300, 400, 360, 270), (1024, 1024, 920, 920)]:
+        frame = smooth(H, W)                                                    # half-pixel windows, a smooth image
+        ours = oracle.crop_resize_u8(frame, cw, ch).astype(np.int32)
+        d = np.abs(ours - pillow(frame, cw, ch))[3:-3, 3:-3]
+        assert d.max() <= 2 and d.mean() < 0.4, ((H, W, cw, ch), int(d.max()), float(d.mean()))
+        off = np.abs(ours - pillow(frame, cw, ch, 0.5))[3:-3, 3:-3]
+        assert off.mean() > 2, ((H, W, cw, ch), float(off.mean()))
 
 
 def test_against_cv2_itself_when_opencv_is_installed(oracle, cvr):
