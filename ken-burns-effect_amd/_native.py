@@ -53,6 +53,35 @@ def lanes_for_delivery(lanes, render_us, frame_bytes):
     return min(lanes, DEFAULT_HOST_LANES) if link_us > 1.5 * render_us else lanes
 
 
+_LANE_STREAMS = {}
+
+
+def lane_streams_of(device, n):
+    """n streams for the lanes of the frame loop beside the caller's stream, one set per device for the life of the process.  LOW priority
+    where HIP offers one: lane 0 -- the caller's stream -- renders a video's FIRST frame, which every byte of a short delivered video
+    waits for, while lane 1 already renders the second group next to it; with the other lanes below it the first frame has the chip to
+    itself when both want it (tools/gpu_r05_prio.sh, three processes each, k frames/s delivered: 20 frames 14.95 -> 15.02, 16 frames
+    14.28 -> 14.40; high-priority lanes 14.83 / 14.25; long videos and frames left in HBM: no difference).  KBE_LANE_PRIORITY=0 keeps
+    torch's own streams."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    have = _LANE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        stream = None
+        if os.environ.get('KBE_LANE_PRIORITY', '1') != '0':
+            try:
+                hip = ctypes.CDLL('libamdhip64.so')
+                least, greatest, handle = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p()
+                with torch.cuda.device(key):
+                    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0 and least.value > 0 and \
+                            hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), least) == 0 and handle.value:      # 1 = hipStreamNonBlocking
+                        stream = torch.cuda.ExternalStream(handle.value, device=torch.device('cuda', key))
+            except (OSError, AttributeError, RuntimeError):
+                stream = None
+        have.append(stream if stream is not None else torch.cuda.Stream(device=torch.device('cuda', key)))
+    return have[:n]
+
+
 def transfer_group(n_frames, lanes, launch_group, fast_ramp=False):
     """-(frames per transfer group) of a delivered video of n_frames on `lanes` lanes (kbe_render_video's batch < 0; the first groups
     ramp 1, 2, 4, ...: include/kbe.h).  Two lanes -- the link binds: groups of up to 32 frames (16 -> 32: 17.3 -> 17.5 k frames/s), a quarter of
@@ -679,7 +708,7 @@ class HipKernels:
             state['stage'] = torch.empty(need, dtype=torch.uint8, device=dev)
         if 'copy_stream' not in state:
             state['copy_stream'] = torch.cuda.Stream(device=dev)
-            state['lane_streams'] = [None] + [torch.cuda.Stream(device=dev) for _ in range(state['lanes'] - 1)]
+            state['lane_streams'] = [None] + lane_streams_of(dev, state['lanes'] - 1)
         lane_streams = (ctypes.c_void_p * MAX_LANES)(*[None if st is None else st.cuda_stream for st in state['lane_streams']])
         focals = (ctypes.c_double * max(n, 1))(*[float(c[0]) for c in cameras])
         shifts = (ctypes.c_float * max(3 * n, 1))(*[float(v) for c in cameras for v in c[1]])
