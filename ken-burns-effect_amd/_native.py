@@ -57,18 +57,19 @@ _LANE_STREAMS = {}
 
 
 def lane_streams_of(device, n):
-    """n streams for the lanes of the frame loop beside the caller's stream, one set per device for the life of the process.  LOW priority
-    where HIP offers one: lane 0 -- the caller's stream -- renders a video's FIRST frame, which every byte of a short delivered video
-    waits for, while lane 1 already renders the second group next to it; with the other lanes below it the first frame has the chip to
-    itself when both want it (tools/gpu_r05_prio.sh, three processes each, k frames/s delivered: 20 frames 14.95 -> 15.02, 16 frames
-    14.28 -> 14.40; high-priority lanes 14.83 / 14.25; long videos and frames left in HBM: no difference).  KBE_LANE_PRIORITY=0 keeps
-    torch's own streams."""
+    """n streams for the lanes of the frame loop beside the caller's stream, one set per device for the life of the process: torch's own
+    streams.  KBE_LANE_PRIORITY=1 (dev) makes them LOW-priority HIP streams: lane 0 -- the caller's stream -- renders a video's FIRST
+    frame, which every byte of a short delivered video waits for, while lane 1 already renders the second group next to it; with the
+    other lanes below it the first frame has the chip when both want it (tools/gpu_r05_prio.sh, three processes each, k frames/s
+    delivered: 20 frames 14.95 -> 15.02, 16 frames 14.28 -> 14.40; high-priority lanes 14.83 / 14.25; long videos and frames left in
+    HBM: no difference).  NOT the default: with several processes on one GPU (tests/test_hip_parity.py: four ranks next to the test
+    process) the low-priority queues are scheduled erratically -- passes of 3.5 to 24.6 ms where torch's streams give 7.0 +- 0.4."""
     device = torch.device(device)
     key = (device.index if device.index is not None else torch.cuda.current_device())
     have = _LANE_STREAMS.setdefault(key, [])
     while len(have) < n:
         stream = None
-        if os.environ.get('KBE_LANE_PRIORITY', '1') != '0':
+        if os.environ.get('KBE_LANE_PRIORITY', '0') == '1':
             try:
                 hip = ctypes.CDLL('libamdhip64.so')
                 least, greatest, handle = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p()
