@@ -54,3 +54,16 @@ def test_single_rank_launch_check():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')], env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _line(r.stdout) == {'launcher': 'ok', 'world_size': 1, 'ranks_seen': 1, 'collectives': None, 'scaling_valid': True}
+
+
+def test_roofline_groups_hold_consecutive_cameras_of_the_path():
+    """bench.consecutive_groups: what the scatter's launch is priced on -- every group n consecutive cameras of the path, the last group the
+    path's last n (no group wraps from the last camera to the first: no video does), a path shorter than a launch one group of all of it."""
+    import bench
+    for steps, n in ((75, 12), (20, 12), (1024, 12), (24, 12), (12, 12), (5, 12), (13, 4)):
+        path = list(range(steps))
+        groups = bench.consecutive_groups(path, n)
+        assert all(g == list(range(g[0], g[0] + len(g))) for g in groups), (steps, n)            # consecutive, no wrap
+        assert all(len(g) == min(n, steps) for g in groups), (steps, n)
+        assert sorted(set(c for g in groups for c in g)) == path, (steps, n)                       # every camera of the path is in some group
+        assert len(groups) == max(1, -(-steps // n)) and groups[-1][-1] == steps - 1, (steps, n)
