@@ -293,6 +293,27 @@ def test_crop_resize_matches_written_algorithm(K, oracle):
         assert np.array_equal(out, oracle.crop_resize_u8(f, cw, ch))
 
 
+def test_crop_resize_properties_at_full_sizes(K):
+    """Size-independent properties of getRectSubPix + resize on the device at BASELINE's frame sizes (the oracle is compared at 1024^2
+    above; 2048^2 takes it minutes): a constant frame stays that constant (both steps' weights sum to one and every rounding is exact
+    on equal taps), a two-valued frame stays within its two values, and the result does not depend on what lies outside the window
+    the crop reads (common.crop_window: the rectangle kbe_render_video fills holes in)."""
+    from ken_burns_effect_amd import common
+    g = torch.Generator(device='cuda').manual_seed(11)
+    for (H, W, cw, ch) in [(1024, 1024, 921, 921), (1024, 1024, 920, 920), (2048, 2048, 1843, 1843), (2048, 2048, 1740, 1741), (1080, 1920, 1728, 972), (333, 517, 401, 299)]:
+        for v in (0, 1, 127, 255):
+            out = K.crop_resize_u8(torch.full((H, W, 3), v, dtype=torch.uint8, device='cuda'), cw, ch)
+            assert out.shape == (H, W, 3) and bool((out == v).all()), (H, W, cw, ch, v)
+        two = (torch.rand(H, W, 3, device='cuda', generator=g) > 0.5).to(torch.uint8) * 200 + 20
+        out = K.crop_resize_u8(two, cw, ch)
+        assert int(out.min()) >= 20 and int(out.max()) <= 220, (H, W, cw, ch)
+        x0, y0, x1, y1 = common.crop_window(W, H, cw, ch)
+        noise = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device='cuda', generator=g)
+        other = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device='cuda', generator=g)
+        other[y0:y1 + 1, x0:x1 + 1] = noise[y0:y1 + 1, x0:x1 + 1]
+        assert torch.equal(K.crop_resize_u8(noise, cw, ch), K.crop_resize_u8(other, cw, ch)), (H, W, cw, ch)
+
+
 # ---------------------------------------------------------------------------------------
 # whole frames
 # ---------------------------------------------------------------------------------------
