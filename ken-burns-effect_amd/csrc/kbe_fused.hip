@@ -1078,8 +1078,9 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
         if (!KBE_SHARED_LISTS || m < 2 || !(near_depth > 0.0)) return P;
         // a sub-group's list is longer than a frame's own, and a list beyond LIST_CAP sends its tile down the slow path: only
         // clouds whose AVERAGE list (1.55 candidates per point of the tile's share, in sub-blocks) leaves a factor of four to
-        // the capacity share (the bench cloud: 54 of 512; 16.8 M points on 2048^2: 198, its densest tiles 480-500 -- shared
-        // they reached 515-555 and eighteen tiles of a video scanned the whole cloud)
+        // the capacity share (the bench cloud: 54 of 2048; 16.8 M points on 2048^2: 198, its densest tiles 480-500 -- with
+        // lists of 512, until round 5, shared lists reached 515-555 there and eighteen tiles of a video scanned the whole cloud;
+        // with 2048 such a cloud may share: measured the same with and without, 288.7 us per frame)
         const Scratch& sc = g[0].sc;
         if (1.55 * (double) pc.Np / kCloudSub / ((double) sc.tiles_x * sc.tiles_y) > LIST_CAP / 4.0) return P;
         const Camera& c0 = g[0].cam;
