@@ -224,6 +224,9 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
  * measurements; same frames.  (Until ABI 9 the library read an environment variable at every launch instead.) */
 #define KBE_STAGE_FUSED_LEAN 1024
 #define KBE_STAGE_FUSED_ROOMY 2048
+/* ... and in a third form (round 6, kbe_fused.hip: frame_body_acc): no records in LDS at all -- two passes over the tile's candidate
+ * list, the z-tested sums added to accumulator planes in LDS by ds_add_f32.  Any number of points per pixel in one round. */
+#define KBE_STAGE_FUSED_ACC 4096
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
@@ -383,6 +386,7 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
 /* fused route: force the lean / the roomy build of the tile launches (KBE_STAGE_FUSED_LEAN / _ROOMY for every frame) */
 #define KBE_VIDEO_FUSED_LEAN 2048
 #define KBE_VIDEO_FUSED_ROOMY 4096
+#define KBE_VIDEO_FUSED_ACC 16384    /* KBE_STAGE_FUSED_ACC for every frame */
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,

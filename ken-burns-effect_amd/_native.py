@@ -186,12 +186,11 @@ def _stream():
 
 
 def fused_build_bits(video=False):
-    """KBE_FUSED_CAP=lean|roomy (tests, measurements): the flag that forces one build of the fused route's tile launches
-    (KBE_STAGE_FUSED_LEAN / _ROOMY, or the kbe_render_video form).  The environment is read HERE, per call; the library reads none."""
+    """KBE_FUSED_CAP=lean|roomy|acc (tests, measurements): the flag that forces one build of the fused route's tile launches
+    (KBE_STAGE_FUSED_LEAN / _ROOMY / _ACC, or the kbe_render_video form).  The environment is read HERE, per call; the library reads none."""
     cap = os.environ.get('KBE_FUSED_CAP')
-    if cap not in ('lean', 'roomy'):
-        return 0
-    return ((2048 if cap == 'lean' else 4096) if video else (1024 if cap == 'lean' else 2048))
+    bits = {'lean': (1024, 2048), 'roomy': (2048, 4096), 'acc': (4096, 16384)}.get(cap)
+    return bits[1 if video else 0] if bits else 0
 
 
 HANDOFF_DEFAULT = 'sdma'    # measured (profiles/r05_handoff_sdma.txt): 20 frames 14.1 k -> 14.5-14.8 k frames/s, 75 frames 16.4-16.5 -> 16.5-16.6 k, long videos equal (KBE_HANDOFF=sdma|blit)

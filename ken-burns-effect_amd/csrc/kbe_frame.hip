@@ -1387,7 +1387,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                         (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
                                         KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags | ((flags & KBE_VIDEO_FUSED_LEAN) ? KBE_STAGE_FUSED_LEAN : 0) |
-                                        ((flags & KBE_VIDEO_FUSED_ROOMY) ? KBE_STAGE_FUSED_ROOMY : 0), crop ? rect : nullptr, lane_frames[l]++ & 1,
+                                        ((flags & KBE_VIDEO_FUSED_ROOMY) ? KBE_STAGE_FUSED_ROOMY : 0) | ((flags & KBE_VIDEO_FUSED_ACC) ? KBE_STAGE_FUSED_ACC : 0), crop ? rect : nullptr, lane_frames[l]++ & 1,
                                         (kbe_stream_t) ls[l]);
         else {
             // a lane's frames alternate between the two z-buffers (A, B, A, ...), each clearing the other's in its tile
@@ -1469,7 +1469,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                     nt[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), carve(scr, W, H), scratch_place(scr, W, H), k & 1, nullptr, nullptr, nullptr, nullptr, nullptr, k };
                 }
             }
-            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0), near_depth);
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_ACC) ? 3 : ((flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0)), near_depth);
             lane_placed[l] = n_next > 0;
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };

@@ -21,29 +21,42 @@ _CLOUD_KEYS = ('tensorInpaPoints', 'tensorInpaImage', 'tensorInpaDepth')
 _SCALAR_KEYS = ('dblFocal', 'dblBaseline', 'intWidth', 'intHeight')
 
 
+NUMA_BIND = {'node': None, 'reason': 'not attempted'}     # what the last bind_to_gpu_numa_node call did (tools/scale_report.py prints it per rank)
+
+
 def bind_to_gpu_numa_node(device_index):
     """Best effort: restrict this process to the CPUs of the NUMA node its GPU hangs off, BEFORE it allocates the pinned
     buffers its frames land in (first touch then places them on that node).  On an 8-GPU node every rank pushes ~53 GB/s of
     frames into host memory; landing them on the other socket would put half the node's traffic on the inter-socket
-    links.  Returns the node number, or None when the topology cannot be read (then nothing is changed)."""
-    import os
+    links.  Returns the node number, or None when the topology cannot be read (then nothing is changed) -- and says which of
+    the two it was, and why, in ``NUMA_BIND`` (a rank that could not bind is reported by the bench line and by
+    tools/scale_report.py instead of passing silently: VERDICT r5 item 7)."""
+    def done(node, reason):
+        NUMA_BIND['node'], NUMA_BIND['reason'] = node, reason
+        return node
     try:
         props = torch.cuda.get_device_properties(device_index)
         bdf = '%04x:%02x:%02x.0' % (getattr(props, 'pci_domain_id', 0), props.pci_bus_id, props.pci_device_id)
+    except Exception as e:
+        return done(None, 'no PCI address for device %r (%s)' % (device_index, type(e).__name__))
+    try:
         node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
-        if node < 0:
-            return None
+    except Exception as e:
+        return done(None, 'no /sys/bus/pci/devices/%s/numa_node (%s)' % (bdf, type(e).__name__))
+    if node < 0:
+        return done(None, 'the kernel reports no NUMA node for %s (a single-node host, or a virtual function)' % bdf)
+    try:
         cpus = set()
         for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
             lo, _, hi = part.partition('-')
             cpus.update(range(int(lo), int(hi or lo) + 1))
         allowed = cpus & os.sched_getaffinity(0)
         if not allowed:
-            return None
+            return done(None, "none of node %d's CPUs is in this process's affinity mask (a cpuset from the launcher)" % node)
         os.sched_setaffinity(0, allowed)
-        return node
-    except Exception:
-        return None
+        return done(node, 'bound to %d CPUs of node %d' % (len(allowed), node))
+    except Exception as e:
+        return done(None, 'node %d: %s' % (node, type(e).__name__))
 
 
 def world():
@@ -65,10 +78,11 @@ def shard_indices(n, rank, world_size, shape=None):
     'dealt<k>' (e.g. 'dealt2'): runs of k consecutive frames dealt to the ranks in turn.
     Measured as an 8-way share of a 128- and a 75-frame 1024^2 video on one GPU (tools/shard_shapes.py; every rank of a node
     has its own GPU and link, so a share rendered alone is what that rank would do), the video at its slowest rank's pace,
-    delivered / left in HBM, k frames/s over 8 GPUs: 128 frames: round-robin 108 / 267, block 106 / 249, dealt4 110 / 272,
-    dealt2 111 / 275; 75 frames: round-robin 93 / 229, block 92 / 213, dealt4 84 / 197 (12 : 8 frames), dealt2 92 / 220.
+    delivered / left in HBM, k frames/s over 8 GPUs (the round's last collection, the figures DESIGN.md section 6 quotes):
+    128 frames: round-robin 114 / 277, block 111 / 261, dealt4 111 / 280, dealt2 114 / 278; 75 frames: round-robin 98 / 233,
+    block 94 / 215, dealt4 85 / 197 (12 : 8 frames), dealt2 97 / 226.
     Round-robin is within 2 % of the best everywhere and never the worst.  KBE_SHARD_SHAPE overrides."""
-    shape = shape or os.environ.get('KBE_SHARD_SHAPE', SHARD_SHAPE)
+    shape = shard_shape(shape)
     if shape == 'round-robin':
         return list(range(rank, n, world_size))
     if shape.startswith('dealt'):           # 'dealt4': runs of 4 consecutive frames dealt to the ranks in turn
@@ -164,13 +178,25 @@ def measure_delivery_lanes(objectSettings, objectCommon):
     return lanes
 
 
+def shard_shape(shape=None):
+    """The shard shape a call uses: the argument, else KBE_SHARD_SHAPE, else SHARD_SHAPE -- resolved ONCE per video
+    (process_kenburns_sharded) and handed to shard_steps and gather_frames alike, so that the two cannot disagree."""
+    return shape or os.environ.get('KBE_SHARD_SHAPE', SHARD_SHAPE)
+
+
 def gather_frames(local_frames, indices, total, device, dst=0, shape=None):
     """Collects per-rank uint8 frames [n_local,H,W,3] on rank `dst` in original step order (`shape`: the one the frames were
-    sharded by).  Returns the full [total,H,W,3] tensor on `dst`, None elsewhere."""
+    sharded by).  Returns the full [total,H,W,3] tensor on `dst`, None elsewhere.  Every rank pads its share to the LARGEST
+    share of the shape (dealt runs hand some ranks more than ceil(total / world_size) frames: 75 frames over 8 ranks in runs
+    of 4 is 12 : 8)."""
     rank, world_size = world()
     if world_size == 1 and not (dist.is_initialized() and single_rank_collectives()):
         return local_frames
-    per = (total + world_size - 1) // world_size
+    shape = shard_shape(shape)
+    shares = [shard_indices(total, r, world_size, shape) for r in range(world_size)]
+    if local_frames.shape[0] != len(shares[rank]):
+        raise ValueError('rank %d holds %d frames, shard shape %r gives it %d of %d' % (rank, local_frames.shape[0], shape, len(shares[rank]), total))
+    per = max(1, max(len(i) for i in shares))
     H, W = local_frames.shape[1:3]
     padded = torch.zeros(per, H, W, 3, dtype=torch.uint8, device=device)
     padded[:local_frames.shape[0]] = local_frames.to(device)
@@ -179,8 +205,7 @@ def gather_frames(local_frames, indices, total, device, dst=0, shape=None):
     if rank != dst:
         return None
     out = torch.empty(total, H, W, 3, dtype=torch.uint8, device=device)
-    for r in range(world_size):
-        idx = shard_indices(total, r, world_size, shape)
+    for r, idx in enumerate(shares):
         if idx:
             out[idx] = bucket[r][:len(idx)]
     return out
@@ -212,7 +237,8 @@ def _process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, devic
     if rank == 0 and world_size > 1 and not gather:
         measure_delivery_lanes(objectSettings, objectCommon)
     broadcast_cloud(objectCommon, device)
-    idx, steps = shard_steps(objectSettings['dblSteps'], rank, world_size)
+    shape = shard_shape()                   # once: the sharding and the gather below use the same one
+    idx, steps = shard_steps(objectSettings['dblSteps'], rank, world_size, shape)
     local_settings = dict(objectSettings, dblSteps=steps)
     crop = common.crop_size(objectSettings) if objectSettings.get('boolCrop', True) else None
     cameras = common.frame_cameras(local_settings, objectCommon)
@@ -220,5 +246,5 @@ def _process_kenburns_sharded(objectSettings, objectCommon, moduleInpaint, devic
         frames = common.render_frames(cameras, objectCommon, crop)
         return idx, [frames[i] for i in range(frames.shape[0])]
     frames = common.render_frames(cameras, objectCommon, crop, keep_on_device=True)
-    full = gather_frames(frames, idx, len(objectSettings['dblSteps']), device)
+    full = gather_frames(frames, idx, len(objectSettings['dblSteps']), device, shape=shape)
     return None if full is None else [f for f in full.cpu().numpy()]

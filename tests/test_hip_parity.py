@@ -709,7 +709,7 @@ def test_lean_and_roomy_builds_of_the_tile_launch_render_the_same_frames(K, monk
     cams = [(512.0, (0.4 * i - 2.0, 1.0 - 0.2 * i, -1.5 * i)) for i in range(10)]
     groups = [cams[0:4], cams[4:9], cams[9:10]]
     frames = {}
-    for build in ('lean', 'roomy'):
+    for build in ('lean', 'roomy', 'acc'):
         monkeypatch.setenv('KBE_FUSED_CAP', build)
         got = []
         for g in groups:
@@ -730,12 +730,13 @@ def test_lean_and_roomy_builds_of_the_tile_launch_render_the_same_frames(K, monk
             d = np.abs(c(buf).astype(np.int32) - got[i].astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() < 2e-3, '%s, group %d pipelined: max %d, %.2e differ' % (build, i, d.max(), (d > 0).mean())
         frames[build] = got
-    for a, b in zip(frames['lean'], frames['roomy']):
-        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
-        assert a.any() and d.max() <= 1 and (d > 0).mean() < 2e-3, 'lean against roomy: max %d, %.2e differ' % (d.max(), (d > 0).mean())
+    for other in ('roomy', 'acc'):
+        for a, b in zip(frames['lean'], frames[other]):
+            d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+            assert a.any() and d.max() <= 1 and (d > 0).mean() < 2e-3, 'lean against %s: max %d, %.2e differ' % (other, d.max(), (d > 0).mean())
 
 
-@pytest.mark.parametrize('build', ['lean', 'roomy', 'no_ahead', 'dense', 'delivered'])
+@pytest.mark.parametrize('build', ['lean', 'roomy', 'no_ahead', 'dense', 'delivered', 'acc', 'acc_no_ahead', 'acc_dense', 'acc_delivered'])
 def test_every_instantiation_of_the_tile_launch_against_the_oracle(K, oracle, monkeypatch, build):
     """The tile launch of the fused route is ONE template in nine instantiations (kbe_fused.hip: lean / roomy / dense x a launch that
     places ahead or not x one frame or a group).  The other tests of the group launches compare HIP with HIP; this one holds each
@@ -751,6 +752,9 @@ def test_every_instantiation_of_the_tile_launch_against_the_oracle(K, oracle, mo
     monkeypatch.setenv('KBE_FUSED', '1')
     monkeypatch.setenv('KBE_FILL_GROUP', '12')
     monkeypatch.setenv('KBE_LANES', '1')                # one lane: groups of 12, 12, 2 frames follow one another, each launch placing the next group
+    if build.startswith('acc'):                         # the launch without records (frame_body_acc), in the same shapes
+        monkeypatch.setenv('KBE_FUSED_CAP', 'acc')
+        build = build[4:] or 'acc'
     if build in ('lean', 'roomy'):
         monkeypatch.setenv('KBE_FUSED_CAP', build)
     if build == 'no_ahead':

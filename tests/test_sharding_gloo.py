@@ -140,6 +140,57 @@ def test_eight_ranks_render_a_75_frame_video_as_one_process_does(tmp_path):
     assert np.array_equal(np.load(str(tmp_path / 'gathered.npy')), single), 'frames gathered on rank 0'
 
 
+def _worker_shape(rank, world_size, port, out_dir, n_frames, shape):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1', KBE_SHARD_SHAPE=shape)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from ken_burns_effect_amd import common, sharding
+        from oracle import kbe_oracle
+        common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+        settings, oc = _scene()
+        settings['dblSteps'] = [i / (n_frames - 1.0) for i in range(n_frames)]
+        if rank != 0:
+            oc = {}
+        else:
+            common._reset_inpa(oc)
+        full = sharding.process_kenburns_sharded(settings, oc, None, torch.device('cpu'), gather=True)
+        if rank == 0:
+            np.save(os.path.join(out_dir, 'gathered_%s.npy' % shape), np.stack(full))
+        else:
+            assert full is None
+        # a share that is not what the shape gives this rank is refused, not padded into the wrong rows
+        if rank == 0:
+            with pytest.raises(ValueError):
+                sharding.gather_frames(torch.zeros(1, 4, 4, 3, dtype=torch.uint8), [0], n_frames, torch.device('cpu'), shape=shape)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shape,largest', [('block', 5), ('dealt4', 7), ('dealt2', 6)])
+def test_gathered_video_under_every_shard_shape(tmp_path, shape, largest):
+    """the gather padded every rank's share to ceil(total / world_size) frames, which a dealt shape exceeds (19 frames
+    over 4 ranks in runs of 4: 7 : 4 : 4 : 4 against ceil = 5) -- the padded copy then failed on the shapes.  The pad is now the
+    LARGEST share of the shape, resolved once per video; the gathered video equals one process's under every shape."""
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import common, sharding
+    from oracle import kbe_oracle
+    n_frames, world_size = 19, 4
+    assert max(len(sharding.shard_indices(n_frames, r, world_size, shape)) for r in range(world_size)) == largest
+    assert sorted(i for r in range(world_size) for i in sharding.shard_indices(n_frames, r, world_size, shape)) == list(range(n_frames))
+    mp.spawn(_worker_shape, args=(world_size, _free_port(), str(tmp_path), n_frames, shape), nprocs=world_size, join=True)
+    common._kernel_set = kbe_oracle.OracleKernels('jacobi')
+    try:
+        settings, oc = _scene()
+        settings['dblSteps'] = [i / (n_frames - 1.0) for i in range(n_frames)]
+        common._reset_inpa(oc)
+        single = np.stack(common.process_kenburns(settings, oc, None))
+    finally:
+        common._kernel_set = None
+    assert np.array_equal(np.load(str(tmp_path / ('gathered_%s.npy' % shape))), single)
+
+
 def _worker_one(rank, world_size, port, out_path):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), KBE_SINGLE_RANK_COLLECTIVES='1')
     sys.path.insert(0, ROOT)
