@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define KBE_ABI_VERSION 10
+#define KBE_ABI_VERSION 11
 
 /* the library is built with -fvisibility=hidden; only these entry points are exported */
 #if defined(__GNUC__)
@@ -224,9 +224,6 @@ KBE_API int kbe_render_frame(const float* points, const float* image, const floa
  * measurements; same frames.  (Until ABI 9 the library read an environment variable at every launch instead.) */
 #define KBE_STAGE_FUSED_LEAN 1024
 #define KBE_STAGE_FUSED_ROOMY 2048
-/* ... and in a third form (round 6, kbe_fused.hip: frame_body_acc): no records in LDS at all -- two passes over the tile's candidate
- * list, the z-tested sums added to accumulator planes in LDS by ds_add_f32.  Any number of points per pixel in one round. */
-#define KBE_STAGE_FUSED_ACC 4096
 KBE_API int kbe_render_frame_stages(const float* points, const float* image, const float* depth, int N, int W,
                                     int H, double focal, double baseline, const float* shift3, void* scratch,
                                     uint8_t* frame_u8, float* render_f32, float* existing_f32, float* zee_f32,
@@ -379,21 +376,34 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * (hsa_amd_memory_async_copy_on_engine; the copy's dependency signal is released and its completion signal awaited by one-lane
  * kernels in the lanes' streams, so the call stays asynchronous and `stream` still sees every frame delivered) instead of the
  * runtime's hipMemcpyAsync, which is a blit kernel on the compute units.  The engine takes the groups in order: no turns.
- * Falls back to hipMemcpyAsync when HSA does not report an engine for the two buffers.  A completion signal that has not fired
- * after seconds of polling is a dead engine: the polling kernel traps and `stream`'s next synchronisation fails.  The one piece of process-wide state the
- * library keeps belongs to this flag: a pool of HSA signals, reused once the call that used them has run to its end. */
+ * Falls back to hipMemcpyAsync when HSA does not report an engine for the two buffers (or refuses a copy: the rest of the video then
+ * leaves through the runtime, the lanes taking turns again).  A completion signal that has not fired after 4 s of polling is a dead or
+ * a stalled engine: the polling kernel gives up, stores into a host-visible error word and RETURNS (nothing traps, the process lives) --
+ * kbe_video_handoff_status() reports it, and a caller that needs to know its frames have landed asks it after synchronising `stream`.
+ * An error INSIDE the call (a launch that fails behind a copy already on the engine) returns only after every such copy has been
+ * released and has completed: no copy of a failed call outlives it or keeps waiting.  The one piece of process-wide state the library
+ * keeps belongs to this flag: a pool of HSA signals, reused once the call that used them has run to its end, and the error word.
+ * Needs an HSA runtime with hsa_amd_memory_async_copy_on_engine (ROCm >= 6.0; libkbe_hip.so links libhsa-runtime64). */
 #define KBE_VIDEO_SDMA 8192
 /* fused route: force the lean / the roomy build of the tile launches (KBE_STAGE_FUSED_LEAN / _ROOMY for every frame) */
 #define KBE_VIDEO_FUSED_LEAN 2048
 #define KBE_VIDEO_FUSED_ROOMY 4096
-#define KBE_VIDEO_FUSED_ACC 16384    /* KBE_STAGE_FUSED_ACC for every frame */
 #define KBE_VIDEO_FILL_PAIRS KBE_VIDEO_FILL_GROUP(2)
+/* TEST HOOK (with KBE_VIDEO_SDMA): the hand-off of the video's second transfer group (its only one, if it has one) fails AFTER its copy
+ * has been enqueued on the engine, the way a failed launch of the releasing kernel would: the call returns KBE_E_LAUNCH, through the same
+ * clean-up a real failure takes (tests/test_hip_parity.py: the next video in the process is delivered intact, nothing is written into
+ * the failed call's buffer after it has returned).  Costs nothing when not set. */
+#define KBE_VIDEO_INJECT_FAULT 32768
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
                              int raster_w, int raster_n, const void* packed, double cloud_focal, int flags,
                              kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams,
                              double near_depth);
+/* KBE_OK, or KBE_E_LAUNCH once a KBE_VIDEO_SDMA hand-off of this process has given up waiting for its engine (sticky: the engine is not
+ * used again; kbe_last_error says so).  Call it after synchronising the stream a delivered video was enqueued on: on the error it first
+ * waits on the host, for seconds at most, for the copies that may still be under way, so that the caller can free its buffer afterwards. */
+KBE_API int kbe_video_handoff_status(void);
 
 /* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where
  * point i of points[B,3,N] + shift[B,3] (a DEVICE array, the tensorShift of :690) owns the pixel its z-splat

@@ -21,10 +21,10 @@ SYMBOLS = (
     'kbe_abi_version', 'kbe_last_error', 'kbe_device_info', 'kbe_selftest_err', 'kbe_selftest_division', 'kbe_zkeys_clear', 'kbe_zsplat', 'kbe_zkeys_decode',
     'kbe_degrid', 'kbe_degrid_serial', 'kbe_accumulate', 'kbe_normalize', 'kbe_render_pointcloud', 'kbe_fill_disocclusion',
     'kbe_frame_scratch_bytes', 'kbe_frame_scratch_init', 'kbe_render_frame', 'kbe_render_frame_stages', 'kbe_render_frame_group', 'kbe_cloud_pack_bytes', 'kbe_cloud_pack', 'kbe_render_frame_fused', 'kbe_render_frame_group_fused', 'kbe_render_frame_group_ahead_ok', 'kbe_render_frame_group_ahead', 'kbe_video_scratch_stride', 'kbe_video_stage_bytes', 'kbe_render_video', 'kbe_render_pointcloud_tiled', 'kbe_generate_mask', 'kbe_frame_u8', 'kbe_crop_resize_u8', 'kbe_depth_to_points', 'kbe_shift_points',
-    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act', 'kbe_frame_scratch_init_sets',
+    'kbe_spatial_filter', 'kbe_laplacian_valid', 'kbe_pconv_epilogue', 'kbe_prelu_mask', 'kbe_bias_act', 'kbe_upsample2x_act', 'kbe_frame_scratch_init_sets', 'kbe_video_handoff_status',
 )
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_LANES = 8          # KBE_MAX_LANES
 DEFAULT_LANES = 4      # streams the frame loop spreads consecutive frames over (env KBE_LANES)
 FUSED_MAX_DENSITY = 20.0         # clouds up to this many points per pixel take the fused scatter by default (KBE_FUSED=auto).  Round 5: a tile's candidate list holds 2048
@@ -186,10 +186,10 @@ def _stream():
 
 
 def fused_build_bits(video=False):
-    """KBE_FUSED_CAP=lean|roomy|acc (tests, measurements): the flag that forces one build of the fused route's tile launches
-    (KBE_STAGE_FUSED_LEAN / _ROOMY / _ACC, or the kbe_render_video form).  The environment is read HERE, per call; the library reads none."""
+    """KBE_FUSED_CAP=lean|roomy (tests, measurements): the flag that forces one build of the fused route's tile launches
+    (KBE_STAGE_FUSED_LEAN / _ROOMY, or the kbe_render_video form).  The environment is read HERE, per call; the library reads none."""
     cap = os.environ.get('KBE_FUSED_CAP')
-    bits = {'lean': (1024, 2048), 'roomy': (2048, 4096), 'acc': (4096, 16384)}.get(cap)
+    bits = {'lean': (1024, 2048), 'roomy': (2048, 4096)}.get(cap)
     return bits[1 if video else 0] if bits else 0
 
 
@@ -733,6 +733,8 @@ class HipKernels:
         flags |= fused_build_bits(video=True)               # KBE_FUSED_CAP: KBE_VIDEO_FUSED_LEAN / _ROOMY
         if not host_out.is_cuda and batch < 0 and handoff_by_sdma():
             flags |= 8192                                   # KBE_VIDEO_SDMA
+            if os.environ.get('KBE_INJECT_HANDOFF_FAULT') == '1':
+                flags |= 32768                              # KBE_VIDEO_INJECT_FAULT (test hook: tests/test_hip_parity.py)
         keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again
         scratch = state['scratch']
         if group > 1:
@@ -758,6 +760,11 @@ class HipKernels:
                                               _ptr(state['packed'], torch.uint8) if fused else None, _d(state['cloud_focal']),
                                               _i(flags), _stream(), copy_stream, _i(lanes), lane_streams, _d(self.near_depth(state) if fused else 0.0)), 'kbe_render_video')
         return host_out
+
+    def handoff_status(self):
+        """After synchronising a delivered video's stream: raises KbeError when an SDMA hand-off of this process gave up waiting for its
+        engine (kbe_video_handoff_status: the frames of that video are not all in host memory)."""
+        self._check(self.lib.kbe_video_handoff_status(), 'kbe_video_handoff_status')
 
     def generate_mask_raw(self, points, shift, W, H, focal, baseline, want_tables=False):
         """generate_mask's kernel (common.py:696-817) -> masks [B,1,N] (and zee [B,1,H,W], ids [B,H,W] int32)."""

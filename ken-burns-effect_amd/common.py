@@ -341,6 +341,8 @@ def render_frames(cameras, objectCommon, crop=None, keep_on_device=False, host_o
             return K.render_video(state, cameras, objectCommon['dblBaseline'], crop, host_out=out)[:n]
         out = K.render_video(state, cameras, objectCommon['dblBaseline'], crop, host_out=host_out, overlap=overlap, batch=batch)
         torch.cuda.current_stream().synchronize()
+        if hasattr(K, 'handoff_status'):
+            K.handoff_status()          # a hand-off that gave up on its engine is an error here, not a video with stale frames in it
         return out.numpy()
     out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device)
     rect = None if crop is None else crop_window(W, H, crop[0], crop[1])

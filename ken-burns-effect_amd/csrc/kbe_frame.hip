@@ -33,7 +33,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -743,11 +745,12 @@ __global__ void __launch_bounds__(64) k_signal_release(volatile int64_t* value)
     __threadfence_system();
     __hip_atomic_store((int64_t*) value, (int64_t) 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// bounded (SDMA_MAX_WAIT of the 100 MHz wall clock: 4 s -- a video's groups take milliseconds): an engine that never reports is a dead
-// device, and a kernel that polls for ever would hide that.  Giving up is an ERROR the caller must see -- the frames of that group
-// are not in its memory: the kernel traps, and the stream's next synchronisation reports the failed launch instead of a video with
-// stale frames in it
-__global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, unsigned long long max_ticks)
+// bounded (SDMA_WAIT_SECONDS of the device's wall clock -- the rate is asked of the runtime, sdma_wait_ticks -- where a video's groups take
+// milliseconds): an engine that never reports is a dead or a stalled device, and a kernel that polls for ever would hide that.  Giving up
+// is an ERROR the caller must see -- the frames of that group are not in its memory -- but not one to kill the process for (a trap raises
+// an HSA queue exception and the runtime aborts: ADVICE r5): the kernel stores 1 into the pool's host-visible error word and returns.
+// kbe_video_handoff_status() reports it (sticky) and waits on the host for the copies still under way; calls after it keep off the engine.
+__global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, unsigned long long max_ticks, int* gave_up)
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -755,22 +758,29 @@ __global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, uns
         if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) return;
         __builtin_amdgcn_s_sleep(16);
     } while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks);
-    __builtin_trap();
+    __hip_atomic_store(gave_up, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-constexpr unsigned long long SDMA_MAX_WAIT = 400000000ull;
+#ifndef KBE_SDMA_WAIT_SECONDS
+#define KBE_SDMA_WAIT_SECONDS 4.0
+#endif
 #ifndef KBE_SDMA_TWO_ENGINES
 #define KBE_SDMA_TWO_ENGINES 0      // (1: consecutive groups alternate between two engines -- measured slower end to end, see sdma_open)
 #endif
 
-struct SdmaPair { hsa_signal_t dep, fin; volatile int64_t* dep_value; volatile int64_t* fin_value; };     // the signals and where their values live
+struct SdmaPair {                       // the signals of one copy and where their values live
+    hsa_signal_t dep, fin; volatile int64_t* dep_value; volatile int64_t* fin_value;
+    bool released;                      // this use: the kernel that releases `dep` is known to be in a stream (else: the error path releases it from the host)
+};
 struct SdmaGeneration { hipEvent_t done; std::vector<SdmaPair> pairs; };
 struct SdmaRoute { hsa_agent_t gpu, cpu; uint32_t engines; };          // the engines that copy from `gpu` to `cpu`'s memory (the preferred ones, or all)
 struct SdmaPool {
     std::mutex mu;
-    int state = 0;                              // 0 = not tried, 1 = HSA is up, -1 = it is not
+    int state = 0;                              // 0 = not tried, 1 = HSA is up, -1 = it is not (or an engine stopped answering: no more copies through it)
     std::vector<SdmaPair> idle;
     std::vector<SdmaGeneration> running;
     std::vector<SdmaRoute> routes;
+    int* gave_up = nullptr;                     // pinned host word, device-visible: a k_signal_wait that gave up stores 1 (sticky)
+    unsigned long long wait_ticks = 0;          // KBE_SDMA_WAIT_SECONDS of the device's wall clock
 };
 static SdmaPool& sdma_pool() { static SdmaPool* p = new SdmaPool; return *p; }         // (never destroyed: the signals must not die before the runtime)
 // A signal whose value device code may store to and poll: HSA asks for one that only GPUs consume (no host interrupt behind it -- nothing
@@ -797,8 +807,23 @@ static bool sdma_open(SdmaCall& c, const void* device_buffer, const void* host_b
 {
     SdmaPool& pool = sdma_pool();
     std::lock_guard<std::mutex> lock(pool.mu);
-    if (pool.state == 0) pool.state = hsa_init() == HSA_STATUS_SUCCESS ? 1 : -1;       // (reference-counted: HIP's own runtime holds it up already)
+    if (pool.state == 0) {
+        pool.state = hsa_init() == HSA_STATUS_SUCCESS ? 1 : -1;       // (reference-counted: HIP's own runtime holds it up already)
+        if (pool.state > 0) {
+            // the word a polling kernel that gives up writes, and how many ticks of the wall clock it polls for (s_memrealtime counts at the
+            // rate the runtime reports: 100 MHz on gfx950)
+            int dev = 0, khz = 0;
+            void* w = nullptr;
+            if (hipHostMalloc(&w, 64, hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError(); pool.state = -1; }
+            else {
+                pool.gave_up = (int*) w; *pool.gave_up = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void) hipGetLastError(); khz = 100000; }
+                pool.wait_ticks = (unsigned long long) (KBE_SDMA_WAIT_SECONDS * 1000.0 * (double) khz);
+            }
+        }
+    }
     if (pool.state < 0) return false;
+    if (__atomic_load_n(pool.gave_up, __ATOMIC_ACQUIRE) != 0) return false;      // an engine stopped answering: the runtime's transfers from here on
     hsa_amd_pointer_info_t dinfo = {}, hinfo = {};
     dinfo.size = hinfo.size = sizeof(hsa_amd_pointer_info_t);
     if (hsa_amd_pointer_info(device_buffer, &dinfo, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || dinfo.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
@@ -852,8 +877,35 @@ static bool sdma_pair(SdmaCall& c, SdmaPair& p)
     }
     hsa_signal_store_relaxed(p.dep, 1);
     hsa_signal_store_relaxed(p.fin, 1);
+    p.released = false;
     c.used.push_back(p);
     return true;
+}
+// The call ends in an ERROR with copies on the engine (a launch failed behind them, KBE_VIDEO_INJECT_FAULT): none of them may outlive
+// the call -- the caller, told of the error, may free its buffer the moment we return -- and none may keep waiting for a release
+// that never comes (the engine's queue would be wedged for the process).  Every copy whose release kernel is not known to be in a
+// stream is released from the host (it moves whatever its slots hold: the frames of a failed call are not valid anyway); the lanes
+// run dry; the host polls every completion signal; a pair whose copy has completed is idle again, one whose copy has not after
+// seconds is never reused.
+static void sdma_abort(SdmaCall& c, const hipStream_t* lanes_streams, int lanes)
+{
+    if (c.used.empty()) return;
+    for (SdmaPair& p : c.used) if (!p.released) hsa_signal_store_screlease(p.dep, 0);
+    for (int l = 0; l < lanes; l++) { (void) hipStreamSynchronize(lanes_streams[l]); (void) hipGetLastError(); }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<SdmaPair> done;
+    for (SdmaPair& p : c.used) {
+        bool fin = false;
+        while (!(fin = hsa_signal_load_scacquire(p.fin) <= 0) && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < KBE_SDMA_WAIT_SECONDS)
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (fin) done.push_back(p);
+    }
+    SdmaPool& pool = sdma_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (done.size() != c.used.size()) { __atomic_store_n(pool.gave_up, 1, __ATOMIC_RELEASE); pool.state = -1; }      // an engine that does not answer
+    pool.idle.insert(pool.idle.end(), done.begin(), done.end());
+    c.used.clear();
+    c.ok = false;
 }
 // the call is enqueued: its signals are idle again once `stream` has run past this point
 static void sdma_close(SdmaCall& c, hipStream_t stream)
@@ -1387,7 +1439,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             rc = kbe_render_frame_fused(packed, N, cloud_focal, W, H, focals[i], baseline, shifts + 3 * (size_t) i,
                                         (char*) scratch + (size_t) l * sb, crop ? raw : out, nullptr, nullptr, nullptr, nullptr,
                                         KBE_STAGE_TILES | KBE_STAGE_FILL | fill_flags | ((flags & KBE_VIDEO_FUSED_LEAN) ? KBE_STAGE_FUSED_LEAN : 0) |
-                                        ((flags & KBE_VIDEO_FUSED_ROOMY) ? KBE_STAGE_FUSED_ROOMY : 0) | ((flags & KBE_VIDEO_FUSED_ACC) ? KBE_STAGE_FUSED_ACC : 0), crop ? rect : nullptr, lane_frames[l]++ & 1,
+                                        ((flags & KBE_VIDEO_FUSED_ROOMY) ? KBE_STAGE_FUSED_ROOMY : 0), crop ? rect : nullptr, lane_frames[l]++ & 1,
                                         (kbe_stream_t) ls[l]);
         else {
             // a lane's frames alternate between the two z-buffers (A, B, A, ...), each clearing the other's in its tile
@@ -1469,7 +1521,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                     nt[j] = FusedTarget{ make_camera(W, H, focals[i], baseline, shifts + 3 * (size_t) i), carve(scr, W, H), scratch_place(scr, W, H), k & 1, nullptr, nullptr, nullptr, nullptr, nullptr, k };
                 }
             }
-            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_ACC) ? 3 : ((flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0)), near_depth);
+            launch_frames_fused(ls[l], count, packed, N, cloud_focal, ft, lane_placed[l], n_next, nt, (flags & KBE_VIDEO_FUSED_LEAN) ? 1 : ((flags & KBE_VIDEO_FUSED_ROOMY) ? 2 : 0), near_depth);
             lane_placed[l] = n_next > 0;
             if ((rc = launched("kbe_render_video/scatter"))) return rc;
             FillRect fr = { 0, 0, W - 1, H - 1 };
@@ -1493,22 +1545,27 @@ int kbe_render_video(const float* points, const float* image, const float* depth
     if (!ringed && !per_frame) {
         // host_out is device memory: the last kernel of every frame stores straight into it (the frames stay in HBM)
         if (pairs) {
-            // lane l takes frames l, l + lanes, l + 2 lanes, ... `group` at a time (a first pass counts the frames of every
-            // scratch set: the bucket route must know a set's last frame)
+            // a chunk of group * lanes CONSECUTIVE frames at a time, lane l taking frames base + l * group .. base + l * group + group - 1 of
+            // it (consecutive cameras share candidate lists, kbe_fused.hip: share_plan; until round 5 lane l took frames l, l + lanes,
+            // ...: cameras `lanes` steps apart in every launch).  The LAST, partial chunk -- a short video is nothing else -- is dealt
+            // evenly: ceil(remaining / lanes) consecutive frames per lane, so that every lane has work (eight frames on four
+            // lanes were one launch on one stream).  (A first pass counts the frames of every scratch set: the bucket route must
+            // know a set's last frame.)
             for (int pass = 0; pass < 2 && rc == KBE_OK; pass++) {
                 counting = pass == 0;
-                for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes)
+                for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes) {
+                    const int left = n_frames - base;
+                    const int per = left >= group * lanes ? group : (left + lanes - 1) / lanes;
                     for (int l = 0; l < lanes && rc == KBE_OK; l++) {
                         int idx[KBE_FRAME_JOBS], count = 0;
                         uint8_t* outs[KBE_FRAME_JOBS];
-                        for (int m = 0; m < group; m++) {
-                            // (a launch takes CONSECUTIVE frames -- consecutive cameras share candidate lists, kbe_fused.hip: share_plan;
-                            // until round 5 lane l took frames l, l + lanes, ...: cameras `lanes` steps apart in every launch)
-                            const int i = KBE_HBM_CONSECUTIVE ? base + l * group + m : base + m * lanes + l;
+                        for (int m = 0; m < (KBE_HBM_CONSECUTIVE ? per : group); m++) {
+                            const int i = KBE_HBM_CONSECUTIVE ? base + l * per + m : base + m * lanes + l;
                             if (i < n_frames) { idx[count] = i; outs[count++] = host_out + (size_t) i * fb; }
                         }
                         if (count) rc = render_group(l, count, idx, outs);
                     }
+                }
             }
         } else
         for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = render(i, i % lanes, host_out + (size_t) i * fb);
@@ -1519,7 +1576,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         //                runtime transfer (hipMemcpyAsync) between a gate kernel that waits for the turn and one that
         //                passes it on.
         // (where the rendering binds, not the link, the transfers need no order: a lane that waits for its turn only idles)
-        DeliverCtl* ctl = lanes > 1 && !(flags & KBE_VIDEO_FREE_TRANSFERS) ? (DeliverCtl*) (stage + ctl_offset) : nullptr;
+        DeliverCtl* const ctl_turns = lanes > 1 && !(flags & KBE_VIDEO_FREE_TRANSFERS) ? (DeliverCtl*) (stage + ctl_offset) : nullptr;
+        DeliverCtl* ctl = ctl_turns;
         if (batch == 0) {
             for (int i = 0; i < n_frames && rc == KBE_OK; i++) {
                 const int l = i % lanes, slot = i % slots;
@@ -1574,7 +1632,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 // lane renders its next group while its last one leaves, measured SLOWER: 14.2 k instead of 14.6 k frames/s for 20
                 // frames, 15.9 k instead of 16.6 k for 75 -- a lane then renders the group after next while the other lane still
                 // renders the group the engine waits for)
-                if (lane_fin[l]) { hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_WAIT); lane_fin[l] = nullptr; }
+                if (lane_fin[l]) { hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], sdma_pool().wait_ticks, sdma_pool().gave_up); lane_fin[l] = nullptr; }
                 if (pairs) for (int k = 0; k < nb && rc == KBE_OK; k += group) {
                     int idx[KBE_FRAME_JOBS], count = 0;
                     uint8_t* outs[KBE_FRAME_JOBS];
@@ -1591,8 +1649,11 @@ int kbe_render_video(const float* points, const float* image, const float* depth
 #endif
                 if (!sdma_asked) {
                     sdma_asked = true;
-                    if (sdma_open(sdma, stage, host_out)) ctl = nullptr;        // the engine takes the copies in order: no turns
+                    (void) sdma_open(sdma, stage, host_out);
                 }
+                // the engine takes the copies in order: no turns -- while it takes them (a copy it refuses sends the rest of the video
+                // through the runtime's transfers, which take turns again: ADVICE r5)
+                ctl = sdma.ok ? nullptr : ctl_turns;
                 if (ctl) hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls);
 #if defined(KBE_VIDEO_GPU_TRACE)
                 (void) hipEventRecord(ev_gate[g], ls[l]);
@@ -1603,12 +1664,23 @@ int kbe_render_video(const float* points, const float* image, const float* depth
                 bool sent = false;
                 if (sdma.ok) {
                     SdmaPair p;
-                    if (sdma_pair(sdma, p) && hsa_amd_memory_async_copy_on_engine(host_out + (size_t) i0 * fb, sdma.cpu, base, sdma.gpu, (size_t) nb * fb, 1, &p.dep, p.fin,
-                                                                                  sdma.engine[sdma.sent++ & 1], true) == HSA_STATUS_SUCCESS) {
-                        hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], p.dep_value);
+                    const bool paired = sdma_pair(sdma, p);
+                    if (paired && hsa_amd_memory_async_copy_on_engine(host_out + (size_t) i0 * fb, sdma.cpu, base, sdma.gpu, (size_t) nb * fb, 1, &p.dep, p.fin,
+                                                                      sdma.engine[sdma.sent++ & 1], true) == HSA_STATUS_SUCCESS) {
+                        // the copy is on the engine and waits for its release: from here on an error must go through sdma_abort
+                        const bool inject = (flags & KBE_VIDEO_INJECT_FAULT) && g == (n_groups > 1 ? 1 : 0);
+                        if (!inject) hipLaunchKernelGGL(k_signal_release, dim3(1), dim3(64), 0, ls[l], p.dep_value);
+                        const hipError_t le = inject ? hipErrorLaunchFailure : hipGetLastError();
+                        if (le != hipSuccess) { rc = fail(KBE_E_LAUNCH, inject ? "kbe_render_video: injected hand-off fault (KBE_VIDEO_INJECT_FAULT)" : "kbe_render_video/release", le); break; }
+                        sdma.used.back().released = true;
                         lane_fin[l] = p.fin_value;
                         sent = true;
-                    } else sdma.ok = false;                         // this group and the rest: the runtime's transfers
+                    } else {
+                        // this group and the rest: the runtime's transfers (the pair, if there is one, was never handed to the engine: idle again)
+                        if (paired) { std::lock_guard<std::mutex> lock(sdma_pool().mu); sdma_pool().idle.push_back(sdma.used.back()); sdma.used.pop_back(); }
+                        sdma.ok = false;
+                        if (ctl_turns && !ctl) { ctl = ctl_turns; hipLaunchKernelGGL(k_turn, dim3(1), dim3(64), 0, ls[l], ctl, 0, turn_polls); }
+                    }
                 }
                 const hipError_t e = sent ? hipSuccess : hipMemcpyAsync(host_out + (size_t) i0 * fb, base, (size_t) nb * fb, hipMemcpyDeviceToHost, ls[l]);
                 if (e != hipSuccess) { rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipMemcpyAsync", e); break; }
@@ -1627,7 +1699,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
             // (SDMA) a lane is done when its last group has left: whoever waits for the lanes (join) waits for the frames
             for (int l = 0; l < lanes; l++)
-                if (lane_fin[l]) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], SDMA_MAX_WAIT);
+                if (lane_fin[l] && rc == KBE_OK) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], sdma_pool().wait_ticks, sdma_pool().gave_up);
 #if defined(KBE_VIDEO_GPU_TRACE)
             for (int l = 0; l < lanes; l++) (void) hipStreamSynchronize(ls[l]);
             for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
@@ -1666,11 +1738,32 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             (void) hipEventRecord(copied[half], dc);
         }
     }
+    if (rc != KBE_OK) sdma_abort(sdma, ls, lanes);       // no copy of a failed call outlives it, none keeps waiting for its release
     join();
     sdma_close(sdma, cs);
     destroy();
     if (rc == KBE_OK && !ok) rc = fail(KBE_E_LAUNCH, "kbe_render_video: hipEventCreate");
     return rc;
+}
+
+int kbe_video_handoff_status(void)
+{
+    SdmaPool& pool = sdma_pool();
+    std::unique_lock<std::mutex> lock(pool.mu);
+    if (!pool.gave_up || __atomic_load_n(pool.gave_up, __ATOMIC_ACQUIRE) == 0) return KBE_OK;
+    pool.state = -1;                                    // no more copies through the engine
+    // the copies of calls that are still on record may yet complete: wait for them here, so that the caller may free its buffers
+    std::vector<SdmaGeneration> gens;
+    gens.swap(pool.running);
+    lock.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (SdmaGeneration& g : gens) {
+        for (SdmaPair& p : g.pairs)
+            while (hsa_signal_load_scacquire(p.fin) > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < KBE_SDMA_WAIT_SECONDS)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+        (void) hipEventDestroy(g.done);                 // (their signals are never reused)
+    }
+    return fail(KBE_E_LAUNCH, "kbe_render_video: an SDMA hand-off gave up waiting for its engine -- the frames of that video are not all in host memory; the engine is not used again");
 }
 
 }  // extern "C"

@@ -1018,334 +1018,9 @@ __global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_FRAME_ATTR)) 
     frame_body<KBE_FRAME_JOBS, true, AHEAD_UNITS_DENSE>(KBE_ARGS(FrameJobs), blockIdx.y);
 }
 
-// ---------------------------------------------------------------------------------------
-// THE TILE LAUNCH WITHOUT RECORDS (round 6; `build` 3, KBE_STAGE_FUSED_ACC): two passes over the tile's candidate list
-// instead of one pass that files every point as a 32-byte record in LDS and a gather that walks per-pixel lists of them.
-//   pass 1   the z-splat of frame_body (ds_min_u32 on the winner corner), nothing else: no slot, no list head, no spill;
-//   then     keys -> floats, degrid (common.py:525-568) -- its result goes into a plane WITH A BORDER of -inf around the tile,
-//            as `z + 1` where that sum is exact (FAST tiles), so that the z test of a corner is ONE comparison and a corner
-//            outside the tile fails it by itself;
-//   pass 2   the same points again -- still in the registers pass 1 left them in when the list is one trip long (the usual
-//            case), otherwise pulled once more (the tile has just had them through the L2) -- each lane adds its point's four
-//            z-tested corner contributions (common.py:586-669) to the tile's five accumulator planes IN LDS with ds_add_f32:
-//            twenty fire-and-forget LDS atomics per point on the LDS pipe, which the launch leaves idle, instead of the
-//            gather's ~250 vector instructions per wave on the issue port the launch is bound by;
-//   then     the accumulators are read back and the epilogue of frame_body resolves them.
-// What it no longer has: REC_CAP (any number of records per tile in ONE round: the dense cloud of configs[4] took three
-// rounds through the spill area in HBM), the lean / roomy split, lazy colours, the 32 registers of the gather's look-ahead.
-// The planes: row stride AW = TW + 4 floats, so that the 16 corners a 4 x 4 source quadrant lands on fall on 16 different
-// banks; 18 KB of LDS per workgroup.  The order of a pixel's sum is the order the atomics retire in (as the reference's own
-// atomicAdd, common.py:641; the records' order was the list atomics' order).
-// ---------------------------------------------------------------------------------------
-constexpr int AW = TW + 4, APLANE = (TH + 2) * AW;
-static_assert(APLANE % 4 == 0, "the planes are initialised four floats per store");
-struct AccLds {
-    float plane[6][APLANE];     // [0]: the degridded z (+ 1 on FAST tiles), border -inf; [1..5]: sums of r, g, b, depth, weight.  Pixel (lx, ly) of the tile: [(ly + 1) * AW + lx + 1]
-    float zpre[KH * KW];        // tile + halo: keys during the splat, floats for the degrid, then the epilogue's staging area
-    int odd_z[TILE_THREADS / 64];
-};
-static_assert(offsetof(AccLds, zpre) % 16 == 0 && offsetof(AccLds, odd_z) % 16 == 0, "16-byte words");
-
-__device__ __forceinline__ void lds_fadd(float* p, float v)
-{
-    (void) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // ds_add_f32, no return
-}
-
-// degrid as tile_degrid (kbe_tiles.h), into the bordered plane
-template <class Args>
-__device__ __forceinline__ void acc_degrid(const Args& a, AccLds& L, int tid, int x0, int y0, bool fast)
-{
-    const int W = a.cam.W, H = a.cam.H;
-    float* const zl = L.plane[0];
-    if (fast && !a.zee_pre) {
-#pragma unroll
-        for (int u = 0; u < PIX_PER_THREAD; u++) {
-            const int i = tid + u * TILE_THREADS;
-            const int ly = i / TW, lx = i - ly * TW;
-            const float* z = &L.zpre[(ly + 1) * KW + (lx + 1)];
-            const float nb_a[4] = { z[1], z[KW], z[KW + 1], z[1 - KW] };            // (+1, 0) (0, +1) (+1, +1) (+1, -1)
-            const float nb_d[4] = { z[-1], z[-KW], z[-KW - 1], z[KW - 1] };         // their mirror images
-            const float zd = degrid_pixel_fast(z[0], nb_a, nb_d);
-            zl[(ly + 1) * AW + lx + 1] = zd + 1.0f;                                 // exact: zd in [2^19, 1e6] (plus_one_is_exact)
-            if (a.zee && x0 + lx < W && y0 + ly < H) a.zee[(size_t) (y0 + ly) * W + x0 + lx] = zd;
-        }
-    } else {
-        for (int i = tid; i < TH * TW; i += TILE_THREADS) {
-            const int ly = i / TW, lx = i - ly * TW;
-            const int x = x0 + lx, y = y0 + ly;
-            if (x >= W || y >= H) continue;                                         // (stays -inf: nothing is added there)
-            auto at = [&](int xx, int yy) { return L.zpre[(yy - y0 + 1) * KW + (xx - x0 + 1)]; };
-            const float zd = degrid_pixel(x, y, W, H, at);
-            zl[(ly + 1) * AW + lx + 1] = fast ? zd + 1.0f : zd;
-            if (a.zee) a.zee[(size_t) y * W + x] = zd;
-            if (a.zee_pre) a.zee_pre[(size_t) y * W + x] = at(x, y);
-        }
-    }
-}
-
-#ifndef KBE_ACC_WAVES
-#define KBE_ACC_WAVES 6
-#endif
-template <int J, bool AHEAD, int UNITS = AHEAD_UNITS>
-__device__ __forceinline__ void frame_body_acc(const __attribute__((address_space(4))) FrameJobsT<J>* jp, int job)
-{
-    FrameArgsPtr ap = (FrameArgsPtr) jp->a + job;
-    PackedCloudPtr pcp = &jp->pc;
-    __shared__ AccLds L;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_tile_rot(blockIdx.x, gridDim.x, job);
-    const int tiles_x = ap->tiles_x, tiles_y = ap->tiles_y;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int W = ap->cam.W, H = ap->cam.H;
-    uint32_t* const zk = (uint32_t*) L.zpre;            // the tile's z-buffer as keys until the splat is complete
-    constexpr int WAVES = TILE_THREADS / 64;
-
-    // ---- the list, the points of its first trip and the first units of the next frames' placements: as frame_body
-    constexpr int DEPTH = KBE_SPLAT_DEPTH, SUBS_PER_STEP = 64 / kCloudSub, TRIP = DEPTH * WAVES;
-    int* const tile_count = ap->tile_count;
-    const int count = tile_count[tile * CNT_STRIDE];
-    const bool wide = *ap->bin_flag > bin_budget(tiles_x, tiles_y);
-    const int* const my_list = ap->cand + (size_t) tile * LIST_CAP;
-    const Placement* const place = ap->place;
-    const CloudColour* const colours = pcp->col;
-    const uint32_t last_sub = (uint32_t) (pcp->Np / kCloudSub) - 1u;
-    Placement pl[DEPTH]; CloudColour cc[DEPTH]; int ent[DEPTH];
-    auto fetch_entries = [&](int st0) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) ent[d] = my_list[(uint32_t) min((st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub, LIST_CAP - 1)];
-    };
-    auto fetch_points = [&]() {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const uint32_t o16 = ((min((uint32_t) ent[d], last_sub) * kCloudSub) + (uint32_t) (lane & (kCloudSub - 1))) << 4;
-            pl[d] = *(const Placement*) ((const char*) place + (o16 - (o16 >> 2)));
-            cc[d] = *(const CloudColour*) ((const char*) colours + o16);
-        }
-    };
-    fetch_entries(wave);
-    constexpr int NU = AHEAD ? UNITS : 0;
-    const int n_next = AHEAD ? jp->n_next : 0;
-    const int share_flags = KBE_SHARED_LISTS ? jp->pad_ : 0;
-    const bool ahead = NU > 0 && (int) blockIdx.y < n_next;             // uniform: this row has a frame to place
-    const int a_units = ahead ? pcp->Np / kCloudBlock : 1;
-    const int a_first = blockIdx.x * WAVES + wave, a_step = gridDim.x * WAVES;
-    CloudPoint a_pt[NU > 0 ? NU : 1];
-    ListSlot a_owed[NU > 0 ? NU : 1];
-#pragma unroll
-    for (int d = 0; d < NU; d++) a_pt[d] = *at_offset32(pcp->pd, (uint32_t) (min(a_first + d * a_step, a_units - 1) * kCloudBlock + lane));
-    // LDS: the keys empty (common.py:430), the z plane -inf (its interior is the degrid's to write), the sums zero -- four entries per store
-    {
-        constexpr int ZK4 = KH * KW / 4, P4 = 6 * APLANE / 4, Z4 = APLANE / 4;
-        static_assert((KH * KW) % 4 == 0 && ZK4 <= TILE_THREADS, "four keys per store");
-        const float ninf = -__builtin_inff();
-        float4* const p4 = (float4*) L.plane;
-#pragma unroll
-        for (int u = 0; u < (P4 + TILE_THREADS - 1) / TILE_THREADS; u++) {
-            const int i = tid + u * TILE_THREADS;
-            const float v = (u == 0 && i < Z4) ? ninf : 0.0f;
-            if (i < P4) p4[i] = make_float4(v, v, v, v);
-        }
-        static_assert(Z4 <= TILE_THREADS, "the z plane lies inside the first trip of stores");
-        if (tid < ZK4) ((uint4*) zk)[tid] = make_uint4(KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY, KBE_ZKEY_EMPTY);
-    }
-    if (tid == 0 && blockIdx.x == 0) *ap->bin_flag_next = 0;
-    fetch_points();                                     // in flight across the barrier
-#pragma unroll
-    for (int d = 0; d < NU; d++) a_owed[d] = ListSlot{ -1, 0 };
-    if (ahead) {
-        PlaceArgsPtr na = (PlaceArgsPtr) jp->nx + blockIdx.y;
-        const Camera ncam = load_camera(&na->cam);
-        const ShareMode nshare = share_mode(jp, blockIdx.y, (share_flags & 2) != 0);
-#pragma unroll
-        for (int d = 0; d < NU; d++)
-            if (a_first + d * a_step < a_units)
-                a_owed[d] = place_point_begin(a_pt[d], (a_first + d * a_step) * kCloudBlock + lane, lane, ncam, tiles_x, tiles_y, na->place, na->tile_count, na->cand, na->bin_flag, nshare);
-    }
-    const bool listed = !wide & (count <= LIST_CAP);            // uniform
-    __syncthreads();
-    if (tid == 0) {                                     // ready for the next frame's placements (every wave has its copy of the count)
-        const int sharers = (KBE_SHARED_LISTS && (share_flags & 1)) ? (int) (jp->a_share[job] >> 8) : 1;
-        if (sharers > 1) {
-            if (atomicAdd(&tile_count[tile * CNT_STRIDE + 1], 1) == sharers - 1) { tile_count[tile * CNT_STRIDE + 1] = 0; tile_count[tile * CNT_STRIDE] = 0; }
-        }
-        else tile_count[tile * CNT_STRIDE] = 0;
-    }
-    KBE_STOP_AFTER(1);
-
-    // ---- what the two passes do with one placed point per lane
-    // pass 1: the min-splat of its dblError on the winner corner (common.py:472-506) when that can be a pixel of tile + halo
-    auto splat_z = [&](float ox, float oy, float err, bool ok) {
-        Proj p;
-        p.nwx = (int) floorf(ox); p.nwy = (int) floorf(oy);
-        const int rx = p.nwx - (x0 - 2), ry = p.nwy - (y0 - 2);
-        if (ok & ((unsigned) rx <= (unsigned) (TW + 2)) & ((unsigned) ry <= (unsigned) (TH + 2))) {
-            project_weights(ox, oy, p);
-            const int k = winner_corner_finite(p);
-            const int cx = p.nwx + (k & 1), cy = p.nwy + (k >> 1);
-            const int lx = cx - (x0 - 1), ly = cy - (y0 - 1);
-            if (inside(cx, cy, W, H) & ((unsigned) lx < (unsigned) KW) & ((unsigned) ly < (unsigned) KH))
-                atomicMin((uint32_t*) ((char*) zk + mad_u24((uint32_t) ly, KW * 4u, (uint32_t) lx << 2)), zkey_encode(err));
-        }
-    };
-    // pass 2: its z-tested bilinear contributions (common.py:586-669).  North-west corner (nwx, nwy) in [x0 - 1, x0 + TW - 1] x
-    // [y0 - 1, y0 + TH - 1]: cell (rx, ry) = (nwx - x0 + 1, nwy - y0 + 1) of the bordered planes IS that corner, its neighbours the
-    // other three; a corner outside the tile reads the border's -inf and fails the test, one outside the image but inside a
-    // tile that overhangs the edge collects sums nobody reads.  FAST: the plane holds z + 1 (exact); else z, compared in fp64 (:639).
-    auto accumulate = [&](auto fast_tag, float ox, float oy, float err, bool ok, const CloudColour& c) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        const float fx = floorf(ox), fy = floorf(oy);
-        const int rx = (int) fx - (x0 - 1), ry = (int) fy - (y0 - 1);
-        if (ok & ((unsigned) rx <= (unsigned) TW) & ((unsigned) ry <= (unsigned) TH)) {
-            float* const cell = (float*) ((char*) L.plane + mad_u24((uint32_t) ry, AW * 4u, (uint32_t) rx << 2));
-            const float z[4] = { cell[0], cell[1], cell[AW], cell[AW + 1] };
-            // |fx| < 2^15 here: fx + 1 is (float) (nwx + 1) (common.py:481-484)
-            const float wl = (fx + 1.0f) - ox, wr = ox - fx, wt = (fy + 1.0f) - oy, wb = oy - fy;
-            const float w[4] = { wl * wt, wr * wt, wl * wb, wr * wb };
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool pass = FAST ? (err <= z[k]) : ((double) err <= (double) z[k] + 1.0);
-                if (pass) {
-                    float* const o = cell + (k >> 1) * AW + (k & 1);
-                    lds_fadd(o + 1 * APLANE, c.r * w[k]);                                // :641 product rounded, then added
-                    lds_fadd(o + 2 * APLANE, c.g * w[k]);
-                    lds_fadd(o + 3 * APLANE, c.b * w[k]);
-                    lds_fadd(o + 4 * APLANE, c.depth * w[k]);
-                    lds_fadd(o + 5 * APLANE, w[k]);                                      // the `ones` channel (:429)
-                }
-            }
-        }
-    };
-
-    // ---- pass 1 over the list (the trips of frame_body's splat)
-    const int n_cand = listed ? count : 0;
-    const int n_steps = (n_cand + SUBS_PER_STEP - 1) / SUBS_PER_STEP;
-    int st_last = wave;                                         // the first step of the wave's last trip: what its registers hold afterwards
-    for (int st0 = wave; st0 < n_steps; st0 += TRIP) {          // wave-uniform
-        const bool more = st0 + TRIP < n_steps;
-        if (more) fetch_entries(st0 + TRIP);
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++)
-            if (st0 + d * WAVES < n_steps)
-                splat_z(pl[d].ox, pl[d].oy, pl[d].err, (st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub < n_cand);
-        st_last = st0;
-        if (more) fetch_points();
-    }
-    if (ahead) {                                        // the list entries the placements up front owe: their atomics have returned by now
-        int* const cand_next = ((PlaceArgsPtr) jp->nx + blockIdx.y)->cand;
-#pragma unroll
-        for (int d = 0; d < NU; d++) place_point_end(a_owed[d], (a_first + d * a_step) * kCloudBlock + lane, cand_next);
-    }
-    __syncthreads();
-    KBE_STOP_AFTER(3);
-
-    asm volatile("" : "+s"(ap) :: "memory");
-    TileOut a;
-    a.cam.W = W; a.cam.H = H;
-    a.zee = ap->zee; a.zee_pre = ap->zee_pre;
-    auto decode_z = [&]() {
-        bool band = true;
-        constexpr int ZK4 = KH * KW / 4;
-        if (tid < ZK4) {
-            const uint4 k = ((const uint4*) zk)[tid];
-            ((float4*) L.zpre)[tid] = make_float4(zkey_decode(k.x), zkey_decode(k.y), zkey_decode(k.z), zkey_decode(k.w));
-            const uint32_t lo = min(min(k.x, k.y), min(k.z, k.w)), hi = max(max(k.x, k.y), max(k.z, k.w));
-            band = (lo >= zkey_encode(524288.0f)) & (hi <= zkey_encode(1000000.0f));          // degrid_fast_ok of all four
-        }
-        const unsigned long long odd = __ballot(!band);
-        if (lane == 0) L.odd_z[tid >> 6] = odd != 0ull;
-    };
-    bool fast;
-    if (listed) {
-        decode_z();
-        __syncthreads();
-        fast = lds_tile_is_fast(L);
-        acc_degrid(a, L, tid, x0, y0, fast);
-        __syncthreads();
-        KBE_STOP_AFTER(4);
-        // ---- pass 2, the wave's trips backwards: the last one is still in its registers
-        auto pass2 = [&](auto fast_tag) {
-            for (int st0 = st_last; st0 >= wave && st0 < n_steps; st0 -= TRIP) {           // wave-uniform
-                const bool more = st0 - TRIP >= wave;
-                if (more) fetch_entries(st0 - TRIP);
-#pragma unroll
-                for (int d = 0; d < DEPTH; d++)
-                    if (st0 + d * WAVES < n_steps)
-                        accumulate(fast_tag, pl[d].ox, pl[d].oy, pl[d].err, (st0 + d * WAVES) * SUBS_PER_STEP + lane / kCloudSub < n_cand, cc[d]);
-                if (more) fetch_points();
-            }
-        };
-        if (fast) pass2(std::true_type{});
-        else pass2(std::false_type{});
-    } else {
-        // ---- the slow path (a list that overflowed, an incoherent cloud): the tile scans ALL blocks of the cloud, each block's
-        // node tested inline, once for the z-splat and once more, behind the degrid, for the sums -- exact passes: shift
-        // (common.py:104-109), projection (:447-468), dblError (:470)
-        const FrameArgs* const gp = (const FrameArgs*) ap;      // (struct copies want a generic pointer)
-        const Camera cam = gp->cam;
-        const PackedCloud pc = *(const PackedCloud*) pcp;
-        const int n_blocks = pc.count[0];
-        CullView q;
-        q.g = cam.focal_f / pc.fd;
-        q.sx = cam.has_shift ? cam.sx : 0.0f; q.sy = cam.has_shift ? cam.sy : 0.0f; q.sz = cam.has_shift ? cam.sz : 0.0f;
-        q.Sx = q.sx * pc.fd; q.Sy = q.sy * pc.fd;
-        q.focal = cam.focal_f;
-        q.rx0 = (float) (x0 - 2) - cam.cx_f; q.rx1 = (float) (x0 + TW + 1) - cam.cx_f;
-        q.ry0 = (float) (y0 - 2) - cam.cy_f; q.ry1 = (float) (y0 + TH + 1) - cam.cy_f;
-        auto scan = [&](auto second, auto fast_tag) {
-            for (int b = wave; b < n_blocks; b += WAVES) {      // wave-uniform
-                if (!node_hits(pc.level[0][b], q)) continue;
-                const CloudPoint p = pc.pd[b * kCloudBlock + lane];
-                float x = p.x, y = p.y, z = p.z, ox = 0.0f, oy = 0.0f;
-                apply_shift(cam, x, y, z);
-                const bool ok = project_xy(cam, x, y, z, ox, oy);
-                const float err = project_err_fast(cam, ok ? z : 1024.0f);
-                if constexpr (decltype(second)::value) accumulate(fast_tag, ox, oy, err, ok, pc.col[b * kCloudBlock + lane]);
-                else splat_z(ox, oy, err, ok);
-            }
-        };
-        scan(std::false_type{}, std::false_type{});
-        __syncthreads();
-        decode_z();
-        __syncthreads();
-        fast = lds_tile_is_fast(L);
-        acc_degrid(a, L, tid, x0, y0, fast);
-        __syncthreads();
-        if (fast) scan(std::true_type{}, std::true_type{});
-        else scan(std::true_type{}, std::false_type{});
-    }
-    __syncthreads();                                    // every wave's sums are in
-    KBE_STOP_AFTER(5);
-    PixAcc acc[PIX_PER_THREAD];
-#pragma unroll
-    for (int m = 0; m < PIX_PER_THREAD; m++) {
-        const int q = tid + m * TILE_THREADS;
-        const int ly = q / TW, lx = q - ly * TW;
-        const float* const o = &L.plane[0][(ly + 1) * AW + lx + 1];
-        acc[m].rg.x = o[1 * APLANE]; acc[m].rg.y = o[2 * APLANE]; acc[m].bd.x = o[3 * APLANE]; acc[m].bd.y = o[4 * APLANE]; acc[m].w = o[5 * APLANE];
-    }
-    asm volatile("" : "+s"(ap) :: "memory");
-    a.frame = ap->frame; a.depth = ap->depth; a.mask = ap->mask; a.holes = ap->holes; a.hole_count = ap->hole_count; a.bbox = ap->bbox; a.coarse = ap->coarse;
-    a.render = ap->render; a.existing = ap->existing;
-    tile_epilogue(a, L, acc, tile, x0, y0);
-    if (AHEAD) {
-        // what the waves did not place up front: further units of the row's frame, further frames (groups that grow)
-        asm volatile("" : "+s"(jp) :: "memory");
-        const int n_left = jp->n_next;
-        if (n_left > 0) place_ahead(jp, n_left, jp->a[job].tiles_x, jp->a[job].tiles_y, wave, lane, NU, KBE_SHARED_LISTS && (jp->pad_ & 2) != 0);
-    }
-}
-
-#define KBE_ACC_ATTR amdgpu_waves_per_eu(KBE_ACC_WAVES, KBE_ACC_WAVES)
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_ACC_ATTR)) k_frame_acc(FrameJob1) { frame_body_acc<1, false>(KBE_ARGS(FrameJob1), 0); }
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_ACC_ATTR)) k_frame_ahead_acc(FrameJob1) { frame_body_acc<1, true>(KBE_ARGS(FrameJob1), 0); }
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_ACC_ATTR)) k_frame_group_acc(FrameJobs) { frame_body_acc<KBE_FRAME_JOBS, false>(KBE_ARGS(FrameJobs), blockIdx.y); }
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_ACC_ATTR)) k_frame_group_ahead_acc(FrameJobs) { frame_body_acc<KBE_FRAME_JOBS, true>(KBE_ARGS(FrameJobs), blockIdx.y); }
-__global__ void __launch_bounds__(TILE_THREADS) __attribute__((KBE_ACC_ATTR)) k_frame_group_ahead_dense_acc(FrameJobs)
-{
-    frame_body_acc<KBE_FRAME_JOBS, true, AHEAD_UNITS_DENSE>(KBE_ARGS(FrameJobs), blockIdx.y);
-}
+// (Round 6 built a tile launch WITHOUT records here -- two passes over the candidate list, the z-tested sums added to accumulator planes in
+// LDS by ds_add_f32 instead of the register gather; commit 19f9093 has it.  Parity-green and 6.5 x slower: the LDS
+// executes fp32 atomic adds about one lane at a time, 105.7 against 15.0 us per frame -- profiles/r06_lds_float_atomics.txt.)
 
 }  // namespace
 
@@ -1498,19 +1173,18 @@ void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double
     const int forced = build;
     const Scratch& sc0 = t[0].sc;
     const bool lean = forced ? forced == 1 : (double) pc.Np <= KBE_LEAN_MAX_DENSITY * (double) t[0].cam.W * (double) t[0].cam.H;
-    const bool acc = forced == 3;           // the launch without records (frame_body_acc)
     if (n == 1 && n_next <= 1) {
         FrameJob1 f1;
         f1.pc = pc; f1.n_next = n_next; f1.pad_ = 0; f1.a[0] = fj.a[0]; f1.nx[0] = fj.nx[0];
         f1.dev[0] = f1.dev[1] = f1.dev[2] = 0.0f; f1.a_share[0] = 1u << 8; f1.nx_share[0] = 0;
-        if (n_next) hipLaunchKernelGGL(acc ? k_frame_ahead_acc : (lean ? k_frame_ahead : k_frame_ahead_roomy), dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
-        else hipLaunchKernelGGL(acc ? k_frame_acc : (lean ? k_frame : k_frame_roomy), dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
+        if (n_next) hipLaunchKernelGGL(lean ? k_frame_ahead : k_frame_ahead_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
+        else hipLaunchKernelGGL(lean ? k_frame : k_frame_roomy, dim3(n_tiles), dim3(TILE_THREADS), 0, s, f1);
     } else if (n_next) {                                                        // (also: one frame that places several)
         const bool dense = ahead_units_per_wave(N, sc0.tiles_x * TW, sc0.tiles_y * TH, n, n_next) > (size_t) AHEAD_UNITS + 1;
-        if (dense) hipLaunchKernelGGL(acc ? k_frame_group_ahead_dense_acc : k_frame_group_ahead_dense, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
-        else hipLaunchKernelGGL(acc ? k_frame_group_ahead_acc : (lean ? k_frame_group_ahead : k_frame_group_ahead_roomy), dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+        if (dense) hipLaunchKernelGGL(k_frame_group_ahead_dense, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+        else hipLaunchKernelGGL(lean ? k_frame_group_ahead : k_frame_group_ahead_roomy, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
     }
-    else hipLaunchKernelGGL(acc ? k_frame_group_acc : (lean ? k_frame_group : k_frame_group_roomy), dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
+    else hipLaunchKernelGGL(lean ? k_frame_group : k_frame_group_roomy, dim3(n_tiles, n), dim3(TILE_THREADS), 0, s, fj);
 }
 size_t fused_place_bytes(int N) { return (size_t) cloud_layout_base(N).Np * sizeof(Placement); }
 }  // namespace kbe

@@ -168,12 +168,12 @@ struct FusedTarget {
 };
 // `placed`: the frames' placements and lists exist (made ahead by the previous tile launch on the same sets); n_next > 0: this tile
 // launch also makes those of `next` (frames that use the other bank of their sets; turn >= 0 everywhere)
-// `build`: 0 = the lean or the roomy build of the tile launch by the cloud's density, 1 = lean, 2 = roomy, 3 = the launch without records (KBE_STAGE_FUSED_LEAN / _ROOMY / _ACC)
+// `build`: 0 = the lean or the roomy build of the tile launch by the cloud's density, 1 = lean, 2 = roomy (KBE_STAGE_FUSED_LEAN / _ROOMY)
 // `near_depth`: the depth of the nearest point the caller knows of (objectDepthrange[0], common.py:88), > 0: consecutive frames placed ahead may share
 // candidate lists (kbe_fused.hip: share_plan); 0: every frame keeps lists of its own
 void launch_frames_fused(hipStream_t s, int n, const void* packed, int N, double cloud_focal, const FusedTarget* targets, bool placed = false, int n_next = 0,
                          const FusedTarget* next = nullptr, int build = 0, double near_depth = 0.0);
-inline int fused_build_of_stages(int stages) { return (stages & 4096) ? 3 : ((stages & 1024) ? 1 : ((stages & 2048) ? 2 : 0)); }
+inline int fused_build_of_stages(int stages) { return (stages & 1024) ? 1 : ((stages & 2048) ? 2 : 0); }
 bool fused_can_place_ahead(int N, int W, int H, int n, int n_next);
 
 // blockIdx -> tile id such that each XCD (block b runs on XCD b % 8) owns a contiguous band of

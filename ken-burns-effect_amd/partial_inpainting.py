@@ -15,6 +15,8 @@ it, common.py:75-77); that path is unreachable from ``kbe.py``.  Here ``'tensorE
 1-channel INPUT hole mask -- what the plain ``Inpaint`` returns and what ``process_inpaint``
 needs -- and the propagated mask is available as ``'tensorMaskOut'`` ([B,32,H,W] view).
 """
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -49,8 +51,9 @@ class _Pair(nn.Module):
 
     # The fused form skips the second `input * mask` (utils/partial_conv.py:61): right when the masks are 0 / 1 -- the first layer's
     # update mask is then 0 / 1 and its output 0 outside it -- and wrong for fractional masks.  Inpaint.forward looks at the mask it
-    # is given and turns the fused form off for a call with a fractional one.
-    binary_masks = True
+    # is given and turns the fused form off for a call with a fractional one -- for THAT call: the switch is a per-thread
+    # value the call sets and restores, not an attribute of the class that two modules on two threads would flip under one another.
+    _call = threading.local()
 
     def _fused(self):
         """The element-wise passes around the two layers ride in the layers' own passes (include/kbe.h: kbe_prelu_mask,
@@ -58,7 +61,7 @@ class _Pair(nn.Module):
         per pair three passes over the feature maps instead of seven -- [prelu * mask] conv [renormalise + prelu] conv
         [renormalise + skip] against prelu, * mask, conv, renormalise, prelu, * mask, conv, renormalise, + skip.  Same values
         (a PReLU of the 0 the renormalisation leaves outside the mask is 0: the second multiplication has nothing to do)."""
-        return _Pair.binary_masks and hasattr(common._K(), 'prelu_mask') and getattr(type(self.conv1).forward, 'fuses_neighbours', False) and not torch.is_grad_enabled()
+        return getattr(_Pair._call, 'binary_masks', True) and hasattr(common._K(), 'prelu_mask') and getattr(type(self.conv1).forward, 'fuses_neighbours', False) and not torch.is_grad_enabled()
 
     def _pair(self, x, mask, skip=None):
         """-> (conv2(act(conv1([act] x))) [+ skip], mask)"""
@@ -154,14 +157,16 @@ class Inpaint(nn.Module):
                 tensorContext = self.moduleContext(torch.cat([tensorImage, tensorDisparity], 1))
             tensorData = torch.cat([tensorImage, tensorDisparity, tensorContext], 1)
 
-        # (one host look at the mask per forward: a fractional mask takes the unfused pairs, which multiply by the mask twice as the
-        # reference does)
-        binary = bool(((tensorMasks == 0) | (tensorMasks == 1)).all())
-        was, _Pair.binary_masks = _Pair.binary_masks, binary
+        # (one host look at the mask per forward -- a device-to-host synchronisation, so only where the answer matters: when the fused
+        # form could run at all.  A fractional mask takes the unfused pairs, which multiply by the mask twice as the reference does.)
+        could_fuse = hasattr(common._K(), 'prelu_mask') and not torch.is_grad_enabled()
+        binary = bool(((tensorMasks == 0) | (tensorMasks == 1)).all()) if could_fuse else True
+        was = getattr(_Pair._call, 'binary_masks', True)
+        _Pair._call.binary_masks = binary
         try:
             return self._forward(tensorData, tensorMasks)
         finally:
-            _Pair.binary_masks = was
+            _Pair._call.binary_masks = was
 
     def _forward(self, tensorData, tensorMasks):
         rows = len(ROW_FEATURES)
