@@ -76,6 +76,32 @@ def build_scene(size, device, inpaint, settings=None, upsample=1):
     return oc
 
 
+KERNEL_SOURCES = ('kbe_fused.hip', 'kbe_frame.hip', 'kbe_tiles.h', 'kbe_device.h', 'kbe_cloud.h', 'kbe_cloud.hip')
+
+
+def kernel_sources_stamp():
+    """sha256 (16 hex digits) of the scatter's kernel sources as they lie in the tree: what a committed PMC file says it was measured
+    on (`sources_sha16`, written by the tools/pmc_*report.py that produce it).  The GPU box has no .git: a content hash travels."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _fresh(doc, path):
+    """A committed PMC file counts while the kernel sources are the ones it was measured on (the constant went stale
+    silently when the kernel changed).  Files from before the stamp existed (rounds 1-5) carry none and are stale by definition
+    once the sources have changed since -- which they have."""
+    stamp = doc.get('sources_sha16')
+    now = kernel_sources_stamp()
+    if stamp == now:
+        return True
+    sys.stderr.write('bench.py: %s was measured on kernel sources %s, the tree holds %s: its figures are left out of the line\n' % (os.path.relpath(path, ROOT), stamp or '(unstamped)', now))
+    return False
+
+
 def measured_traffic(workload=''):
     """Per-frame HBM bytes of the frame kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, calibrated and corrected by tools/pmc_report.py as MI355X_MICROARCH.md
@@ -88,6 +114,8 @@ def measured_traffic(workload=''):
         return {}, None
     try:
         doc = json.load(open(files[-1]))
+        if not _fresh(doc, files[-1]):
+            return {}, None
         per = {name: v['hbm_bytes'] for name, v in doc['kernels'].items()}
         # the group launches by frames per launch (tools/pmc_group_report.py): {'k_frame_group_ahead': {'12': {...}}}
         per['by_frames_per_launch'] = {k: v for k, v in doc.get('by_frames_per_launch', {}).items() if isinstance(v, dict)}
@@ -105,6 +133,8 @@ def measured_instructions():
         return {}, None
     try:
         doc = json.load(open(files[-1]))
+        if not _fresh(doc, files[-1]):
+            return {}, None
         per = dict(doc['kernels'])
         per['by_frames_per_launch'] = {k: v for k, v in doc.get('by_frames_per_launch', {}).items() if isinstance(v, dict)}
         return per, os.path.relpath(files[-1], ROOT)
@@ -461,6 +491,32 @@ def pipeline_bench(args, device):
     host = torch.zeros(frames_per_video, size, size, 3, dtype=torch.uint8, pin_memory=True)
     loop_s, _ = timed(lambda: common.render_frames(cams, oc, crop, host_out=host), 10, 2)
 
+    # the writers (/root/reference/utils/pipeline.py:120-134: cv2.imwrite per frame, moviepy -> ffmpeg mpeg4 for frames +
+    # reversed[1:]): host work behind the delivered frames, timed as legs of their own -- the video file the package
+    # writes where there is no ffmpeg binary (Motion-JPEG in an ISO base media file, its frames encoded by Pillow on a pool of host
+    # threads, each distinct frame once), the same on ONE thread with every frame encoded (round 5's writer), and the PNG frames
+    import shutil
+    import tempfile
+
+    from ken_burns_effect_amd import pipeline as pipeline_mod
+    frames_np = [f for f in host.numpy()]
+    video = frames_np + frames_np[-2::-1]
+    tmp = tempfile.mkdtemp(prefix='kbe_writers_')
+    try:
+        mp4 = os.path.join(tmp, '3d_kbe.mp4')
+        video_s, _ = timed(lambda: pipeline_mod.write_video(mp4, video, fps=25), 5, 1)
+        video_bytes = os.path.getsize(mp4)
+        codec = 'mpeg4 (ffmpeg pipe)' if shutil.which('ffmpeg') else 'Motion-JPEG (Pillow, quality 92) in an ISO base media file'
+        threads = pipeline_mod._writer_pool_size(len(frames_np))
+        os.environ['KBE_WRITER_THREADS'] = '1'
+        try:
+            serial_s, _ = timed(lambda: pipeline_mod.write_video(mp4, [f.copy() for f in video], fps=25), 2, 0)     # (copies: every frame its own object, as round 5 encoded them)
+        finally:
+            del os.environ['KBE_WRITER_THREADS']
+        png_s, _ = timed(lambda: pipeline_mod.write_frames(os.path.join(tmp, 'frames'), frames_np), 3, 1)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
     # 4b: the partial-convolution Inpaint forward at 1024^2, fused epilogue against the reference's formulation
     reference_forward = partial_conv_reference_forward
     big = 1024
@@ -498,6 +554,12 @@ def pipeline_bench(args, device):
                    'miopen_find': True if args.miopen_find else pipe.miopen_find, 'call_ms': {'median': round(call_s * 1e3, 2), 'min': round(min(call_ts) * 1e3, 2), 'max': round(max(call_ts) * 1e3, 2)}},
         'stages_ms': {'estimate (resize + 3 networks + unprojection)': round(est_s * 1e3, 2), 'point cloud growth (2 x context net, 68-channel warp, Inpaint forward)': round(grow_s * 1e3, 2),
                       'frame loop (%d frames delivered)' % frames_per_video: round(loop_s * 1e3, 2)},
+        'writers_ms': {'video file (%d frames = forth and back, %s)' % (len(video), codec): round(video_s * 1e3, 2), 'host_threads': threads, 'video_bytes': video_bytes,
+                       'the same on one thread, every frame encoded (round 5)': round(serial_s * 1e3, 2),
+                       'png frames (%d, Pillow)' % frames_per_video: round(png_s * 1e3, 2),
+                       'image_to_video_file_ms': round((call_s + video_s) * 1e3, 2),
+                       'note': 'host-side legs behind the delivered frames, not part of `value` (the reference: cv2.imwrite + moviepy/ffmpeg, /root/reference/utils/pipeline.py:120-134); '
+                               'networks (estimate + growth) take %.1f ms of the call' % ((est_s + grow_s) * 1e3)},
         'partial_inpaint_1024': {'what': 'SURVEY 8d "4b": partial-convolution Inpaint.forward at 1024x1024, fp32 on MIOpen',
                                  'fused_epilogue_ms': round(fused_s * 1e3, 2), 'reference_formulation_ms': round(ref_s * 1e3, 2),
                                  'fused_conv_tflop': round(fused_flops / 1e12, 3), 'reference_conv_tflop': round(ref_flops / 1e12, 3),
@@ -679,6 +741,8 @@ def main():
         sync()
         broadcast_ms = (time.perf_counter() - t0) * 1e3
 
+    own_times = []
+
     def timed_pass(run):
         """EXACTLY K frames between barrier + synchronize on both sides; max over ranks."""
         sync()
@@ -686,6 +750,7 @@ def main():
         run()
         sync()
         dt = time.perf_counter() - t0
+        own_times.append(dt)            # (this rank's own clock, before the max over the ranks: `ranks` in the line)
         if world_size > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -704,6 +769,7 @@ def main():
     # (--device-only: left in HBM); the HBM-resident rate is measured the same way and reported beside it
     times = timed(run_device if args.device_only else run_host)
     elapsed = float(np.median(times))
+    own_elapsed = float(np.median(own_times))
     times_dev = times if args.device_only else timed(run_device)
     elapsed_dev = float(np.median(times_dev))
 
@@ -720,6 +786,16 @@ def main():
                         'ok': worst <= 1 and frames_check < 1e-3}
         if not frames_check['ok']:
             sys.stderr.write('bench.py: DELIVERED FRAMES DIFFER from the frames left in HBM: %s\n' % frames_check)
+
+    # every rank's own account of the timed region (multi-rank runs): its device, the NUMA node it bound to (or why it did not), its
+    # own time per pass and what that is on its PCIe link -- a node where one rank's link or socket lags shows here, not in the max
+    rank_rows = None
+    if world_size > 1:
+        mine = {'rank': rank, 'device': dev_index, 'numa_node': numa_node, 'numa': sharding.NUMA_BIND['reason'], 'frames': n_mine,
+                'ms_per_pass': round(own_elapsed * 1e3, 4),
+                'pcie_GBs': None if args.device_only else round(n_mine * size * size * 3 / own_elapsed / 1e9, 2)}
+        rank_rows = [None] * world_size
+        dist.all_gather_object(rank_rows, mine)
 
     if rank == 0:
         from ken_burns_effect_amd import _native
@@ -880,6 +956,7 @@ def main():
                             'note': 'uint8 frames of %.2f MB over PCIe Gen5 x16 (63 GB/s spec, ~57 measured with hipMemcpyAsync on an idle chip)'
                                     % (size * size * 3 / 1e6)}
         if world_size > 1:
+            line['ranks'] = rank_rows
             line['scaling_valid'] = scaling_valid
             if scaling_note:
                 line['scaling_note'] = scaling_note

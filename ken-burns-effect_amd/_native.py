@@ -902,12 +902,66 @@ class HipKernels:
         return out, um
 
 
+class HipSerialScheduleKernels:
+    """KBE_DEGRID=serial: the frames the REFERENCE-RUN fixtures hold (tests/golden/kenburns_*.npz: the reference's kernel text
+    executed one element after the other), from the HIP library.
+
+    The reference's updateDegrid (common.py:525-568) rewrites the z-buffer in place while its neighbours read it; what a CUDA
+    run produces lies somewhere between the serial index order and the out-of-place (Jacobi) schedule and is not reproducible
+    from run to run.  The product's default is Jacobi -- the fused tile launch, the only deterministic
+    parallel schedule: against the serial one it moves 0.1-0.65 % of a frame's pixels (32-59 dB by scene).  This kernel set is the
+    other end of that range: every op is still the HIP library's, but render_pointcloud / render_frame run stage by stage --
+    kbe_zsplat, kbe_degrid_serial (a wavefront sweep with exactly the serial schedule's data dependences), kbe_accumulate,
+    kbe_normalize, kbe_fill_disocclusion, kbe_frame_u8 -- one frame at a time (no native video loop).  Byte for byte the frames
+    of the fixtures up to the order of the fp32 atomics (one count on < 0.2 % of the values); ~2 ms per 1024^2 frame instead
+    of 21 us: for comparisons with a serial execution of the reference, not for production."""
+    name = 'hip-serial'
+
+    def __init__(self, K, keep_zee=False):
+        self.K, self.zee_log = K, ([] if keep_zee else None)
+
+    def __getattr__(self, name):
+        if name == 'render_video':            # forces common.render_frames onto the per-frame loop below
+            raise AttributeError(name)
+        return getattr(self.K, name)
+
+    def render_pointcloud(self, points, data, W, H, focal, baseline):
+        zkeys, _ = self.K.zsplat(points, W, H, focal, baseline)                                     # common.py:435-507
+        zee = self.K.degrid_serial(zkeys=zkeys)                                                     # :525-568, serial schedule
+        if self.zee_log is not None:
+            self.zee_log.append(zee)
+        return self.K.normalize(self.K.accumulate(points, data, zee, focal, baseline))              # :586-669, :686
+
+    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None, **kw):
+        return {'points': points.reshape(1, 3, -1), 'data': torch.cat([image.reshape(1, 3, -1), depth.reshape(1, 1, -1)], 1), 'W': W, 'H': H}
+
+    def render_frame(self, state, shift3, focal, baseline, fill_rect=None, **kw):
+        pts = self.K.shift_points(state['points'], shift3)                                          # common.py:238-244
+        render, existing = self.render_pointcloud(pts, state['data'], state['W'], state['H'], focal, baseline)   # :246-251
+        filled = self.K.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())       # :253
+        return self.K.frame_u8(filled)                                                              # :255
+
+
 _kernels = None
+_serial_kernels = None
+
+
+def degrid_schedule():
+    """KBE_DEGRID=jacobi (default: the fused tile launch) | serial (HipSerialScheduleKernels)."""
+    v = os.environ.get('KBE_DEGRID', 'jacobi')
+    if v not in ('jacobi', 'serial'):
+        raise KbeError('KBE_DEGRID=%r: jacobi (default) or serial' % v)
+    return v
 
 
 def kernels():
-    """The process-wide kernel set (HIP).  Raises KbeError when the extension is missing."""
-    global _kernels
+    """The process-wide kernel set (HIP).  Raises KbeError when the extension is missing.  KBE_DEGRID=serial: the same library
+    behind HipSerialScheduleKernels (read per call, like every other switch of the host side)."""
+    global _kernels, _serial_kernels
     if _kernels is None:
         _kernels = HipKernels()
+    if degrid_schedule() == 'serial':
+        if _serial_kernels is None:
+            _serial_kernels = HipSerialScheduleKernels(_kernels)
+        return _serial_kernels
     return _kernels

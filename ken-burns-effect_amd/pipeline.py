@@ -142,17 +142,42 @@ class Pipeline():
             # channel order on disk as the reference produces it: frames are in the INPUT's channel order
             # (BGR from cv2.imread unless --pretrained-estim); cv2.imwrite / moviepy want BGR / RGB (:125-134)
             to_rgb = (lambda f: f) if pretrained_estim else (lambda f: f[:, :, ::-1])
+            rgb = [to_rgb(f) for f in frames]
             if self.output_frames:
-                write_frames(os.path.join(output_path, 'frames'), [to_rgb(f) for f in frames])
-            write_video(os.path.join(output_path, '3d_kbe.mp4'), [to_rgb(f) for f in frames + list(reversed(frames))[1:]], fps=25)
+                write_frames(os.path.join(output_path, 'frames'), rgb)
+            # forth and back (:131): the SAME array objects twice -- an intra-frame encoder (the Motion-JPEG writers below) encodes each once
+            write_video(os.path.join(output_path, '3d_kbe.mp4'), rgb + rgb[-2::-1], fps=25)
         return frames
+
+
+WRITER_THREADS = None        # threads the writers encode with (None: one per host core, at most 32; KBE_WRITER_THREADS overrides; 1: in the caller's thread)
+
+
+def _writer_pool_size(n_jobs):
+    want = os.environ.get('KBE_WRITER_THREADS') or WRITER_THREADS or min(32, os.cpu_count() or 1)
+    return max(1, min(int(want), n_jobs))
+
+
+def _encode_all(jobs, encode):
+    """encode(job) for every job, on a pool of host threads: Pillow's JPEG and PNG encoders release the interpreter lock, so the frames
+    of a video -- independent of one another in every format written here -- are encoded side by side.  (Measured, round 6, 512^2:
+    149 frames on one thread cost many times what the renderer needs for the video; bench.py --pipeline times the writers as their own legs.)"""
+    workers = _writer_pool_size(len(jobs))
+    if workers <= 1:
+        return [encode(j) for j in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return list(pool.map(encode, jobs))
 
 
 def write_frames(frames_dir, frames_rgb):
     from PIL import Image
     os.makedirs(frames_dir, exist_ok=True)
-    for idx, frame in enumerate(frames_rgb):
+
+    def save(job):
+        idx, frame = job
         Image.fromarray(np.ascontiguousarray(frame)).save(os.path.join(frames_dir, '%d.png' % idx))
+    _encode_all(list(enumerate(frames_rgb)), save)
 
 
 def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
@@ -187,14 +212,22 @@ def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
 
 
 def _jpegs(frames_rgb, quality):
+    """One baseline JPEG per frame.  A frame OBJECT that occurs several times in the list (the way back of a forth-and-back video,
+    pipeline.py:131) is encoded once; the distinct frames are encoded on the writers' thread pool."""
     import io
     from PIL import Image
-    out = []
+    distinct, first = [], {}
     for frame in frames_rgb:
+        if id(frame) not in first:
+            first[id(frame)] = len(distinct)
+            distinct.append(frame)
+
+    def encode(frame):
         buf = io.BytesIO()
         Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
-        out.append(buf.getvalue())
-    return out
+        return buf.getvalue()
+    encoded = _encode_all(distinct, encode)
+    return [encoded[first[id(frame)]] for frame in frames_rgb]
 
 
 def write_mjpeg_mp4(path, frames_rgb, fps=25, quality=92):

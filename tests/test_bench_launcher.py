@@ -67,3 +67,42 @@ def test_roofline_groups_hold_consecutive_cameras_of_the_path():
         assert all(len(g) == min(n, steps) for g in groups), (steps, n)
         assert sorted(set(c for g in groups for c in g)) == path, (steps, n)                       # every camera of the path is in some group
         assert len(groups) == max(1, -(-steps // n)) and groups[-1][-1] == steps - 1, (steps, n)
+
+
+def _scale_report():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('scale_report', os.path.join(ROOT, 'tools', 'scale_report.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_scale_report_prints_a_curve_only_from_scaling_measurements():
+    """tools/scale_report.py: the curve frames/s(N) / frames/s(1) exists only when every line of the mode is a
+    scaling measurement -- ranks on devices of their own, RCCL up (`scaling_valid`) -- none failed, and there is an N = 1 line."""
+    sr = _scale_report()
+    row = lambda n, v, ok=True, mode='weak': {'n_gpus': n, 'mode': mode, 'value': v, 'scaling_valid': ok}     # noqa: E731
+    curve, why = sr.curve_of([row(1, 100.0), row(2, 190.0), row(8, 720.0), row(1, 50.0, mode='strong')], 'weak')
+    assert curve == {'1': 1.0, '2': 1.9, '8': 7.2} and why is None
+    curve, why = sr.curve_of([row(1, 100.0), row(2, 190.0, ok=False)], 'weak')
+    assert curve is None and 'scaling_valid false' in why and 'N = 2' in why
+    curve, why = sr.curve_of([row(2, 190.0), row(4, 380.0)], 'weak')
+    assert curve is None and 'N = 1' in why
+    curve, why = sr.curve_of([row(1, 100.0), {'n_gpus': 2, 'mode': 'weak', 'error': 'timed out'}], 'weak')
+    assert curve is None and 'failed' in why
+    # a bench line as rank 0 prints it -> the report's row (per-rank accounts, the NUMA node or why there is none)
+    doc = {'metric': 'm', 'value': 31000.0, 'unit': 'frames/s', 'ms_per_step': 4.8, 'scaling': 'weak', 'scaling_valid': True, 'cloud_broadcast_ms': 0.4,
+           'config': {'ranks_seen': 2, 'collectives': 'nccl'}, 'pcie': {'achieved': 50.1},
+           'ranks': [{'rank': 0, 'device': 0, 'numa_node': 0, 'numa': 'bound to 96 CPUs of node 0', 'frames': 75, 'ms_per_pass': 4.7, 'pcie_GBs': 50.1},
+                     {'rank': 1, 'device': 1, 'numa_node': None, 'numa': 'the kernel reports no NUMA node for 0000:0b:00.0', 'frames': 75, 'ms_per_pass': 4.8, 'pcie_GBs': 49.2}]}
+    r = sr.summarise(2, 'weak', doc)
+    assert r['ranks_seen'] == 2 and r['collectives'] == 'nccl' and r['scaling_valid'] and r['ranks'][1]['numa_node'] is None and r['cloud_broadcast_ms'] == 0.4
+    assert sr.summarise(2, 'weak', {'error': 'no JSON line (exit 1)', 'stderr': 'x'})['error']
+
+
+def test_numa_binding_says_what_it_did(monkeypatch):
+    """sharding.bind_to_gpu_numa_node never passes silently: NUMA_BIND holds the node, or the reason there is none."""
+    sys.path.insert(0, ROOT)
+    from ken_burns_effect_amd import sharding
+    assert sharding.bind_to_gpu_numa_node(0) is None             # no GPU here: no PCI address
+    assert sharding.NUMA_BIND['node'] is None and 'PCI address' in sharding.NUMA_BIND['reason']

@@ -1662,6 +1662,36 @@ def test_hand_off_turns_with_four_processes_on_one_gpu():
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_scale_report_dry_run_on_one_gpu(tmp_path):
+    """tools/scale_report.py --dry-run: the one command that will measure the scaling curve on a node, run here the
+    only way a 1-GPU box can -- N = 1 and N = 2 with the two ranks sharing the GPU and the collectives on gloo.  Every path runs (launcher,
+    broadcast, weak and strong sharding, per-rank accounts with the NUMA node or the reason there is none); the lines of N = 2 say
+    `scaling_valid: false` and the report REFUSES to print a curve from them."""
+    import json
+    import subprocess
+    import sys
+    out = str(tmp_path / 'scale.json')
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'KBE_DIST_BACKEND'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'scale_report.py'), '--gpus', '1,2', '--dry-run', '--steps', '12', '--warmup', '4',
+                        '--video-frames', '16', '--size', '256', '--out', out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'weak scaling: NO CURVE' in r.stdout and 'strong scaling: NO CURVE' in r.stdout and 'scaling_valid false' in r.stdout
+    doc = json.load(open(out))
+    assert doc['dry_run'] and doc['weak_curve'] is None and doc['strong_curve'] is None
+    rows = {(x['mode'], x['n_gpus']): x for x in doc['rows']}
+    assert set(rows) == {('weak', 1), ('weak', 2), ('strong', 1), ('strong', 2)} and all('error' not in x for x in rows.values())
+    for mode in ('weak', 'strong'):
+        two = rows[(mode, 2)]
+        assert two['ranks_seen'] == 2 and two['collectives'].startswith('gloo') and two['scaling_valid'] is False and two['value'] > 0
+        assert two['cloud_broadcast_ms'] is not None and [x['rank'] for x in two['ranks']] == [0, 1]
+        assert all(x['numa'] and x['frames'] > 0 and x['ms_per_pass'] > 0 and x['pcie_GBs'] > 0 for x in two['ranks'])
+        assert rows[(mode, 1)]['scaling_valid'] is True
+    assert sum(x['frames'] for x in rows[('strong', 2)]['ranks']) == 16 and [x['frames'] for x in rows[('weak', 2)]['ranks']] == [12, 12]
+
+
 def test_numa_binding_of_a_rank_is_best_effort():
     """sharding.bind_to_gpu_numa_node: the CPUs of the GPU's NUMA node, or None (and nothing changed) when unknown."""
     import os

@@ -4,7 +4,8 @@ frames reproduced by the HIP kernels.
 
 Two kernel sets are used:
   * the product set (`_native.kernels()`): tile renderer, out-of-place (Jacobi) degrid;
-  * `HipSerialKernels` (below, test infrastructure): the library's stage-by-stage HIP kernels with the degrid run under
+  * the product's serial-schedule route (`KBE_DEGRID=serial`: `_native.HipSerialScheduleKernels`, since round 6 a documented
+    option of the package instead of a class in this file): the library's stage-by-stage HIP kernels with the degrid run under
     the SERIAL schedule (`kbe_degrid_serial`).  The golden vectors were produced by the reference's kernel text
     executed one element after the other (tests/golden/make_golden.py), so this is the schedule under which a HIP
     run can be compared with a reference run bit for bit (z-buffers) and count for count (frames).
@@ -41,35 +42,6 @@ def g(a):
 
 def c(t):
     return t.detach().cpu().numpy()
-
-
-class HipSerialKernels:
-    """Test seam: every op is the HIP library's; render_pointcloud / render_frame run stage by stage with the degrid
-    under the serial schedule (the product's tile renderer uses the out-of-place one)."""
-    name = 'hip-serial'
-
-    def __init__(self, K):
-        self.K, self.zee_log = K, []
-
-    def __getattr__(self, name):
-        if name == 'render_video':            # forces common.render_frames onto the per-frame loop below
-            raise AttributeError(name)
-        return getattr(self.K, name)
-
-    def render_pointcloud(self, points, data, W, H, focal, baseline):
-        zkeys, _ = self.K.zsplat(points, W, H, focal, baseline)
-        zee = self.K.degrid_serial(zkeys=zkeys)
-        self.zee_log.append(zee)
-        return self.K.normalize(self.K.accumulate(points, data, zee, focal, baseline))
-
-    def prepare_cloud(self, points, image, depth, W, H, focal=None, raster=None):
-        return {'points': points.reshape(1, 3, -1), 'data': torch.cat([image.reshape(1, 3, -1), depth.reshape(1, 1, -1)], 1), 'W': W, 'H': H}
-
-    def render_frame(self, state, shift3, focal, baseline, fill_rect=None, **kw):
-        pts = self.K.shift_points(state['points'], shift3)                                          # common.py:238-244
-        render, existing = self.render_pointcloud(pts, state['data'], state['W'], state['H'], focal, baseline)   # :246-251
-        filled = self.K.fill_disocclusion(render, render[:, 3:4] * (existing > 0.0).float())       # :253
-        return self.K.frame_u8(filled)                                                              # :255
 
 
 def _depthrange(v):
@@ -112,10 +84,14 @@ def test_reference_run_frames_on_the_hip_kernels_serial_schedule(K, monkeypatch,
     """process_kenburns of the reference (kernel text executed serially) vs the same call on the HIP kernels with the
     serial degrid: per-frame z-buffers bit for bit, the appended point cloud bit for bit, frames within one uint8 count
     (the accumulation order of atomicAdd is the only freedom left; the reference's own is not defined either)."""
-    from ken_burns_effect_amd import common
+    from ken_burns_effect_amd import _native, common
     z = load_golden(name)
-    ks = HipSerialKernels(K)
-    monkeypatch.setattr(common, '_kernel_set', ks)
+    # the PRODUCT's serial-schedule route (VERDICT r5 item 6): KBE_DEGRID=serial makes _native.kernels() -- what common uses when
+    # nobody injects a kernel set -- the stage-by-stage kernels with kbe_degrid_serial; its z-buffers are logged here to be compared
+    monkeypatch.setenv('KBE_DEGRID', 'serial')
+    ks = _native.kernels()
+    assert isinstance(ks, _native.HipSerialScheduleKernels) and common._K() is ks
+    monkeypatch.setattr(ks, 'zee_log', [])
     settings, oc = _scene(z, K)
     frames = common.process_kenburns(settings, oc, ReplayInpaint(z) if not z['dolly'] else None)
     for key, ref in (('tensorInpaPoints', 'inpa_points'), ('tensorInpaImage', 'inpa_image'), ('tensorInpaDepth', 'inpa_depth'),
@@ -263,15 +239,17 @@ def test_pointcloud_inpainting_on_the_hip_kernels_matches_reference(net, K, monk
     image, disp = g(z['image']), g(z['disparity'])
     H, W = image.shape[2:]
     oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H}
-    ks = HipSerialKernels(K)
-    monkeypatch.setattr(common, '_kernel_set', ks)
+    from ken_burns_effect_amd import _native
+    monkeypatch.setenv('KBE_DEGRID', 'serial')
+    ks = _native.kernels()
+    monkeypatch.setattr(ks, 'zee_log', [])
     with torch.no_grad():
         out = net.pointcloud_inpainting(image, disp, g(z['pi_shift']), oc)
     assert_bits_equal(c(ks.zee_log[-1]), z['pi_zee'], 'z-buffer of the 68-channel forward warp (serial schedule)')
     assert_bits_equal(c(out['tensorExisting']), z['pi_existing'], 'existing mask after median-5 dilation')
     _close(out['tensorImage'], z['pi_image'], TOL_IMAGE, 'pointcloud_inpainting image')
     _close(out['tensorDisparity'], z['pi_disparity'], TOL_DISPARITY_REL * max(1.0, float(np.abs(z['pi_disparity']).max())), 'pointcloud_inpainting disparity')
-    monkeypatch.setattr(common, '_kernel_set', None)
+    monkeypatch.delenv('KBE_DEGRID')
     with torch.no_grad():
         prod = net.pointcloud_inpainting(image, disp, g(z['pi_shift']), oc)
     same = c(prod['tensorExisting']) == z['pi_existing']
@@ -339,7 +317,7 @@ def test_partial_inpaint_forward_with_a_fractional_mask_takes_the_unfused_pairs(
             assert seen and all(seen), 'a 0 / 1 mask takes them'
         finally:
             partial_inpainting._Pair._fused = real
-        assert partial_inpainting._Pair.binary_masks is True
+        assert getattr(partial_inpainting._Pair._call, 'binary_masks', True) is True        # the call's switch is restored (per thread since round 6)
         fused_forward = partial_conv.PartialConv2d.forward
         partial_conv.PartialConv2d.forward = bench.partial_conv_reference_forward
         for m in net.modules():

@@ -4,8 +4,12 @@
 tools/pmc_report.py calibrated: its hbm_traffic.json, second argument).  bench.py reads the result for that workload's `roofline.traffic`.
     python tools/pmc_config4_report.py config4_traffic.txt hbm_traffic.json > hbm_traffic_config4.json"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
 
 SIZE, POINTS = 2048, 4 * 2048 * 2048
 TILES = (SIZE // 32) * (SIZE // 16)
@@ -29,4 +33,4 @@ for e in out.values():
     e['bytes_per_point'] = round(e['hbm_bytes'] / POINTS, 1)
 print(json.dumps({'workload': {'size': SIZE, 'upsample': 2, 'points': POINTS}, 'note': 'HBM bytes per FRAME (a launch holds frames_per_launch of them); '
                   'units calibrated by tools/pmc_report.py', 'bytes_per_FETCH_SIZE_unit': unit['FETCH_SIZE'], 'bytes_per_WRITE_SIZE_unit': unit['WRITE_SIZE'],
-                  'kernels': out}, indent=1))
+                  'kernels': out, 'sources_sha16': bench.kernel_sources_stamp()}, indent=1))

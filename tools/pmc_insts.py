@@ -5,6 +5,7 @@ launches (KBE_LANES=1 KBE_FILL_GROUP=1 tools/frame_once.py, once per route) -> J
 import collections
 import csv
 import json
+import os
 import sys
 
 KEYS = ('k_place', 'k_frame', 'k_frame_ahead', 'k_project', 'k_tiles')
@@ -21,4 +22,7 @@ for k in KEYS:
         mean = lambda n: sum(c[n]) / len(c[n]) if c[n] else None     # noqa: E731
         out['kernels'][k] = {'launches': len(c['SQ_INSTS_VALU']), 'valu': mean('SQ_INSTS_VALU'), 'salu': mean('SQ_INSTS_SALU'), 'lds': mean('SQ_INSTS_LDS'),
                              'waves': mean('SQ_WAVES')}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out['sources_sha16'] = bench.kernel_sources_stamp()        # what bench.py checks before it quotes these figures
 print(json.dumps(out, indent=1))

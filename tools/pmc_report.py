@@ -9,6 +9,7 @@ prints corrected bytes per launch for the frame kernels.
 import collections
 import csv
 import json
+import os
 import sys
 
 CAL_BYTES = 96 * 1024 * 1024 * 4
@@ -43,4 +44,7 @@ for key in ('k_project', 'k_tiles', 'k_place', 'k_frame', 'k_frame_ahead', 'k_fi
     if f and w:
         out['kernels'][key] = {'launches': len(f), 'fetch_bytes': cal_f * sum(f) / len(f), 'write_bytes': cal_w * sum(w) / len(w)}
         out['kernels'][key]['hbm_bytes'] = out['kernels'][key]['fetch_bytes'] + out['kernels'][key]['write_bytes']
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out['sources_sha16'] = bench.kernel_sources_stamp()        # what bench.py checks before it quotes these figures
 print(json.dumps(out, indent=1))
