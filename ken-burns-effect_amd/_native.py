@@ -34,7 +34,7 @@ FUSED_MAX_DENSITY = 20.0         # clouds up to this many points per pixel take 
                                  # (profiles/r05_density_sweep.txt; the bucket route: 153 / 14 083 us at 4 / 9, the atomic kernels 2.1 / 5.2 / 20.5 ms at 4 / 9 / 24).
                                  # (4.5 in round 4, 1.5 before.)
 FUSED_MAX_POINTS = 1 << 28       # the packed cloud's route addresses points by 32-bit byte offsets (KBE_FUSED_MAX_POINTS, kbe_tiles.h): larger clouds take the bucket route
-FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes two frames per launch on every lane
+FUSED_DENSE = 1.5                # "denser than the raster" from here on: delivered to host memory such a video takes three frames per launch on every lane (two until round 6)
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
                        # launch's 4 KB of kernel arguments hold.  A launch alone on a stream costs ~5 us besides its frames (ramp and tail: 8 / 12
                        # frames per launch 16.5 / 16.1 us per frame), and delivered to host memory -- the link binds -- a video runs at the same rate
@@ -584,11 +584,14 @@ class HipKernels:
             # 1024^2 25.5 / 24.9 / 25.0, 1280^2 41.4 / 40.5 / 41.2, 1536^2 59.3 / 58.4 / 58.5; with a placement launch per group, round
             # 3's first half: 1024^2 25.3 / 26.7; the bucket route: 13.7, 18.8, 25.5, 29.4, 51.7, 72.8)
             group = FUSED_HOST_GROUP if to_host else 4
-            if to_host and state['N'] > FUSED_DENSE * W * H:
-                # a cloud much denser than the raster is bound by its rendering, not by the link: long launches next to another lane's
-                # transfer (a blit kernel) only slow each other -- measured, 16.8 M points at 2048^2, us per delivered frame with 8 / 4 / 2
-                # frames per launch on four lanes: 446 / 422 / 395 (the bucket route: 433); 4.2 M at 1024^2: 118 / 108 / 104 (114-154)
-                group = 2
+            if state['N'] > FUSED_DENSE * W * H:              # (left in HBM too since round 6: four per launch was the slowest of 2 / 3 / 4 there)
+                # a cloud much denser than the raster is bound by its rendering, not by the link: few frames per launch on every lane.  Round 4
+                # (blit hand-off: long launches next to another lane's copy kernel slowed each other), 16.8 M points at 2048^2, us per
+                # delivered frame with 8 / 4 / 2 frames per launch on four lanes: 446 / 422 / 395.  Round 6, SDMA hand-off, frames/s delivered /
+                # left in HBM with 2 / 3 / 4 / 6 / 8: 2 948 / 3 234, 2 941 / 3 246, 2 707 / 3 141, 2 598 / 2 999, 2 390 / 2 974 -- and the launch
+                # alone on a stream 289.5 / 273.8 / 269.1 / 265.6 / 263.7 us per frame (its tail amortised): three is as fast as two for the
+                # video and 5 % faster per launch (tools/gpu_r06_config4_groups.sh, profiles/r06_config4_groups.txt)
+                group = 3
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /
             # 8.6, 640^2 15.1 / 12.8 / 13.1, 768^2 19.1 / 16.4 / 17.4, 896^2 24.8 / 23.8 / 24.3, 1024^2 28.9 / 30.6 / 30.9)

@@ -522,6 +522,32 @@ def gen_kenburns():
         save('kenburns_' + tag, **arrays)
 
 
+def gen_autozoom():
+    """process_autozoom of the reference (common.py:114-170).  The function is dead code there and cannot run as written: it calls
+    process_shift without the objectCommon argument that function takes (:146-152).  Its BODY runs here unmodified; the one missing
+    argument is supplied by wrapping the module's process_shift for the duration of the call.  Kept: inputs, settings, the window it returns."""
+    h = HARNESS
+    cases = {}
+    for tag, (H, W, seed, zoom, shift) in {'a': (48, 64, 71, 1.25, 8.0), 'b': (40, 56, 72, 1.5, 10.0)}.items():
+        image, disp = synthetic.make_rgbd(H, W, seed, 'smooth')
+        depth = (512.0 * 120) / (disp + 1e-7)
+        pts = h.C.depth_to_points(depth, 512.0)
+        common = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H, 'objectDepthrange': synthetic.depthrange_of(depth),
+                  'tensorRawPoints': pts.view(1, 3, -1), 'tensorRawImage': image, 'tensorRawDisparity': disp, 'tensorRawDepth': depth}
+        settings = {'dblShift': shift, 'dblZoom': zoom, 'objectFrom': {'dblCenterU': W / 2.0, 'dblCenterV': H / 2.0, 'intCropWidth': W, 'intCropHeight': H}}
+        real = h.C.process_shift
+        h.C.process_shift = lambda s, _c=common, _r=real: _r(s, _c)
+        try:
+            window = h.C.process_autozoom(settings, common)
+        finally:
+            h.C.process_shift = real
+        dr = common['objectDepthrange']
+        cases[tag] = dict(image=npy(image), disparity=npy(disp), zoom=np.float64(zoom), shift=np.float64(shift),
+                          depthrange=np.array([dr[0], dr[1], dr[2][0], dr[2][1], dr[3][0], dr[3][1]], np.float64),
+                          window=np.array([window['dblCenterU'], window['dblCenterV'], window['intCropWidth'], window['intCropHeight']], np.float64))
+    save('autozoom', **{'%s_%s' % (t, k): v for t, c in cases.items() for k, v in c.items()})
+
+
 def gen_kenburns_at_size():
     """process_kenburns of the reference at 256 x 320 on a smooth scene (KBE path with two Inpaint passes, and a dolly zoom):
     only the seed, the steps and the reference's pre-crop uint8 FRAMES are kept (the inputs are regenerated from the seed by
@@ -597,6 +623,6 @@ if __name__ == '__main__':
     HARNESS = Harness()
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)   # bit-stable conv results
-    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'kenburns_at_size', 'disparity', 'generate_mask']
+    which = sys.argv[1:] or ['render', 'fill', 'torch_helpers', 'partial_conv', 'inpaint', 'kenburns', 'kenburns_at_size', 'disparity', 'generate_mask', 'autozoom']
     for w in which:
         globals()['gen_' + w]()

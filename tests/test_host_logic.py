@@ -70,6 +70,27 @@ def test_process_shift_matches_reference(common):
     assert_bits_equal(pts.numpy(), z['ps_points'], 'inputs are never mutated')
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_process_autozoom_matches_the_reference_run(common, tag):
+    """common.py:114-170.  The reference's process_autozoom is dead code that cannot run as written (it calls process_shift without
+    objectCommon, :146-152); the fixture holds what its unmodified body returns once that one argument is supplied
+    (tests/golden/make_golden.py: gen_autozoom): the crop window, out of a 16 x 16 grid of shifts, under which the shifted cloud
+    covers the most pixels -- this package's version must pick the same window (test it or delete it)."""
+    from oracle import kbe_oracle
+    z = load_golden('autozoom')
+    image, disp = _t(z[tag + '_image']), _t(z[tag + '_disparity'])
+    H, W = image.shape[2:]
+    depth = (512.0 * 120) / (disp + 1e-7)
+    oc = {'dblFocal': 512.0, 'dblBaseline': 120, 'intWidth': W, 'intHeight': H, 'objectDepthrange': _depthrange(z[tag + '_depthrange']),
+          'tensorRawPoints': kbe_oracle.depth_to_points(depth, 512.0).view(1, 3, -1), 'tensorRawImage': image, 'tensorRawDisparity': disp, 'tensorRawDepth': depth}
+    settings = {'dblShift': float(z[tag + '_shift']), 'dblZoom': float(z[tag + '_zoom']),
+                'objectFrom': {'dblCenterU': W / 2.0, 'dblCenterV': H / 2.0, 'intCropWidth': W, 'intCropHeight': H}}
+    got = common.process_autozoom(settings, oc)
+    want = z[tag + '_window']
+    assert [got['dblCenterU'], got['dblCenterV'], got['intCropWidth'], got['intCropHeight']] == [float(want[0]), float(want[1]), int(want[2]), int(want[3])]
+    assert isinstance(got['intCropWidth'], int) and isinstance(got['intCropHeight'], int)
+
+
 def test_dolly_trace_matches_reference(common):
     z = load_golden('kenburns_dolly')
     settings, oc = _scene(z)
