@@ -493,8 +493,8 @@ def pipeline_bench(args, device):
 
     # the writers (/root/reference/utils/pipeline.py:120-134: cv2.imwrite per frame, moviepy -> ffmpeg mpeg4 for frames +
     # reversed[1:]): host work behind the delivered frames, timed as legs of their own -- the video file the package
-    # writes where there is no ffmpeg binary (Motion-JPEG in an ISO base media file, its frames encoded by Pillow on a pool of host
-    # threads, each distinct frame once), the same on ONE thread with every frame encoded (round 5's writer), and the PNG frames
+    # writes where there is no ffmpeg binary (Motion-JPEG in an ISO base media file, each distinct frame encoded once by libkbe_jpeg.so
+    # on host threads), round 5's writer beside it (Pillow: one frame at a time, every frame encoded), and the PNG frames (zlib on threads)
     import shutil
     import tempfile
 
@@ -506,13 +506,15 @@ def pipeline_bench(args, device):
         mp4 = os.path.join(tmp, '3d_kbe.mp4')
         video_s, _ = timed(lambda: pipeline_mod.write_video(mp4, video, fps=25), 5, 1)
         video_bytes = os.path.getsize(mp4)
-        codec = 'mpeg4 (ffmpeg pipe)' if shutil.which('ffmpeg') else 'Motion-JPEG (Pillow, quality 92) in an ISO base media file'
+        encoder = pipeline_mod.jpeg_encoder()[0]
+        codec = 'mpeg4 (ffmpeg pipe)' if shutil.which('ffmpeg') else 'Motion-JPEG (quality 92, %s) in an ISO base media file' % ('libkbe_jpeg.so' if encoder == 'native' else 'Pillow')
         threads = pipeline_mod._writer_pool_size(len(frames_np))
-        os.environ['KBE_WRITER_THREADS'] = '1'
+        encode_s, _ = timed(lambda: pipeline_mod._jpegs(video, 92), 5, 1)
+        os.environ['KBE_JPEG'] = 'pillow'               # round 5's writer: Pillow, one frame at a time, every frame of the way back encoded again
         try:
-            serial_s, _ = timed(lambda: pipeline_mod.write_video(mp4, [f.copy() for f in video], fps=25), 2, 0)     # (copies: every frame its own object, as round 5 encoded them)
+            serial_s, _ = timed(lambda: pipeline_mod.write_video(mp4, [f.copy() for f in video], fps=25), 2, 0)
         finally:
-            del os.environ['KBE_WRITER_THREADS']
+            del os.environ['KBE_JPEG']
         png_s, _ = timed(lambda: pipeline_mod.write_frames(os.path.join(tmp, 'frames'), frames_np), 3, 1)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -555,8 +557,9 @@ def pipeline_bench(args, device):
         'stages_ms': {'estimate (resize + 3 networks + unprojection)': round(est_s * 1e3, 2), 'point cloud growth (2 x context net, 68-channel warp, Inpaint forward)': round(grow_s * 1e3, 2),
                       'frame loop (%d frames delivered)' % frames_per_video: round(loop_s * 1e3, 2)},
         'writers_ms': {'video file (%d frames = forth and back, %s)' % (len(video), codec): round(video_s * 1e3, 2), 'host_threads': threads, 'video_bytes': video_bytes,
-                       'the same on one thread, every frame encoded (round 5)': round(serial_s * 1e3, 2),
-                       'png frames (%d, Pillow)' % frames_per_video: round(png_s * 1e3, 2),
+                       'of which encoding the %d distinct frames' % frames_per_video: round(encode_s * 1e3, 2),
+                       "round 5's writer (Pillow, one thread, all %d frames encoded)" % len(video): round(serial_s * 1e3, 2),
+                       'png frames (%d, zlib level 1 on the writer threads)' % frames_per_video: round(png_s * 1e3, 2),
                        'image_to_video_file_ms': round((call_s + video_s) * 1e3, 2),
                        'note': 'host-side legs behind the delivered frames, not part of `value` (the reference: cv2.imwrite + moviepy/ffmpeg, /root/reference/utils/pipeline.py:120-134); '
                                'networks (estimate + growth) take %.1f ms of the call' % ((est_s + grow_s) * 1e3)},

@@ -150,34 +150,75 @@ class Pipeline():
         return frames
 
 
-WRITER_THREADS = None        # threads the writers encode with (None: one per host core, at most 32; KBE_WRITER_THREADS overrides; 1: in the caller's thread)
+WRITER_THREADS = None        # host threads the writers encode on (None: one per core, at most 32; KBE_WRITER_THREADS overrides; 1: the caller's thread only)
+_JPEG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libkbe_jpeg.so')
+_jpeg_lib = None
 
 
 def _writer_pool_size(n_jobs):
     want = os.environ.get('KBE_WRITER_THREADS') or WRITER_THREADS or min(32, os.cpu_count() or 1)
-    return max(1, min(int(want), n_jobs))
+    return max(1, min(int(want), max(n_jobs, 1)))
 
 
-def _encode_all(jobs, encode):
-    """encode(job) for every job, on a pool of host threads: Pillow's JPEG and PNG encoders release the interpreter lock, so the frames
-    of a video -- independent of one another in every format written here -- are encoded side by side.  (Measured, round 6, 512^2:
-    149 frames on one thread cost many times what the renderer needs for the video; bench.py --pipeline times the writers as their own legs.)"""
+def jpeg_encoder():
+    """'native' (libkbe_jpeg.so, include/kbe_jpeg.h: a batch of frames on host threads) or 'pillow' (one frame at a time: Pillow's encoder
+    holds the interpreter lock -- measured, 8 threads: 201 ms against 171 ms on one).  KBE_JPEG=pillow forces the latter; a missing
+    library falls back to it with a warning (the writers are host-side conveniences, not the render path: that one has no fallback)."""
+    global _jpeg_lib
+    if os.environ.get('KBE_JPEG', 'native') == 'pillow':
+        return 'pillow', None
+    if _jpeg_lib is None:
+        import ctypes
+        if not os.path.exists(_JPEG_LIB_PATH):
+            import warnings
+            warnings.warn('%s is missing (python -c "import __graft_entry__ as g; g.build()"): the video writer encodes with Pillow, one frame at a time' % _JPEG_LIB_PATH)
+            return 'pillow', None
+        lib = ctypes.CDLL(_JPEG_LIB_PATH)
+        lib.kbe_jpeg_bound.restype = ctypes.c_size_t
+        lib.kbe_jpeg_bound.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.kbe_jpeg_encode_batch.restype = ctypes.c_int
+        _jpeg_lib = lib
+    return 'native', _jpeg_lib
+
+
+def _on_threads(jobs, work):
+    """work(job) for every job on the writers' pool of host threads (for work that releases the interpreter lock: zlib does)."""
     workers = _writer_pool_size(len(jobs))
     if workers <= 1:
-        return [encode(j) for j in jobs]
+        return [work(j) for j in jobs]
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        return list(pool.map(encode, jobs))
+        return list(pool.map(work, jobs))
+
+
+def png_bytes(frame_rgb, level=1):
+    """One uint8 HxWx3 frame as a PNG (8-bit RGB, every row with the Sub filter, ONE zlib stream at `level`; default 1 = cv2.imwrite's
+    default, /root/reference/utils/pipeline.py:125).  Written here rather than through Pillow because zlib.compress releases the
+    interpreter lock and Pillow's PNG encoder does not: write_frames encodes a video's frames side by side."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(frame_rgb)
+    h, w = a.shape[:2]
+    raw = np.empty((h, 1 + 3 * w), np.uint8)
+    raw[:, 0] = 1                                                   # filter type 1 (Sub): each byte minus the byte three to its left
+    flat = a.reshape(h, 3 * w)
+    raw[:, 1:4] = flat[:, :3]
+    raw[:, 4:] = flat[:, 3:] - flat[:, :-3]                         # (uint8 arithmetic wraps: exactly the filter's modulo 256)
+
+    def chunk(tag, body):
+        return struct.pack('>I', len(body)) + tag + body + struct.pack('>I', zlib.crc32(tag + body) & 0xFFFFFFFF)
+    return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) + chunk(b'IDAT', zlib.compress(raw.tobytes(), level)) + chunk(b'IEND', b''))
 
 
 def write_frames(frames_dir, frames_rgb):
-    from PIL import Image
+    """%d.png per frame (pipeline.py:122-126), encoded on the writers' threads."""
     os.makedirs(frames_dir, exist_ok=True)
 
     def save(job):
         idx, frame = job
-        Image.fromarray(np.ascontiguousarray(frame)).save(os.path.join(frames_dir, '%d.png' % idx))
-    _encode_all(list(enumerate(frames_rgb)), save)
+        with open(os.path.join(frames_dir, '%d.png' % idx), 'wb') as f:
+            f.write(png_bytes(frame))
+    _on_threads(list(enumerate(frames_rgb)), save)
 
 
 def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
@@ -213,20 +254,35 @@ def write_mjpeg_avi(path, frames_rgb, fps=25, quality=92):
 
 def _jpegs(frames_rgb, quality):
     """One baseline JPEG per frame.  A frame OBJECT that occurs several times in the list (the way back of a forth-and-back video,
-    pipeline.py:131) is encoded once; the distinct frames are encoded on the writers' thread pool."""
-    import io
-    from PIL import Image
+    pipeline.py:131) is encoded once; the distinct frames go to libkbe_jpeg.so as one batch on the writers' host threads."""
     distinct, first = [], {}
     for frame in frames_rgb:
         if id(frame) not in first:
             first[id(frame)] = len(distinct)
             distinct.append(frame)
+    kind, lib = jpeg_encoder()
+    sizes = {f.shape for f in distinct}
+    if kind == 'native' and len(sizes) == 1:
+        import ctypes
+        arrays = [np.ascontiguousarray(f, dtype=np.uint8) for f in distinct]
+        h, w = arrays[0].shape[:2]
+        n, cap = len(arrays), int(lib.kbe_jpeg_bound(w, h))
+        outs = [np.empty(cap, np.uint8) for _ in range(n)]
+        got = (ctypes.c_size_t * n)()
+        rc = lib.kbe_jpeg_encode_batch((ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays]), n, w, h, 3 * w, int(quality),
+                                       (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs]), ctypes.c_size_t(cap), got, _writer_pool_size(n))
+        if rc != 0:
+            raise RuntimeError('kbe_jpeg_encode_batch: %d' % rc)
+        encoded = [outs[i][:got[i]].tobytes() for i in range(n)]
+    else:
+        import io
+        from PIL import Image
 
-    def encode(frame):
-        buf = io.BytesIO()
-        Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
-        return buf.getvalue()
-    encoded = _encode_all(distinct, encode)
+        def encode(frame):
+            buf = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(frame)).save(buf, format='JPEG', quality=quality)
+            return buf.getvalue()
+        encoded = [encode(f) for f in distinct]
     return [encoded[first[id(frame)]] for frame in frames_rgb]
 
 
