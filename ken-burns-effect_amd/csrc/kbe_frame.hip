@@ -1547,25 +1547,24 @@ int kbe_render_video(const float* points, const float* image, const float* depth
         if (pairs) {
             // a chunk of group * lanes CONSECUTIVE frames at a time, lane l taking frames base + l * group .. base + l * group + group - 1 of
             // it (consecutive cameras share candidate lists, kbe_fused.hip: share_plan; until round 5 lane l took frames l, l + lanes,
-            // ...: cameras `lanes` steps apart in every launch).  The LAST, partial chunk -- a short video is nothing else -- is dealt
-            // evenly: ceil(remaining / lanes) consecutive frames per lane, so that every lane has work (eight frames on four
-            // lanes were one launch on one stream).  (A first pass counts the frames of every scratch set: the bucket route must
-            // know a set's last frame.)
+            // ...: cameras `lanes` steps apart in every launch).  The last, partial chunk fills the lanes one after the other, `group`
+            // frames each.  (ADVICE r5 proposed to deal it evenly, ceil(remaining / lanes) frames per lane, so that every lane has work:
+            // measured in round 6 -- tools/gpu_r06_tail.sh, frames/s left in HBM, lane by lane / evenly: 6 frames 26.5 / 26.4 k, 8: 29.5 /
+            // 29.5, 12: 33.5 / 33.4, 20: 35.9 / 33.9, 24: 37.6 / 35.5, 30: 38.2 / 37.7, 40: 39.8 / 39.6 -- never faster, 5 % slower
+            // where it turns one four-frame launch into four one-frame launches: a launch's ramp and tail cost more than the idle lanes.)
+            // (A first pass counts the frames of every scratch set: the bucket route must know a set's last frame.)
             for (int pass = 0; pass < 2 && rc == KBE_OK; pass++) {
                 counting = pass == 0;
-                for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes) {
-                    const int left = n_frames - base;
-                    const int per = left >= group * lanes ? group : (left + lanes - 1) / lanes;
+                for (int base = 0; base < n_frames && rc == KBE_OK; base += group * lanes)
                     for (int l = 0; l < lanes && rc == KBE_OK; l++) {
                         int idx[KBE_FRAME_JOBS], count = 0;
                         uint8_t* outs[KBE_FRAME_JOBS];
-                        for (int m = 0; m < (KBE_HBM_CONSECUTIVE ? per : group); m++) {
-                            const int i = KBE_HBM_CONSECUTIVE ? base + l * per + m : base + m * lanes + l;
+                        for (int m = 0; m < group; m++) {
+                            const int i = KBE_HBM_CONSECUTIVE ? base + l * group + m : base + m * lanes + l;
                             if (i < n_frames) { idx[count] = i; outs[count++] = host_out + (size_t) i * fb; }
                         }
                         if (count) rc = render_group(l, count, idx, outs);
                     }
-                }
             }
         } else
         for (int i = 0; i < n_frames && rc == KBE_OK; i++) rc = render(i, i % lanes, host_out + (size_t) i * fb);
