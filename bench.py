@@ -794,11 +794,16 @@ def main():
     # own time per pass and what that is on its PCIe link -- a node where one rank's link or socket lags shows here, not in the max
     rank_rows = None
     if world_size > 1:
-        mine = {'rank': rank, 'device': dev_index, 'numa_node': numa_node, 'numa': sharding.NUMA_BIND['reason'], 'frames': n_mine,
-                'ms_per_pass': round(own_elapsed * 1e3, 4),
-                'pcie_GBs': None if args.device_only else round(n_mine * size * size * 3 / own_elapsed / 1e9, 2)}
-        rank_rows = [None] * world_size
-        dist.all_gather_object(rank_rows, mine)
+        # (one all_gather of six numbers per rank on the collectives' own device -- the kind of call the timed region's max-reduction makes --
+        # rather than a pickled object: the path must hold under RCCL on a node nobody has run it on)
+        mine = torch.tensor([rank, dev_index, -1 if numa_node is None else numa_node, sharding.NUMA_BIND['code'], n_mine, own_elapsed], dtype=torch.float64, device=device)
+        rows = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(rows, mine)
+        rank_rows = []
+        for row in rows:
+            r, d, node, code, frames, secs = row.cpu().tolist()
+            rank_rows.append({'rank': int(r), 'device': int(d), 'numa_node': None if node < 0 else int(node), 'numa': sharding.NUMA_CODES.get(int(code), '?'), 'frames': int(frames),
+                              'ms_per_pass': round(secs * 1e3, 4), 'pcie_GBs': None if args.device_only else round(frames * size * size * 3 / max(secs, 1e-12) / 1e9, 2)})
 
     if rank == 0:
         from ken_burns_effect_amd import _native

@@ -21,7 +21,11 @@ _CLOUD_KEYS = ('tensorInpaPoints', 'tensorInpaImage', 'tensorInpaDepth')
 _SCALAR_KEYS = ('dblFocal', 'dblBaseline', 'intWidth', 'intHeight')
 
 
-NUMA_BIND = {'node': None, 'reason': 'not attempted'}     # what the last bind_to_gpu_numa_node call did (tools/scale_report.py prints it per rank)
+# what the last bind_to_gpu_numa_node call did: the node, a code (NUMA_CODES: what travels between ranks as a number) and the words for it
+NUMA_CODES = {0: 'bound to the CPUs of its node', 1: 'not attempted', 2: 'no PCI address for the device', 3: 'no numa_node entry for the device in /sys',
+              4: 'the kernel reports no NUMA node for the device (a single-node host, or a virtual function)',
+              5: "none of the node's CPUs is in the process's affinity mask (a cpuset from the launcher)", 6: 'the topology could not be read'}
+NUMA_BIND = {'node': None, 'code': 1, 'reason': NUMA_CODES[1]}
 
 
 def bind_to_gpu_numa_node(device_index):
@@ -31,20 +35,21 @@ def bind_to_gpu_numa_node(device_index):
     links.  Returns the node number, or None when the topology cannot be read (then nothing is changed) -- and says which of
     the two it was, and why, in ``NUMA_BIND`` (a rank that could not bind is reported by the bench line and by
     tools/scale_report.py instead of passing silently: VERDICT r5 item 7)."""
-    def done(node, reason):
-        NUMA_BIND['node'], NUMA_BIND['reason'] = node, reason
+    def done(node, code, detail=''):
+        NUMA_BIND['node'], NUMA_BIND['code'] = node, code
+        NUMA_BIND['reason'] = NUMA_CODES[code] + (' (%s)' % detail if detail else '')
         return node
     try:
         props = torch.cuda.get_device_properties(device_index)
         bdf = '%04x:%02x:%02x.0' % (getattr(props, 'pci_domain_id', 0), props.pci_bus_id, props.pci_device_id)
     except Exception as e:
-        return done(None, 'no PCI address for device %r (%s)' % (device_index, type(e).__name__))
+        return done(None, 2, 'no PCI address for device %r: %s' % (device_index, type(e).__name__))
     try:
         node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
     except Exception as e:
-        return done(None, 'no /sys/bus/pci/devices/%s/numa_node (%s)' % (bdf, type(e).__name__))
+        return done(None, 3, '%s: %s' % (bdf, type(e).__name__))
     if node < 0:
-        return done(None, 'the kernel reports no NUMA node for %s (a single-node host, or a virtual function)' % bdf)
+        return done(None, 4, bdf)
     try:
         cpus = set()
         for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
@@ -52,11 +57,11 @@ def bind_to_gpu_numa_node(device_index):
             cpus.update(range(int(lo), int(hi or lo) + 1))
         allowed = cpus & os.sched_getaffinity(0)
         if not allowed:
-            return done(None, "none of node %d's CPUs is in this process's affinity mask (a cpuset from the launcher)" % node)
+            return done(None, 5, 'node %d' % node)
         os.sched_setaffinity(0, allowed)
-        return done(node, 'bound to %d CPUs of node %d' % (len(allowed), node))
+        return done(node, 0, '%d CPUs of node %d' % (len(allowed), node))
     except Exception as e:
-        return done(None, 'node %d: %s' % (node, type(e).__name__))
+        return done(None, 6, 'node %d: %s' % (node, type(e).__name__))
 
 
 def world():

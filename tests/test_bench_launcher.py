@@ -105,4 +105,5 @@ def test_numa_binding_says_what_it_did(monkeypatch):
     sys.path.insert(0, ROOT)
     from ken_burns_effect_amd import sharding
     assert sharding.bind_to_gpu_numa_node(0) is None             # no GPU here: no PCI address
-    assert sharding.NUMA_BIND['node'] is None and 'PCI address' in sharding.NUMA_BIND['reason']
+    assert sharding.NUMA_BIND['node'] is None and sharding.NUMA_BIND['code'] == 2 and 'PCI address' in sharding.NUMA_BIND['reason']
+    assert sharding.NUMA_CODES[sharding.NUMA_BIND['code']] in sharding.NUMA_BIND['reason']
