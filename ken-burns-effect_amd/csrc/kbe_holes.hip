@@ -231,7 +231,7 @@ __device__ void build_strips(const int4* __restrict__ bbox, const uint32_t* __re
     const int wpr = (W + 31) >> 5;
     const bool rows_cross = fabsf(uy) >= 1.0e-6f;               // else: a horizontal direction, a strip is whole rows
     const float inv_uy = rows_cross ? 1.0f / uy : 0.0f;
-    static_assert(TW == 32 && TH == 16, "a tile row is one word of the validity bitmask, a tile sixteen of them");
+    static_assert(TW == 32 && TH <= 16, "a tile row is one word of the validity bitmask, a tile at most sixteen of them");
     // the strip's extent along a over the rows (columns) b0 .. b1 -- steep: c = -uy x + ux y => x = (ux y - c) / uy; flat: y = (c + uy x) / ux
     const auto along = [&](float b0, float b1, float& a0, float& a1) {
         const float v0 = steep ? (ua * b0 - c0) * inv : (c0 + ua * b0) * inv, v1 = steep ? (ua * b0 - c1) * inv : (c1 + ua * b0) * inv;
