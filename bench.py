@@ -80,13 +80,18 @@ KERNEL_SOURCES = ('kbe_fused.hip', 'kbe_frame.hip', 'kbe_tiles.h', 'kbe_device.h
 
 
 def kernel_sources_stamp():
-    """sha256 (16 hex digits) of the scatter's kernel sources as they lie in the tree: what a committed PMC file says it was measured
-    on (`sources_sha16`, written by the tools/pmc_*report.py that produce it).  The GPU box has no .git: a content hash travels."""
+    """sha256 (16 hex digits) of the scatter's kernel sources as they lie in the tree -- their CODE: comments and white space are taken
+    out first, so that a reworded comment does not disown a measurement -- what a committed PMC file says it was measured on
+    (`sources_sha16`, written by the tools/pmc_*report.py that produce it).  The GPU box has no .git: a content hash travels."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc', name), 'rb') as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc', name), 'r', encoding='utf-8', errors='replace') as f:
+            text = f.read()
+        text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)          # block comments
+        text = re.sub(r'//[^\n]*', ' ', text)                       # line comments (no string literal of these files holds "//")
+        h.update(re.sub(r'\s+', ' ', text).encode())
     return h.hexdigest()[:16]
 
 

@@ -38,7 +38,7 @@ FUSED_DENSE = 1.5                # "denser than the raster" from here on: delive
 FUSED_HOST_GROUP = 12  # frames per launch of the fused scatter when the frames are delivered to host memory (KBE_FILL_GROUP overrides): as many as a
                        # launch's 4 KB of kernel arguments hold.  A launch alone on a stream costs ~5 us besides its frames (ramp and tail: 8 / 12
                        # frames per launch 16.5 / 16.1 us per frame), and delivered to host memory -- the link binds -- a video runs at the same rate
-                       # with 8 or 12 (17.4-17.6 k frames/s, --steps 75 16.1-16.3 k, --steps 20 13.8-13.9 k either way: tools/gpu_r04_group12.sh)
+                       # with 8 or 12 (17.4-17.6 k frames/s, --steps 75 16.1-16.3 k, --steps 20 13.8-13.9 k either way: tools/batches/gpu_r04_group12.sh)
 DEFAULT_FILL_GROUP = 4 # frames a lane fills per launch when the table-driven fill is on (env KBE_FILL_GROUP, 1..4)
 PROBE_MIN_FRAMES = 128 # delivered videos from this length on have their lanes measured (HipKernels.delivery_lanes); shorter ones take the a-priori estimate
 DEFAULT_HOST_LANES = 2 # of those, the lanes used when the frames are delivered to pinned host memory AND the link binds (host_lanes below)
@@ -60,7 +60,7 @@ def lane_streams_of(device, n):
     """n streams for the lanes of the frame loop beside the caller's stream, one set per device for the life of the process: torch's own
     streams.  KBE_LANE_PRIORITY=1 (dev) makes them LOW-priority HIP streams: lane 0 -- the caller's stream -- renders a video's FIRST
     frame, which every byte of a short delivered video waits for, while lane 1 already renders the second group next to it; with the
-    other lanes below it the first frame has the chip when both want it (tools/gpu_r05_prio.sh, three processes each, k frames/s
+    other lanes below it the first frame has the chip when both want it (tools/batches/gpu_r05_prio.sh, three processes each, k frames/s
     delivered: 20 frames 14.95 -> 15.02, 16 frames 14.28 -> 14.40; high-priority lanes 14.83 / 14.25; long videos and frames left in
     HBM: no difference).  NOT the default: with several processes on one GPU (tests/test_hip_parity.py: four ranks next to the test
     process) the low-priority queues are scheduled erratically -- passes of 3.5 to 24.6 ms where torch's streams give 7.0 +- 0.4."""
@@ -89,13 +89,13 @@ def transfer_group(n_frames, lanes, launch_group, fast_ramp=False):
     the video between 64 and 128 frames, 16 below.  More lanes -- the rendering binds, not the link (delivery_lanes): a
     lane then waits for nothing but its own last transfer, and what a video loses is its END -- the lanes' last groups leave one after
     the other when nothing is left to render, and groups of 32 deal the frames unevenly to four lanes: a transfer group is what ONE
-    scatter launch renders (`launch_group`).  Measured (tools/gpu_r05_dolly_batch.sh, profiles/r05_transfer_groups.txt): bench --dolly,
+    scatter launch renders (`launch_group`).  Measured (tools/batches/gpu_r05_dolly_batch.sh, profiles/r05_transfer_groups.txt): bench --dolly,
     256 frames, k frames/s delivered with groups of up to 32 / 16 / 12 / 8 frames 10.2 / 10.7 / 10.7 / 11.4 (left in HBM: 13.0);
     configs[4], 64 frames, groups of 32 / 2: 2.2 / 3.0 k."""
     if lanes > DEFAULT_HOST_LANES:
         return -max(1, int(launch_group))
     # (the ramp is never cut below 16: until late in round 5 a short video's cap was n / 4 alone -- "small enough for each lane to have two
-    # groups of full size", a rule from the blit hand-off's days; with the SDMA engine a transfer fewer is worth more: tools/gpu_r05_short_batch.sh,
+    # groups of full size", a rule from the blit hand-off's days; with the SDMA engine a transfer fewer is worth more: tools/batches/gpu_r05_short_batch.sh,
     # k frames/s delivered with the old cap / 8 / 16: 16 frames 13.8-13.9 / 14.3 / 14.3, 20 frames 14.8 / 14.9 / 14.9, 30 frames 15.5 / 15.4 / 15.65; 40, 75: equal)
     return -max(1, min(32, max(n_frames // (2 * lanes), 16, (n_frames + 1) // 2 if fast_ramp else 0)))
 
@@ -590,7 +590,7 @@ class HipKernels:
                 # delivered frame with 8 / 4 / 2 frames per launch on four lanes: 446 / 422 / 395.  Round 6, SDMA hand-off, frames/s delivered /
                 # left in HBM with 2 / 3 / 4 / 6 / 8: 2 948 / 3 234, 2 941 / 3 246, 2 707 / 3 141, 2 598 / 2 999, 2 390 / 2 974 -- and the launch
                 # alone on a stream 289.5 / 273.8 / 269.1 / 265.6 / 263.7 us per frame (its tail amortised): three is as fast as two for the
-                # video and 5 % faster per launch (tools/gpu_r06_config4_groups.sh, profiles/r06_config4_groups.txt)
+                # video and 5 % faster per launch (tools/batches/gpu_r06_config4_groups.sh, profiles/r06_config4_groups.txt)
                 group = 3
         else:
             # the bucket route (measured, us per frame with 1 / 2 / 4 frames per launch: 256^2 13.3 / 9.8 / 6.2, 512^2 13.7 / 9.8 /

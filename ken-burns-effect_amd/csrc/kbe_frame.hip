@@ -1549,7 +1549,7 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             // it (consecutive cameras share candidate lists, kbe_fused.hip: share_plan; until round 5 lane l took frames l, l + lanes,
             // ...: cameras `lanes` steps apart in every launch).  The last, partial chunk fills the lanes one after the other, `group`
             // frames each.  (ADVICE r5 proposed to deal it evenly, ceil(remaining / lanes) frames per lane, so that every lane has work:
-            // measured in round 6 -- tools/gpu_r06_tail.sh, frames/s left in HBM, lane by lane / evenly: 6 frames 26.5 / 26.4 k, 8: 29.5 /
+            // measured in round 6 -- tools/batches/gpu_r06_tail.sh, frames/s left in HBM, lane by lane / evenly: 6 frames 26.5 / 26.4 k, 8: 29.5 /
             // 29.5, 12: 33.5 / 33.4, 20: 35.9 / 33.9, 24: 37.6 / 35.5, 30: 38.2 / 37.7, 40: 39.8 / 39.6 -- never faster, 5 % slower
             // where it turns one four-frame launch into four one-frame launches: a launch's ramp and tail cost more than the idle lanes.)
             // (A first pass counts the frames of every scratch set: the bucket route must know a set's last frame.)

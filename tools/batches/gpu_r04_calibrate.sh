@@ -2,7 +2,7 @@
 # GPU box (round 4): the chip's VALU issue rate per kind of instruction (tools/valu_rate.hip), what the SQ
 # counters read on those known instruction streams, the scatter launches alone on a stream (tools/ahead_time.py) and the busy /
 # wait PMC passes over the same launches.  Everything lands in gpurun_out/r04/.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r04_calibrate.sh'
+#   gpurun --timeout 1500 -- 'bash tools/batches/gpu_r04_calibrate.sh'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box (round 4): delivered videos with a switch of the hand-off on and off (arguments: the environment settings to compare)
-#   bash tools/gpu_r04_groups2.sh "KBE_EARLY_TURN=0" "KBE_EARLY_TURN=1"
+#   bash tools/batches/gpu_r04_groups2.sh "KBE_EARLY_TURN=0" "KBE_EARLY_TURN=1"
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box (round 4): the scatter alone on a stream (tools/ahead_time.py, 8 and 12 frames per launch shown) for prebuilt libraries
 # (_variants/NAME.so, built here beforehand: e.g. the round's starting point) and for variant builds (quoted extra hipcc flags).
-#   gpurun -- 'bash tools/gpu_r04_variants.sh head.so "" "-DKBE_FRAME_WAVES=6 -DKBE_TILE_CAP=704"'
+#   gpurun -- 'bash tools/batches/gpu_r04_variants.sh head.so "" "-DKBE_FRAME_WAVES=6 -DKBE_TILE_CAP=704"'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: round 5's profile artefacts, written under gpurun_out/$1 (copy what is to be judged into profiles/).  As tools/gpu_profile.sh,
 # with the scatter's launch traced and counted on CONSECUTIVE cameras of the product's 75-step path.
-#   gpurun --timeout 3000 -- 'bash tools/gpu_r05_profile.sh r05p'
+#   gpurun --timeout 3000 -- 'bash tools/batches/gpu_r05_profile.sh r05p'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-r05p}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 6: configs[4] (2048^2, 16.8 M points) by frames per scatter launch -- the rule "two per launch for dense clouds delivered to the
 # host" dates from the blit hand-off (round 4: 446 / 422 / 395 us per delivered frame with 8 / 4 / 2); with the SDMA engine no copy kernel sits next to the launches
-#   gpurun --timeout 1200 -- 'bash tools/gpu_r06_config4_groups.sh r06b'
+#   gpurun --timeout 1200 -- 'bash tools/batches/gpu_r06_config4_groups.sh r06b'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-r06b}

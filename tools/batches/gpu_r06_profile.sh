@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: round 6's profile artefacts, written under gpurun_out/$1 (copy what is to be judged into profiles/).  As tools/gpu_profile.sh,
 # with the scatter's launch traced and counted on CONSECUTIVE cameras of the product's 75-step path.
-#   gpurun --timeout 3000 -- 'bash tools/gpu_r06_profile.sh r06p'
+#   gpurun --timeout 3000 -- 'bash tools/batches/gpu_r06_profile.sh r06p'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-r06p}
@@ -62,7 +62,7 @@ KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --n
 KBE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 $R/bench.py --gpus 2 --video-frames 128 --warmup 8 2>> $OUT/bench.err | tail -1 > $OUT/bench_video128_2ranks_gloo_one_gpu.json
 # 5b. the one command for a multi-GPU node, as a dry run on this box's one GPU (ranks share it, collectives on gloo: no curve)
 timeout 900 python $R/tools/scale_report.py --gpus 1,2 --dry-run --out $OUT/scale_report_dry_run.json > $OUT/scale_report_dry_run.txt 2>> $OUT/bench.err
-# 5c. configs[4] under the counters (HBM bytes per point of the dense launch; the shape tools/gpu_r05_seventh.sh collected it in)
+# 5c. configs[4] under the counters (HBM bytes per point of the dense launch; the shape tools/batches/gpu_r05_seventh.sh collected it in)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pd_$c
   SIZE=2048 UPSAMPLE=2 CLOUD=raw KBE_LANES=1 FRAMES=18 REPS=1 timeout 400 rocprofv3 --pmc $c -d /tmp/pd_$c -o c --output-format csv -- python $R/tools/throughput.py > /tmp/pd.log 2>&1 || tail -3 /tmp/pd.log

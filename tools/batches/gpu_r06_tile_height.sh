@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 6: the fused scatter on 32 x 8 tiles (KBE_TILE_H=8: one pixel per thread, ~300 records per tile -- no second rounds at one
 # point per pixel, more halo per pixel) against 32 x 16; variant libraries built by tools/build_variants.sh
-#   gpurun --timeout 2400 -- 'bash tools/gpu_r06_tile_height.sh r06t "th8 th8c384 th8c384w7 th8c320w8 wide0"'
+#   gpurun --timeout 2400 -- 'bash tools/batches/gpu_r06_tile_height.sh r06t "th8 th8c384 th8c384w7 th8c320w8 wide0"'
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-r06t}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Here (no GPU): variant libraries for tools/gpu_r04_variants.sh, one per "name=flags" argument, into _variants/ (git-ignored; they
+# Here (no GPU): variant libraries for tools/batches/gpu_r04_variants.sh, one per "name=flags" argument, into _variants/ (git-ignored; they
 # travel to the GPU box with the snapshot).   bash tools/build_variants.sh "head=-DKBE_XCD_ROT=0 -DKBE_LATE_ARGS=0" "tree="
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/_variants

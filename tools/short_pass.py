@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders a FRAMES-frame delivered video of the bench cloud PASSES times, a host synchronisation between the passes (dev aid: the
-workload tools/gpu_r05_timeline.sh traces; tools/sdma_timeline.py lays the last pass out)."""
+workload tools/batches/gpu_r05_timeline.sh traces; tools/sdma_timeline.py lays the last pass out)."""
 import os
 import sys
 import time
