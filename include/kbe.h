@@ -394,15 +394,20 @@ KBE_API size_t kbe_video_stage_bytes(int W, int H, int lanes, int batch);
  * clean-up a real failure takes (tests/test_hip_parity.py: the next video in the process is delivered intact, nothing is written into
  * the failed call's buffer after it has returned).  Costs nothing when not set. */
 #define KBE_VIDEO_INJECT_FAULT 32768
+/* TEST HOOK (with KBE_VIDEO_SDMA): the kernels that wait for the lanes' LAST groups to have left give up after one tick of the wall clock
+ * instead of seconds -- the path an engine that stops answering takes: the error word is set, kbe_video_handoff_status() reports it once
+ * (after waiting on the host for the copies, which here do complete), the engine stays off for the process. */
+#define KBE_VIDEO_INJECT_TIMEOUT 65536
 KBE_API int kbe_render_video(const float* points, const float* image, const float* depth, int N, int W, int H,
                              double baseline, int n_frames, const double* focals, const float* shifts, int crop_w,
                              int crop_h, void* scratch, uint8_t* stage, int batch, uint8_t* host_out,
                              int raster_w, int raster_n, const void* packed, double cloud_focal, int flags,
                              kbe_stream_t stream, kbe_stream_t copy_stream, int lanes, const kbe_stream_t* lane_streams,
                              double near_depth);
-/* KBE_OK, or KBE_E_LAUNCH once a KBE_VIDEO_SDMA hand-off of this process has given up waiting for its engine (sticky: the engine is not
- * used again; kbe_last_error says so).  Call it after synchronising the stream a delivered video was enqueued on: on the error it first
- * waits on the host, for seconds at most, for the copies that may still be under way, so that the caller can free its buffer afterwards. */
+/* KBE_OK, or -- ONCE -- KBE_E_LAUNCH after a KBE_VIDEO_SDMA hand-off of this process has given up waiting for its engine (kbe_last_error
+ * says so; the engine is not used again: later videos leave through hipMemcpyAsync, complete, and this call says KBE_OK for them).  Call it
+ * after synchronising the stream a delivered video was enqueued on: on the error it first waits on the host, for seconds at most, for the
+ * copies that may still be under way, so that the caller can free its buffer afterwards. */
 KBE_API int kbe_video_handoff_status(void);
 
 /* generate_mask's kernel (common.py:689-817; the median-5 of :829 is kbe_spatial_filter): masks[B,N] = 1 where

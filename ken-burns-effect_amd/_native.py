@@ -738,6 +738,8 @@ class HipKernels:
             flags |= 8192                                   # KBE_VIDEO_SDMA
             if os.environ.get('KBE_INJECT_HANDOFF_FAULT') == '1':
                 flags |= 32768                              # KBE_VIDEO_INJECT_FAULT (test hook: tests/test_hip_parity.py)
+            if os.environ.get('KBE_INJECT_HANDOFF_TIMEOUT') == '1':
+                flags |= 65536                              # KBE_VIDEO_INJECT_TIMEOUT (test hook)
         keep_flags = flags & ~base_flags                    # the switches set above, should the launch shape be taken again
         scratch = state['scratch']
         if group > 1:

@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(64) k_signal_wait(volatile int64_t* value, uns
         if (__hip_atomic_load((int64_t*) value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= 0) return;
         __builtin_amdgcn_s_sleep(16);
     } while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks);
-    __hip_atomic_store(gave_up, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(gave_up, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (1 = not yet reported: kbe_video_handoff_status)
 }
 #ifndef KBE_SDMA_WAIT_SECONDS
 #define KBE_SDMA_WAIT_SECONDS 4.0
@@ -1698,7 +1698,8 @@ int kbe_render_video(const float* points, const float* image, const float* depth
             }
             // (SDMA) a lane is done when its last group has left: whoever waits for the lanes (join) waits for the frames
             for (int l = 0; l < lanes; l++)
-                if (lane_fin[l] && rc == KBE_OK) hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], sdma_pool().wait_ticks, sdma_pool().gave_up);
+                if (lane_fin[l] && rc == KBE_OK)            // (KBE_VIDEO_INJECT_TIMEOUT: one tick of patience -- the give-up path, for its test)
+                    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, ls[l], lane_fin[l], (flags & KBE_VIDEO_INJECT_TIMEOUT) ? 1ull : sdma_pool().wait_ticks, sdma_pool().gave_up);
 #if defined(KBE_VIDEO_GPU_TRACE)
             for (int l = 0; l < lanes; l++) (void) hipStreamSynchronize(ls[l]);
             for (int g = 0; g < n_groups && rc == KBE_OK; g++) {
@@ -1749,7 +1750,11 @@ int kbe_video_handoff_status(void)
 {
     SdmaPool& pool = sdma_pool();
     std::unique_lock<std::mutex> lock(pool.mu);
-    if (!pool.gave_up || __atomic_load_n(pool.gave_up, __ATOMIC_ACQUIRE) == 0) return KBE_OK;
+    // the word: 0 = nothing happened, 1 = a polling kernel gave up (not yet reported), 2 = reported -- the engine stays off either way
+    // (sdma_open looks for != 0), but the error is this call's to report ONCE: the videos after it leave through the runtime's transfers
+    // and are complete, their callers must not be told otherwise
+    if (!pool.gave_up || __atomic_load_n(pool.gave_up, __ATOMIC_ACQUIRE) != 1) return KBE_OK;
+    __atomic_store_n(pool.gave_up, 2, __ATOMIC_RELEASE);
     pool.state = -1;                                    // no more copies through the engine
     // the copies of calls that are still on record may yet complete: wait for them here, so that the caller may free its buffers
     std::vector<SdmaGeneration> gens;
