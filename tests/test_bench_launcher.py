@@ -107,3 +107,34 @@ def test_numa_binding_says_what_it_did(monkeypatch):
     assert sharding.bind_to_gpu_numa_node(0) is None             # no GPU here: no PCI address
     assert sharding.NUMA_BIND['node'] is None and sharding.NUMA_BIND['code'] == 2 and 'PCI address' in sharding.NUMA_BIND['reason']
     assert sharding.NUMA_CODES[sharding.NUMA_BIND['code']] in sharding.NUMA_BIND['reason']
+
+
+def test_pmc_figures_are_quoted_only_from_files_measured_on_these_kernel_sources(tmp_path, monkeypatch, capsys):
+    """VERDICT r5 "weak" 7: `roofline.traffic` was a constant read from a committed PMC file and would go stale silently when the kernel
+    changed.  The report tools now stamp their JSON with a hash of the kernel sources' CODE (comments and white space taken out), bench.py
+    quotes a file only while its stamp is the tree's, and says on stderr when it leaves one out."""
+    import json
+    import shutil
+    import bench
+    src = os.path.join(ROOT, 'ken-burns-effect_amd', 'csrc')
+    fake = tmp_path / 'repo'
+    (fake / 'ken-burns-effect_amd' / 'csrc').mkdir(parents=True)
+    (fake / 'profiles').mkdir()
+    for name in bench.KERNEL_SOURCES:
+        shutil.copy(os.path.join(src, name), str(fake / 'ken-burns-effect_amd' / 'csrc' / name))
+    monkeypatch.setattr(bench, 'ROOT', str(fake))
+    stamp = bench.kernel_sources_stamp()
+    assert stamp == bench.kernel_sources_stamp() and len(stamp) == 16
+    target = fake / 'ken-burns-effect_amd' / 'csrc' / 'kbe_tiles.h'
+    text = target.read_text()
+    target.write_text('// a reworded comment\n/* and a block\n   of them */\n' + text.replace('\n', '\n   \n', 3))
+    assert bench.kernel_sources_stamp() == stamp, 'comments and white space are not code'
+    doc = {'kernels': {'k_frame': {'hbm_bytes': 1.0}}, 'by_frames_per_launch': {}, 'sources_sha16': stamp}
+    (fake / 'profiles' / 'r09_hbm_traffic.json').write_text(json.dumps(doc))
+    per, where = bench.measured_traffic()
+    assert per['k_frame'] == 1.0 and where.endswith('r09_hbm_traffic.json')
+    target.write_text(text.replace('constexpr int CNT_STRIDE = 32;', 'constexpr int CNT_STRIDE = 64;'))
+    assert bench.kernel_sources_stamp() != stamp, 'a changed constant is code'
+    assert bench.measured_traffic() == ({}, None) and 'left out of the line' in capsys.readouterr().err
+    (fake / 'profiles' / 'r09_hbm_traffic.json').write_text(json.dumps({'kernels': {'k_frame': {'hbm_bytes': 1.0}}}))        # a file from before the stamp existed
+    assert bench.measured_traffic() == ({}, None)

@@ -335,3 +335,22 @@ def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     monkeypatch.setenv('KBE_FILL_DIST', '0')
     assert shape(raw, zoom) == (2 << 1, 3, True)
     assert shape(dict(raw, fused=False), zoom) == (2 << 1, 3, False), 'the route is the state\'s (prepare_cloud: KBE_FUSED=0 / 1 force it there)'
+
+
+def test_degrid_schedule_switch_selects_the_serial_route(monkeypatch):
+    """KBE_DEGRID (round 6): jacobi -- the fused tile launch, the default -- or serial: the same HIP library behind the stage-by-stage
+    kernel set that reproduces a serial execution of the reference (no render_video: the frame loop goes frame by frame).  Read per call."""
+    from ken_burns_effect_amd import _native
+    monkeypatch.delenv('KBE_DEGRID', raising=False)
+    default = _native.kernels()
+    assert isinstance(default, _native.HipKernels) and _native.degrid_schedule() == 'jacobi'
+    monkeypatch.setenv('KBE_DEGRID', 'serial')
+    serial = _native.kernels()
+    assert isinstance(serial, _native.HipSerialScheduleKernels) and serial.K is default and serial.name == 'hip-serial'
+    assert not hasattr(serial, 'render_video') and serial.lib is default.lib                      # everything else is the library's
+    assert _native.kernels() is serial                                                             # one per process
+    monkeypatch.setenv('KBE_DEGRID', 'gauss-seidel')
+    with pytest.raises(_native.KbeError):
+        _native.kernels()
+    monkeypatch.delenv('KBE_DEGRID')
+    assert _native.kernels() is default
