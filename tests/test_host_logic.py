@@ -325,6 +325,10 @@ def test_video_launch_shape_by_frame_size_and_camera(monkeypatch):
     assert shape(raw, zoom) == (1 | (7 << 5), 8, True)
     assert shape(raw, zoom, batch=8) == (1, 1, True), 'the staged ring renders one frame per launch'
     assert shape({'W': 512, 'H': 512, 'N': 300000, 'cloud_focal': 512.0, 'fused': True}, still) == (3 << 1, 4, True)
+    # a cloud denser than the raster on the fused route (configs[4]: 16.8 M points at 2048^2): three frames per launch, delivered or left in
+    # HBM (two until round 6, from the blit hand-off's days: profiles/r06_config4_groups.txt)
+    config4 = {'W': 2048, 'H': 2048, 'N': 4 * 2048 * 2048, 'cloud_focal': 1024.0, 'fused': True}
+    assert shape(config4, still, to_host=True) == (2 << 1, 3, True) and shape(config4, still) == (2 << 1, 3, True)
     # the bucket route (a cloud denser than the raster: prepare_cloud leaves `fused` off)
     dense = lambda size, n: {'W': size, 'H': size, 'N': n, 'cloud_focal': 512.0, 'fused': False}    # noqa: E731
     assert shape(dense(1024, 4 << 20), still) == (0, 1, False)
