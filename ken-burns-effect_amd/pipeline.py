@@ -272,14 +272,20 @@ def _jpegs(frames_rgb, quality):
         import ctypes
         arrays = [np.ascontiguousarray(f, dtype=np.uint8) for f in distinct]
         h, w = arrays[0].shape[:2]
-        n, cap = len(arrays), int(lib.kbe_jpeg_bound(w, h))
-        outs = [np.empty(cap, np.uint8) for _ in range(n)]
-        got = (ctypes.c_size_t * n)()
-        rc = lib.kbe_jpeg_encode_batch((ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays]), n, w, h, 3 * w, int(quality),
-                                       (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs]), ctypes.c_size_t(cap), got, _writer_pool_size(n))
-        if rc != 0:
-            raise RuntimeError('kbe_jpeg_encode_batch: %d' % rc)
-        encoded = [outs[i][:got[i]].tobytes() for i in range(n)]
+        cap = int(lib.kbe_jpeg_bound(w, h))
+        # (the output buffers are worst-case sized -- 6 MB for a 1024^2 frame -- and reused: batches of at most ~256 MB of them)
+        per = max(1, min(len(arrays), (256 << 20) // cap))
+        outs = [np.empty(cap, np.uint8) for _ in range(per)]
+        encoded = []
+        for at in range(0, len(arrays), per):
+            part = arrays[at:at + per]
+            n = len(part)
+            got = (ctypes.c_size_t * n)()
+            rc = lib.kbe_jpeg_encode_batch((ctypes.c_void_p * n)(*[a.ctypes.data for a in part]), n, w, h, 3 * w, int(quality),
+                                           (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs[:n]]), ctypes.c_size_t(cap), got, _writer_pool_size(n))
+            if rc != 0:
+                raise RuntimeError('kbe_jpeg_encode_batch: %d' % rc)
+            encoded += [outs[i][:got[i]].tobytes() for i in range(n)]
     else:
         import io
         from PIL import Image
